@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""
+Headline benchmark of the DPP hot path (BASELINE.json): DoF/s over assemble + solve on the 3D
+UnitCube Q1 two-pressure problem, solved by block Picard (fixed-stress) sweeps whose block solves
+are multigrid-preconditioned CG on the CSR blocks.
+
+One "step" = one pass of the hot path on inputs resident in HBM: integrate K and M (cell kernels +
+scatter-add), eliminate Dirichlet dofs / form the DPP blocks and the lifted right-hand side, run the
+Picard solve to snes_rtol 1e-8.  The mesh connectivity / CSR pattern and the boundary data are built
+before the timed region, like the mesh construction that precedes the reference's timing window
+(reference src/perphil/experiments/petsc_profiling_3d.py:57 vs :82-86).
+
+    python bench.py --gpus 1 --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (CSR SpMV kernel,
+HIP events per launch on the solver's stream, algorithmic bytes 12 nnz + 20 nrows) and
+`cpu_baseline` (the NumPy/SciPy oracle of the same algorithm on a bounded sample, 1 core).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def picard_cfg(_ffi, inner_rtol=1e-10, smooth=2):
+    cfg = _ffi.SolverCfg()
+    cfg.ksp_type, cfg.pc_type, cfg.restart, cfg.max_it = _ffi.KSP_GMRES, _ffi.PC_FIELDSPLIT, 30, 50000
+    cfg.rtol, cfg.atol = 1e-8, 1e-12
+    cfg.inner_ksp_type, cfg.inner_pc_type, cfg.inner_max_it = _ffi.KSP_CG, _ffi.PC_MG, 50000
+    cfg.inner_rtol, cfg.inner_atol = inner_rtol, 1e-300
+    cfg.picard, cfg.picard_rtol, cfg.picard_atol, cfg.picard_max_it = 1, 1e-8, 1e-12, 100
+    cfg.mg_smooth = smooth
+    return cfg
+
+
+def mms_boundary(n_cells, k1, k2, beta, mu):
+    """Boundary node ids and manufactured Dirichlet values of the global unit cube."""
+    from perphil_amd import fd
+    from perphil_amd.parameters import DPPParameters
+    from perphil_amd.manufactured_solutions import exact_expressions_3d
+
+    mesh = fd.UnitCubeMesh(n_cells, n_cells, n_cells, hexahedral=True)
+    b = mesh.boundary_nodes()
+    X = mesh.node_coordinates(b)
+    _, p1, _, p2 = exact_expressions_3d(mesh, DPPParameters(k1=k1, k2=k2, beta=beta, mu=mu))
+    return b, p1(X), p2(X)
+
+
+def cpu_baseline(sample_n, k1, k2, beta, mu):
+    """The oracle (CPU port of the same algorithm: assembly + Picard with multigrid-CG block solves)
+    timed on one host core on a smaller cube; returns DoF/s."""
+    from oracle import dpp_oracle as o
+    from oracle import dpp_mg_oracle as mgo
+
+    t0 = time.perf_counter()
+    P = o.Params(k1=k1, k2=k2, beta=beta, mu=mu)
+    om = o.build_mesh(3, o.CELL_HEX, sample_n, sample_n, sample_n)
+    t_mesh = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    osys = o.build_system(om, P)
+    n = osys.n
+    a, b, c = P.abc
+    mask = np.zeros(n, bool)
+    mask[o.boundary_nodes(om)] = True
+    L1 = mgo.build_hierarchy(3, o.CELL_HEX, sample_n, sample_n, sample_n, a, b, mask)
+    L2 = mgo.build_hierarchy(3, o.CELL_HEX, sample_n, sample_n, sample_n, c, b, mask)
+    A = osys.A.tocsr()
+    A11, A12, A21, A22 = A[:n, :n], A[:n, n:], A[n:, :n], A[n:, n:]
+    rhs = osys.rhs
+    du = np.zeros(2 * n)
+    r0 = np.linalg.norm(rhs)
+    res, its = r0, 0
+    while res > max(1e-8 * r0, 1e-12) and its < 100:
+        x0 = du[:n].copy() if its else None
+        du[:n] = o.pcg(A11, rhs[:n] - A12 @ du[n:], lambda v: mgo.vcycle(L1, v, 2), rtol=1e-10, x0=x0).x
+        x0 = du[n:].copy() if its else None
+        du[n:] = o.pcg(A22, rhs[n:] - A21 @ du[:n], lambda v: mgo.vcycle(L2, v, 2), rtol=1e-10, x0=x0).x
+        its += 1
+        res = np.linalg.norm(rhs - A @ du)
+    t = time.perf_counter() - t0
+    return {"value": 2 * n / t, "unit": "DoF/s", "cores": 1, "kind": "port",
+            "sample": f"{sample_n}^3 Q1 unit cube ({2 * n} DoF), assemble + Picard ({its} sweeps) with multigrid-CG "
+                      f"block solves in NumPy/SciPy, {t:.1f} s (mesh build {t_mesh:.1f} s excluded)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=256, help="cells per direction of the unit cube")
+    ap.add_argument("--cpu-sample-n", type=int, default=48)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inner-rtol", type=float, default=1e-10)
+    ap.add_argument("--smooth", type=int, default=2)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+
+    import torch  # device selection, barrier, synchronize: plumbing only
+    from perphil_amd import _ffi
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist  # noqa: F811
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    N = args.n
+    k1, k2, beta, mu = 1.0, 1e-2, 1.0, 1.0
+
+    if world > 1:
+        from perphil_amd.distributed import SlabSolver
+
+        solver = SlabSolver(N, world, rank, local_rank, k1, k2, beta, mu, inner_rtol=args.inner_rtol, smooth=args.smooth)
+        dofs_global = solver.global_dofs
+        step = solver.step
+        ctx = solver.ctx
+    else:
+        ctx = _ffi.Context(local_rank)
+        ctx.mesh_build(3, _ffi.CELL_HEX, N, N, N)
+        b, g1, g2 = mms_boundary(N, k1, k2, beta, mu)
+        ctx.set_dirichlet(0, b, g1)
+        ctx.set_dirichlet(1, b, g2)
+        cfg = picard_cfg(_ffi, args.inner_rtol, args.smooth)
+        dofs_global = 2 * ctx.n
+        last = {}
+
+        def step():
+            ctx.set_option("invalidate_KM", 1)          # integrate K and M again: assembly is part of the step
+            ctx.assemble(k1, k2, beta, mu, monolithic=False)
+            _, info, _ = ctx.solve(cfg, fetch=False)
+            last["info"] = info
+            return info
+
+    def fence():
+        torch.cuda.synchronize()
+        ctx.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        info = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tm = ctx.timers()
+
+    # ---- roofline of the dominant kernel: one more (untimed) step with an event pair around every
+    # SpMV launch on the solver's stream; bytes are algorithmic (12 nnz + 20 nrows per launch) --------
+    ctx.set_option("time_spmv", 1)
+    step()
+    ctx.synchronize()
+    tr = ctx.timers()
+    ctx.set_option("time_spmv", 0)
+    launches = tr["spmv_launches"] + tr["spmv_dot_launches"]
+    ms = tr["spmv_ms"] + tr["spmv_dot_ms"]
+    byts = tr["spmv_bytes"] + tr["spmv_dot_bytes"]
+    achieved = (byts / 1e9) / (ms / 1e3) if ms > 0 else 0.0
+    # fine-level scalar-block SpMV alone (the inner loop the 50 % target is stated on)
+    fine_ms = ctx.spmv_bench(_ffi.MAT_A11, 50)
+    fine_bytes = 12.0 * ctx.nnzb + 20.0 * ctx.n
+    roofline = {
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "kernel": "k_spmv<8,*> (CSR-vector SpMV, all multigrid levels of one step)",
+        "launches_per_step": int(launches), "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
+        "algorithmic_bytes_per_launch": round(byts / max(launches, 1), 0),
+        "fine_level": {"avg_launch_ms": round(fine_ms, 4), "algorithmic_bytes": fine_bytes,
+                       "achieved": round(fine_bytes / 1e9 / (fine_ms / 1e3), 1),
+                       "frac": round(fine_bytes / 1e9 / (fine_ms / 1e3) / HBM_PEAK_GBS, 4)},
+    }
+
+    out = {
+        "metric": "DoF/s (assemble+solve), 3D UnitCube Q1 DPP, Picard-split",
+        "value": dofs_global * args.steps / elapsed,
+        "unit": "DoF/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"3D UnitCube {N}^3 Q1, two-pressure DPP (k1=1, k2=1e-2, beta=mu=1), manufactured Dirichlet data, "
+                        f"assemble + block Picard (fixed-stress) to snes_rtol 1e-8, block solves = CG + geometric multigrid "
+                        f"(Chebyshev-Jacobi V({args.smooth},{args.smooth})) to rtol {args.inner_rtol:g} on CSR blocks",
+            "cells": N ** 3, "dofs": int(dofs_global), "parallelism": f"slab{world}" if world > 1 else "single",
+            "picard_sweeps": int(info.iterations), "inner_cg_iterations": int(info.inner_iterations),
+            "picard_ms_per_sweep": round(tm["solve_ms"] / max(int(info.iterations), 1), 3),
+            "assemble_ms": round(tm["assemble_ms"] + tm["bc_blocks_ms"], 3), "solve_ms": round(tm["solve_ms"], 3),
+            "final_residual": float(info.resnorm), "rhs_norm": float(info.rhs_norm),
+        },
+        "roofline": roofline,
+    }
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, k1, k2, beta, mu)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,171 @@
+/*
+ * perphil_hip.h — C ABI of the MI355X-native DPP hot path (libperphil_hip.so).
+ *
+ * The reference (ThermoPhase-FCSRG/perphil) exposes no FFI: its boundary for this path is the
+ * Python call  solve_dpp(W, model_params, bcs, solver_parameters, options_prefix) -> Solution
+ * (reference src/perphil/solvers/solver.py:30-76) whose arithmetic runs inside Firedrake/PETSc.
+ * This header declares what a ctypes binding of that call needs; each entry point cites the
+ * reference interface (or the third-party work triggered from it) that it replaces.
+ * perphil_amd/_ffi.py is the binding; INTEGRATION.md shows the stub a perphil maintainer adds.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative pph_status on failure; no exceptions and
+ *     no aborts cross this boundary; pph_last_error() returns a message for the last failure.
+ *   - the caller owns every host buffer it passes (borrowed for the duration of the call only);
+ *     the library owns all device memory behind the opaque handle; nothing returned by pointer
+ *     outlives pph_ctx_destroy().
+ *   - one host thread drives one context (not re-entrant); independent contexts are independent.
+ *   - numbering: node (i,j,k) -> i + (nx+1)*(j + (ny+1)*k) inside the LOCAL box of the context;
+ *     monolithic dof = field*n + node (field-major; reference
+ *     src/perphil/experiments/iterative_bench.py:323-324).
+ *   - all floating point is IEEE fp64; indices are int32 (columns, cell->dof map) / int64 (row
+ *     pointers, counts).
+ */
+#ifndef PERPHIL_HIP_H
+#define PERPHIL_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pph_ctx pph_ctx;
+
+typedef enum {
+  PPH_OK = 0,
+  PPH_ERR_INVALID = -1,   /* bad argument / call order          -> Python ValueError   */
+  PPH_ERR_HIP = -2,       /* HIP runtime failure                -> Python RuntimeError */
+  PPH_ERR_NOMEM = -3,     /* device or host allocation failed   -> Python MemoryError  */
+  PPH_ERR_DIVERGED = -4,  /* Krylov/Picard hit max_it or broke down (result still written) */
+  PPH_ERR_COMM = -5       /* RCCL failure                                              */
+} pph_status;
+
+/* cell kinds of the structured unit square / cube
+ * (reference src/perphil/mesh/builtin.py:20 -> fd.UnitSquareMesh quads / "left"-diagonal
+ *  triangles; src/perphil/experiments/petsc_profiling_3d.py:31 -> fd.UnitCubeMesh, 6 Kuhn tets
+ *  per cube; notebooks/condition-number-study-3d.py:66 -> hexahedral=True) */
+enum { PPH_CELL_QUAD = 0, PPH_CELL_TRI = 1, PPH_CELL_HEX = 2, PPH_CELL_TET = 3 };
+
+/* Krylov / preconditioner / outer-loop kinds: the supported subset of the PETSc option
+ * dictionaries in reference src/perphil/solvers/parameters.py:4-102 */
+enum { PPH_KSP_PREONLY = 0, PPH_KSP_CG = 1, PPH_KSP_GMRES = 2 };
+enum {
+  PPH_PC_NONE = 0,
+  PPH_PC_JACOBI = 1,      /* pc_type jacobi                                              */
+  PPH_PC_BLOCK2 = 2,      /* 2x2 node-block Jacobi (both pressures of one node coupled)    */
+  PPH_PC_FIELDSPLIT = 3,  /* pc_type fieldsplit, pc_fieldsplit_type multiplicative         */
+  PPH_PC_MG = 4           /* geometric multigrid V-cycle (scalar blocks; inside fieldsplit/Picard) */
+};
+
+typedef struct {
+  int32_t ksp_type;      /* PPH_KSP_*  (ksp_type)                                        */
+  int32_t pc_type;       /* PPH_PC_*   (pc_type)                                         */
+  int32_t restart;       /* GMRES restart, PETSc default 30                              */
+  int32_t max_it;        /* ksp_max_it                                                   */
+  double rtol;           /* ksp_rtol                                                     */
+  double atol;           /* ksp_atol                                                     */
+  /* block solves of the field-split PC / Picard sweeps (fieldsplit_0_/fieldsplit_1_ options;
+   * the reference's LU block solves become inner Krylov solves run to inner_rtol)          */
+  int32_t inner_ksp_type;
+  int32_t inner_pc_type;
+  int32_t inner_max_it;
+  int32_t picard;        /* 0: Krylov on the monolithic system; 1: block Picard (fixed-stress)
+                          * outer loop per reference src/perphil/forms/dpp.py:196-203       */
+  double inner_rtol;
+  double inner_atol;
+  double picard_rtol;    /* snes_rtol */
+  double picard_atol;    /* snes_atol */
+  int32_t picard_max_it; /* snes_max_it */
+  int32_t mg_smooth;     /* smoothing steps per level side for PPH_PC_MG (default 2)     */
+} pph_solver_cfg;
+
+typedef struct {
+  int32_t iterations;        /* outer Krylov its (ksp.getIterationNumber(), solver.py:73) or Picard sweeps */
+  int32_t inner_iterations;  /* total inner Krylov iterations                            */
+  int32_t converged;         /* 1 / 0                                                    */
+  int32_t reserved;
+  double resnorm;            /* final (preconditioned) residual norm (ksp.getResidualNorm(), solver.py:74) */
+  double rhs_norm;           /* ||F(u0)||_2, PETSc's "0 SNES Function norm"               */
+} pph_solve_info;
+
+/* ---- context ------------------------------------------------------------------------- */
+/* replaces: process-wide PETSc/Firedrake initialisation behind `import firedrake` */
+int pph_ctx_create(int device, pph_ctx** out);
+int pph_ctx_destroy(pph_ctx* ctx);
+/* message of the last failure on ctx (ctx may be NULL: last failure of pph_ctx_create) */
+const char* pph_last_error(const pph_ctx* ctx);
+/* blocks until all device work of the context has finished */
+int pph_ctx_synchronize(pph_ctx* ctx);
+
+/* ---- mesh + cell->dof map --------------------------------------------------------------
+ * replaces: create_mesh() (reference src/perphil/mesh/builtin.py:4-20), fd.UnitCubeMesh call
+ * sites (petsc_profiling_3d.py:31), create_function_spaces()/MixedFunctionSpace (CG-1 dof map,
+ * src/perphil/forms/spaces.py:34-35).
+ * The context's LOCAL box holds cell layers [z_cell_begin, z_cell_begin+z_cell_count) of the
+ * global nx*ny*nz mesh (2D: nz = 0, z_cell_begin = 0, z_cell_count = 0).  ghost_lo / ghost_hi
+ * mark the lowest / highest local node plane as a ghost plane owned by the neighbouring slab
+ * (multi-GPU cell-slab decomposition); single GPU: whole mesh, no ghosts. */
+int pph_mesh_build(pph_ctx* ctx, int dim, int cell_kind, int nx, int ny, int nz,
+                   int z_cell_begin, int z_cell_count, int ghost_lo, int ghost_hi);
+int pph_mesh_sizes(const pph_ctx* ctx, int64_t* n_nodes, int64_t* n_cells, int32_t* nodes_per_cell,
+                   int64_t* nnz_block);
+int pph_get_dofmap(pph_ctx* ctx, int32_t* cells_host /* [n_cells][nodes_per_cell] */);
+int pph_get_coords(pph_ctx* ctx, double* coords_host /* [n_nodes][dim] */);
+
+/* ---- Dirichlet data ---------------------------------------------------------------------
+ * replaces: fd.DirichletBC(W.sub(field), expr, "on_boundary") as consumed at
+ * reference src/perphil/solvers/solver.py:66.  `nodes` are local node ids, `vals` the boundary
+ * values (evaluated by the caller, e.g. from the manufactured solution,
+ * src/perphil/utils/manufactured_solutions.py:39-51,87-88).  Replaces earlier data of `field`. */
+int pph_set_dirichlet(pph_ctx* ctx, int field, const int64_t* nodes, const double* vals, int64_t count);
+
+/* ---- assembly -----------------------------------------------------------------------------
+ * replaces: dpp_form() (reference src/perphil/forms/dpp.py:95-132) + the TSFC element kernel /
+ * PyOP2 cell loop / MatSetValues / BC elimination that solver.solve() triggers
+ * (src/perphil/solvers/solver.py:71 -> SNESJacobianEval), and dpp_delayed_form() (dpp.py:135-205).
+ * Builds on device: scalar CSR pattern, K and M by cell-local integration + scatter-add, then the
+ * Dirichlet-eliminated blocks A11 = (k1/mu)K + (beta/mu)M, A22 = (k2/mu)K + (beta/mu)M,
+ * A12 = A21^T = -(beta/mu)M and the lifted right-hand side.  `monolithic != 0` additionally
+ * materialises the 2n x 2n field-major CSR. */
+int pph_assemble_dpp(pph_ctx* ctx, double k1, double k2, double beta, double mu, int monolithic);
+
+/* ---- solve --------------------------------------------------------------------------------
+ * replaces: LinearVariationalSolver.solve() -> KSPSolve (reference src/perphil/solvers/solver.py:67-71);
+ * with cfg->picard the block Picard loop stated by dpp_delayed_form (dpp.py:196-203).
+ * x_host (len 2n, caller-owned) receives the full solution u = u0 + du, field-major.
+ * hist (optional, capacity hist_cap) receives residual norms per outer iteration, entry 0 = initial. */
+int pph_solve(pph_ctx* ctx, const pph_solver_cfg* cfg, double* x_host, pph_solve_info* info,
+              double* hist, int hist_cap);
+/* same solve, result left on the device (timing without the PCIe copy); fetch with pph_get_solution */
+int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* info, double* hist, int hist_cap);
+int pph_get_solution(pph_ctx* ctx, double* x_host /* len 2n */);
+
+/* ---- export for parity checks -----------------------------------------------------------
+ * replaces: get_matrix_data_from_form() -> petsc_matrix.getValuesCSR()
+ * (reference src/perphil/solvers/conditioning.py:66-102).
+ * which: 0 monolithic (needs monolithic assembly), 1 K, 2 M, 3 A11, 4 A22, 5 A12, 6 A21 */
+int pph_csr_sizes(const pph_ctx* ctx, int which, int64_t* nrows, int64_t* nnz);
+int pph_get_csr(pph_ctx* ctx, int which, int64_t* rowptr, int32_t* col, double* val);
+int pph_get_rhs(pph_ctx* ctx, double* rhs_host /* len 2n */, double* u0_host /* len 2n, may be NULL */);
+/* y = A x with the selected matrix (host vectors); replaces PETSc MatMult for tests */
+int pph_spmv(pph_ctx* ctx, int which, const double* x_host, double* y_host);
+/* `reps` back-to-back device SpMVs on resident vectors, average kernel ms via HIP events */
+int pph_spmv_bench(pph_ctx* ctx, int which, int reps, double* avg_ms);
+
+/* ---- stats ---------------------------------------------------------------------------------
+ * replaces: PETSc -log_view event times scraped by reference src/perphil/experiments/petsc_profiling.py:302-447.
+ * out[0] mesh+pattern ms, [1] K/M integration+scatter ms, [2] BC elimination/blocks ms, [3] last solve ms;
+ * SpMV accounting of the last solve per kernel variant v (0: plain, 1: fused with the p.Ap dot):
+ * out[4+3v] sum of per-launch durations in ms (0 unless option "time_spmv" is on), out[5+3v] launches,
+ * out[6+3v] algorithmic bytes (12 nnz + 20 nrows per launch). */
+int pph_get_timers(pph_ctx* ctx, double* out, int n);
+/* tuning / profiling switches (no reference counterpart): "spmv_lanes" (0 = automatic, 4..64 lanes per
+ * CSR row), "time_spmv" (1: bracket every SpMV launch of a solve with a HIP event pair on the context
+ * stream), "invalidate_KM" (drop the integrated K and M so the next assemble integrates again) */
+int pph_set_option(pph_ctx* ctx, const char* name, double value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PERPHIL_HIP_H */

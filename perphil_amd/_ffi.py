@@ -1,0 +1,240 @@
+"""
+ctypes binding of ``libperphil_hip.so`` (C ABI declared in ``include/perphil_hip.h``).
+
+This is the only crossing between the Python host layer and the device code: Python -> ctypes ->
+C ABI -> HIP.  There is no CPU fallback: if the shared library is missing or cannot be loaded the
+import of this module raises, and every call that fails inside the library raises
+(``ValueError`` for PPH_ERR_INVALID, ``MemoryError`` for PPH_ERR_NOMEM, ``RuntimeError``
+otherwise), mirroring how PETSc errors surface as exceptions from the reference's
+``solver.solve()`` (reference ``src/perphil/solvers/solver.py:71``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libperphil_hip.so")
+
+PPH_OK, PPH_ERR_INVALID, PPH_ERR_HIP, PPH_ERR_NOMEM, PPH_ERR_DIVERGED, PPH_ERR_COMM = 0, -1, -2, -3, -4, -5
+CELL_QUAD, CELL_TRI, CELL_HEX, CELL_TET = 0, 1, 2, 3
+KSP_PREONLY, KSP_CG, KSP_GMRES = 0, 1, 2
+PC_NONE, PC_JACOBI, PC_BLOCK2, PC_FIELDSPLIT, PC_MG = 0, 1, 2, 3, 4
+MAT_MONO, MAT_K, MAT_M, MAT_A11, MAT_A22, MAT_A12, MAT_A21 = 0, 1, 2, 3, 4, 5, 6
+
+# every symbol include/perphil_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "pph_ctx_create", "pph_ctx_destroy", "pph_last_error", "pph_ctx_synchronize",
+    "pph_mesh_build", "pph_mesh_sizes", "pph_get_dofmap", "pph_get_coords",
+    "pph_set_dirichlet", "pph_assemble_dpp",
+    "pph_solve", "pph_solve_device", "pph_get_solution",
+    "pph_csr_sizes", "pph_get_csr", "pph_get_rhs", "pph_spmv", "pph_spmv_bench",
+    "pph_get_timers", "pph_set_option",
+]
+
+
+class SolverCfg(C.Structure):
+    """``pph_solver_cfg``"""
+    _fields_ = [
+        ("ksp_type", C.c_int32), ("pc_type", C.c_int32), ("restart", C.c_int32), ("max_it", C.c_int32),
+        ("rtol", C.c_double), ("atol", C.c_double),
+        ("inner_ksp_type", C.c_int32), ("inner_pc_type", C.c_int32), ("inner_max_it", C.c_int32),
+        ("picard", C.c_int32),
+        ("inner_rtol", C.c_double), ("inner_atol", C.c_double),
+        ("picard_rtol", C.c_double), ("picard_atol", C.c_double),
+        ("picard_max_it", C.c_int32), ("mg_smooth", C.c_int32),
+    ]
+
+
+class SolveInfo(C.Structure):
+    """``pph_solve_info``"""
+    _fields_ = [
+        ("iterations", C.c_int32), ("inner_iterations", C.c_int32), ("converged", C.c_int32),
+        ("reserved", C.c_int32), ("resnorm", C.c_double), ("rhs_norm", C.c_double),
+    ]
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C perphil_amd/csrc`).  perphil_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    p = C.c_void_p
+    i32p, i64p, f64p = C.POINTER(C.c_int32), C.POINTER(C.c_int64), C.POINTER(C.c_double)
+    sig = {
+        "pph_ctx_create": ([C.c_int, C.POINTER(p)], C.c_int),
+        "pph_ctx_destroy": ([p], C.c_int),
+        "pph_last_error": ([p], C.c_char_p),
+        "pph_ctx_synchronize": ([p], C.c_int),
+        "pph_mesh_build": ([p] + [C.c_int] * 9, C.c_int),
+        "pph_mesh_sizes": ([p, i64p, i64p, i32p, i64p], C.c_int),
+        "pph_get_dofmap": ([p, C.c_void_p], C.c_int),
+        "pph_get_coords": ([p, C.c_void_p], C.c_int),
+        "pph_set_dirichlet": ([p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64], C.c_int),
+        "pph_assemble_dpp": ([p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int], C.c_int),
+        "pph_solve": ([p, C.POINTER(SolverCfg), C.c_void_p, C.POINTER(SolveInfo), C.c_void_p, C.c_int], C.c_int),
+        "pph_solve_device": ([p, C.POINTER(SolverCfg), C.POINTER(SolveInfo), C.c_void_p, C.c_int], C.c_int),
+        "pph_get_solution": ([p, C.c_void_p], C.c_int),
+        "pph_csr_sizes": ([p, C.c_int, i64p, i64p], C.c_int),
+        "pph_get_csr": ([p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p], C.c_int),
+        "pph_get_rhs": ([p, C.c_void_p, C.c_void_p], C.c_int),
+        "pph_spmv": ([p, C.c_int, C.c_void_p, C.c_void_p], C.c_int),
+        "pph_spmv_bench": ([p, C.c_int, C.c_int, f64p], C.c_int),
+        "pph_get_timers": ([p, C.c_void_p, C.c_int], C.c_int),
+        "pph_set_option": ([p, C.c_char_p, C.c_double], C.c_int),
+    }
+    for name, (argtypes, restype) in sig.items():
+        fn = getattr(lib, name)  # AttributeError here = ABI mismatch: fail loudly
+        fn.argtypes = argtypes
+        fn.restype = restype
+    return lib
+
+
+lib = _load()
+
+
+class ConvergenceError(RuntimeError):
+    """Krylov / Picard iteration did not converge (Firedrake raises ConvergenceError likewise)."""
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """Owner of one ``pph_ctx`` (one GPU, one stream).  Not thread-safe; one per device."""
+
+    def __init__(self, device: int = 0):
+        self._h = C.c_void_p()
+        st = lib.pph_ctx_create(int(device), C.byref(self._h))
+        if st != PPH_OK:
+            msg = (lib.pph_last_error(None) or b"").decode()
+            raise RuntimeError(f"pph_ctx_create(device={device}) failed ({st}): {msg}")
+        self.device = int(device)
+        self.n = 0
+        self.dim = 0
+
+    # -- plumbing -----------------------------------------------------------------------------
+    def _check(self, st: int, allow_diverged: bool = False) -> int:
+        if st == PPH_OK or (allow_diverged and st == PPH_ERR_DIVERGED):
+            return st
+        msg = (lib.pph_last_error(self._h) or b"").decode()
+        if st == PPH_ERR_INVALID:
+            raise ValueError(msg)
+        if st == PPH_ERR_NOMEM:
+            raise MemoryError(msg)
+        if st == PPH_ERR_DIVERGED:
+            raise ConvergenceError(msg)
+        raise RuntimeError(f"libperphil_hip error {st}: {msg}")
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h:
+            lib.pph_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def synchronize(self) -> None:
+        self._check(lib.pph_ctx_synchronize(self._h))
+
+    def set_option(self, name: str, value: float) -> None:
+        self._check(lib.pph_set_option(self._h, name.encode(), float(value)))
+
+    # -- mesh ---------------------------------------------------------------------------------
+    def mesh_build(self, dim: int, kind: int, nx: int, ny: int, nz: int = 0, z_begin: int = 0,
+                   z_count: Optional[int] = None, ghost_lo: bool = False, ghost_hi: bool = False) -> None:
+        if z_count is None:
+            z_count = nz
+        self._check(lib.pph_mesh_build(self._h, dim, kind, nx, ny, nz, z_begin, z_count, int(ghost_lo), int(ghost_hi)))
+        n, nc, m, nnz = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int64()
+        self._check(lib.pph_mesh_sizes(self._h, C.byref(n), C.byref(nc), C.byref(m), C.byref(nnz)))
+        self.n, self.ncell, self.m, self.nnzb, self.dim = n.value, nc.value, m.value, nnz.value, dim
+
+    def dofmap(self) -> np.ndarray:
+        out = np.empty((self.ncell, self.m), dtype=np.int32)
+        self._check(lib.pph_get_dofmap(self._h, _ptr(out)))
+        return out
+
+    def coords(self) -> np.ndarray:
+        out = np.empty((self.n, self.dim), dtype=np.float64)
+        self._check(lib.pph_get_coords(self._h, _ptr(out)))
+        return out
+
+    # -- system -------------------------------------------------------------------------------
+    def set_dirichlet(self, field: int, nodes: np.ndarray, vals: np.ndarray) -> None:
+        nodes = np.ascontiguousarray(nodes, dtype=np.int64)
+        vals = np.ascontiguousarray(vals, dtype=np.float64)
+        if nodes.shape != vals.shape:
+            raise ValueError("nodes and vals must have the same shape")
+        self._check(lib.pph_set_dirichlet(self._h, int(field), _ptr(nodes), _ptr(vals), nodes.size))
+
+    def assemble(self, k1: float, k2: float, beta: float, mu: float, monolithic: bool = True) -> None:
+        self._check(lib.pph_assemble_dpp(self._h, float(k1), float(k2), float(beta), float(mu), int(monolithic)))
+
+    def solve(self, cfg: SolverCfg, fetch: bool = True, hist_cap: int = 0, raise_on_diverged: bool = True):
+        info = SolveInfo()
+        hist = np.zeros(max(hist_cap, 1), dtype=np.float64)
+        x = np.empty(2 * self.n, dtype=np.float64) if fetch else None
+        if fetch:
+            st = lib.pph_solve(self._h, C.byref(cfg), _ptr(x), C.byref(info), _ptr(hist), int(hist_cap))
+        else:
+            st = lib.pph_solve_device(self._h, C.byref(cfg), C.byref(info), _ptr(hist), int(hist_cap))
+        self._check(st, allow_diverged=not raise_on_diverged)
+        nh = min(hist_cap, info.iterations + 1)
+        return x, info, hist[:nh].copy()
+
+    def solution(self) -> np.ndarray:
+        x = np.empty(2 * self.n, dtype=np.float64)
+        self._check(lib.pph_get_solution(self._h, _ptr(x)))
+        return x
+
+    # -- export -------------------------------------------------------------------------------
+    def csr(self, which: int):
+        import scipy.sparse as sp
+
+        nrows, nnz = C.c_int64(), C.c_int64()
+        self._check(lib.pph_csr_sizes(self._h, which, C.byref(nrows), C.byref(nnz)))
+        rowptr = np.empty(nrows.value + 1, dtype=np.int64)
+        col = np.empty(nnz.value, dtype=np.int32)
+        val = np.empty(nnz.value, dtype=np.float64)
+        self._check(lib.pph_get_csr(self._h, which, _ptr(rowptr), _ptr(col), _ptr(val)))
+        return sp.csr_matrix((val, col, rowptr), shape=(nrows.value, nrows.value))
+
+    def rhs(self):
+        r = np.empty(2 * self.n, dtype=np.float64)
+        u0 = np.empty(2 * self.n, dtype=np.float64)
+        self._check(lib.pph_get_rhs(self._h, _ptr(r), _ptr(u0)))
+        return r, u0
+
+    def spmv(self, which: int, x: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.empty_like(x)
+        self._check(lib.pph_spmv(self._h, which, _ptr(x), _ptr(y)))
+        return y
+
+    def spmv_bench(self, which: int, reps: int) -> float:
+        ms = C.c_double()
+        self._check(lib.pph_spmv_bench(self._h, which, int(reps), C.byref(ms)))
+        return ms.value
+
+    def timers(self) -> dict:
+        t = np.zeros(10, dtype=np.float64)
+        self._check(lib.pph_get_timers(self._h, _ptr(t), 10))
+        return {"mesh_ms": t[0], "assemble_ms": t[1], "bc_blocks_ms": t[2], "solve_ms": t[3],
+                "spmv_ms": t[4], "spmv_launches": int(t[5]), "spmv_bytes": t[6],
+                "spmv_dot_ms": t[7], "spmv_dot_launches": int(t[8]), "spmv_dot_bytes": t[9]}

@@ -1,0 +1,407 @@
+// C-ABI entry points of libperphil_hip.so (see include/perphil_hip.h for the contract and the
+// reference interfaces each one replaces).
+#include "pph_internal.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+static thread_local std::string g_last_error;
+
+void pph_set_error(pph_ctx* ctx, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  g_last_error = buf;
+}
+
+template <typename T>
+int DevBuf<T>::alloc(pph_ctx* ctx, size_t count) {
+  release();
+  if (count == 0) count = 1;
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, count * sizeof(T));
+  if (e != hipSuccess) {
+    pph_set_error(ctx, "hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
+    (void)hipGetLastError();
+    return (e == hipErrorOutOfMemory) ? PPH_ERR_NOMEM : PPH_ERR_HIP;
+  }
+  p = (T*)q;
+  n = count;
+  return PPH_OK;
+}
+
+template <typename T>
+void DevBuf<T>::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  n = 0;
+}
+
+template struct DevBuf<double>;
+template struct DevBuf<int32_t>;
+template struct DevBuf<int64_t>;
+template struct DevBuf<uint8_t>;
+template struct DevBuf<unsigned long long>;
+
+extern "C" {
+
+const char* pph_last_error(const pph_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int pph_ctx_create(int device, pph_ctx** out) {
+  if (!out) return PPH_ERR_INVALID;
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    pph_set_error(nullptr, "no HIP device available (%s)", hipGetErrorString(e));
+    return PPH_ERR_HIP;
+  }
+  if (device < 0 || device >= count) {
+    pph_set_error(nullptr, "device %d out of range [0,%d)", device, count);
+    return PPH_ERR_INVALID;
+  }
+  pph_ctx* ctx = new (std::nothrow) pph_ctx();
+  if (!ctx) return PPH_ERR_NOMEM;
+  ctx->device = device;
+  auto fail = [&](const char* what, hipError_t err) {
+    pph_set_error(nullptr, "%s failed: %s", what, hipGetErrorString(err));
+    delete ctx;
+    return PPH_ERR_HIP;
+  };
+  if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
+  if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+  if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return fail("hipEventCreate", e);
+  if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return fail("hipEventCreate", e);
+  if ((e = hipHostMalloc((void**)&ctx->h_scal, sizeof(double) * PPH_MAX_SCAL, hipHostMallocDefault)) != hipSuccess)
+    return fail("hipHostMalloc", e);
+  // reduction results + partial sums (32 slots x 2048 workgroups)
+  if (ctx->scal.alloc(ctx, (size_t)PPH_MAX_SCAL + 32 * 2048) < 0) {
+    g_last_error = ctx->err;
+    delete ctx;
+    return PPH_ERR_NOMEM;
+  }
+  *out = ctx;
+  return PPH_OK;
+}
+
+static void release_system(pph_ctx* ctx) {
+  ctx->A11.release(); ctx->A22.release(); ctx->A12.release(); ctx->A21.release();
+  ctx->rhs.release(); ctx->u0.release(); ctx->sol.release();
+  ctx->mrowptr.release(); ctx->mcol.release(); ctx->mval.release();
+  mg_release(ctx);
+  ctx->asm_ok = false;
+  ctx->mono_ok = false;
+}
+
+int pph_ctx_destroy(pph_ctx* ctx) {
+  if (!ctx) return PPH_OK;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  release_system(ctx);
+  ctx->mesh.release_all();
+  for (int f = 0; f < 2; ++f) { ctx->bcmask[f].release(); ctx->g[f].release(); }
+  for (auto& w : ctx->work) w.release();
+  for (auto& p : ctx->ev_pool) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
+  ctx->scal.release();
+  if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return PPH_OK;
+}
+
+int pph_ctx_synchronize(pph_ctx* ctx) {
+  if (!ctx) return PPH_ERR_INVALID;
+  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PPH_OK;
+}
+
+// ---- mesh ---------------------------------------------------------------------------------------
+__global__ void k_fill_u8(uint8_t* __restrict__ p, uint8_t v, int64_t begin, int64_t end) {
+  for (int64_t i = begin + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < end;
+       i += (int64_t)gridDim.x * blockDim.x)
+    p[i] |= v;
+}
+
+int pph_mesh_build(pph_ctx* ctx, int dim, int cell_kind, int nx, int ny, int nz, int z_cell_begin, int z_cell_count,
+                   int ghost_lo, int ghost_hi) {
+  if (!ctx) return PPH_ERR_INVALID;
+  PPH_HIP(ctx, hipSetDevice(ctx->device));
+  PPH_REQUIRE(ctx, dim == 2 || dim == 3, "dim must be 2 or 3, got %d", dim);
+  PPH_REQUIRE(ctx, nx >= 1 && ny >= 1, "nx, ny must be >= 1");
+  if (dim == 2) {
+    PPH_REQUIRE(ctx, cell_kind == PPH_CELL_QUAD || cell_kind == PPH_CELL_TRI, "2D cell kinds: quad (0), tri (1)");
+    PPH_REQUIRE(ctx, nz == 0 && z_cell_begin == 0 && z_cell_count == 0 && !ghost_lo && !ghost_hi,
+                "2D meshes take nz = z_cell_begin = z_cell_count = 0 and no ghost planes");
+  } else {
+    PPH_REQUIRE(ctx, cell_kind == PPH_CELL_HEX || cell_kind == PPH_CELL_TET, "3D cell kinds: hex (2), tet (3)");
+    PPH_REQUIRE(ctx, nz >= 1 && z_cell_count >= 1 && z_cell_begin >= 0 && z_cell_begin + z_cell_count <= nz,
+                "slab [%d,%d) outside [0,%d)", z_cell_begin, z_cell_begin + z_cell_count, nz);
+    PPH_REQUIRE(ctx, !(ghost_lo && z_cell_begin == 0) && !(ghost_hi && z_cell_begin + z_cell_count == nz),
+                "a ghost plane cannot lie on the domain boundary");
+  }
+  release_system(ctx);
+  ctx->mesh.release_all();
+  ctx->mesh_ok = false;
+  PPH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  MeshData& m = ctx->mesh;
+  m.dim = dim; m.kind = cell_kind; m.nx = nx; m.ny = ny; m.nz = nz; m.z0 = z_cell_begin; m.nzl = z_cell_count;
+  ctx->ghost_lo = ghost_lo ? 1 : 0;
+  ctx->ghost_hi = ghost_hi ? 1 : 0;
+  PPH_TRY(pph_launch_mesh(ctx, m));
+  ctx->n = m.n;
+  ctx->nnzb = m.nnzb;
+  for (int f = 0; f < 2; ++f) {
+    PPH_TRY(ctx->bcmask[f].alloc(ctx, (size_t)m.n));
+    PPH_TRY(ctx->g[f].alloc(ctx, (size_t)m.n));
+    PPH_HIP(ctx, hipMemsetAsync(ctx->bcmask[f].p, 0, (size_t)m.n, ctx->stream));
+    PPH_HIP(ctx, hipMemsetAsync(ctx->g[f].p, 0, sizeof(double) * (size_t)m.n, ctx->stream));
+    const int64_t plane = (int64_t)m.px * m.py;
+    if (ctx->ghost_lo)
+      hipLaunchKernelGGL(k_fill_u8, dim3(64), dim3(256), 0, ctx->stream, ctx->bcmask[f].p, (uint8_t)2, (int64_t)0, plane);
+    if (ctx->ghost_hi)
+      hipLaunchKernelGGL(k_fill_u8, dim3(64), dim3(256), 0, ctx->stream, ctx->bcmask[f].p, (uint8_t)2, m.n - plane, m.n);
+  }
+  PPH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  PPH_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  PPH_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  ctx->t_mesh = ms;
+  PPH_HIP(ctx, hipGetLastError());
+  ctx->mesh_ok = true;
+  return PPH_OK;
+}
+
+int pph_mesh_sizes(const pph_ctx* ctx, int64_t* n_nodes, int64_t* n_cells, int32_t* nodes_per_cell,
+                   int64_t* nnz_block) {
+  if (!ctx || !ctx->mesh_ok) return PPH_ERR_INVALID;
+  if (n_nodes) *n_nodes = ctx->mesh.n;
+  if (n_cells) *n_cells = ctx->mesh.ncell;
+  if (nodes_per_cell) *nodes_per_cell = ctx->mesh.m;
+  if (nnz_block) *nnz_block = ctx->mesh.nnzb;
+  return PPH_OK;
+}
+
+int pph_get_dofmap(pph_ctx* ctx, int32_t* cells_host) {
+  if (!ctx) return PPH_ERR_INVALID;
+  PPH_REQUIRE(ctx, ctx->mesh_ok && cells_host, "pph_get_dofmap: no mesh or NULL buffer");
+  PPH_HIP(ctx, hipMemcpyAsync(cells_host, ctx->mesh.cells.p, sizeof(int32_t) * (size_t)ctx->mesh.ncell * ctx->mesh.m,
+                              hipMemcpyDeviceToHost, ctx->stream));
+  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PPH_OK;
+}
+
+int pph_get_coords(pph_ctx* ctx, double* coords_host) {
+  if (!ctx) return PPH_ERR_INVALID;
+  PPH_REQUIRE(ctx, ctx->mesh_ok && coords_host, "pph_get_coords: no mesh or NULL buffer");
+  const MeshData& m = ctx->mesh;
+  const size_t n = (size_t)m.n;
+  std::vector<double> tmp(n);
+  const double* src[3] = {m.cx.p, m.cy.p, m.cz.p};
+  for (int d = 0; d < m.dim; ++d) {
+    PPH_HIP(ctx, hipMemcpyAsync(tmp.data(), src[d], sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+    PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < n; ++i) coords_host[i * m.dim + d] = tmp[i];
+  }
+  return PPH_OK;
+}
+
+// ---- Dirichlet data -----------------------------------------------------------------------------
+int pph_set_dirichlet(pph_ctx* ctx, int field, const int64_t* nodes, const double* vals, int64_t count) {
+  if (!ctx) return PPH_ERR_INVALID;
+  PPH_HIP(ctx, hipSetDevice(ctx->device));
+  PPH_REQUIRE(ctx, ctx->mesh_ok, "pph_set_dirichlet before pph_mesh_build");
+  PPH_REQUIRE(ctx, field == 0 || field == 1, "field must be 0 or 1, got %d", field);
+  PPH_REQUIRE(ctx, count >= 0 && (count == 0 || (nodes && vals)), "NULL nodes/vals with count %lld", (long long)count);
+  const int64_t n = ctx->n;
+  for (int64_t i = 0; i < count; ++i)
+    PPH_REQUIRE(ctx, nodes[i] >= 0 && nodes[i] < n, "Dirichlet node %lld outside [0,%lld)", (long long)nodes[i],
+                (long long)n);
+  release_system(ctx);  // any assembled system is stale now
+  // mask bytes are written from the host side to avoid byte-granular races between threads
+  std::vector<uint8_t> hmask((size_t)n);
+  std::vector<double> hg((size_t)n, 0.0);
+  PPH_HIP(ctx, hipMemcpyAsync(hmask.data(), ctx->bcmask[field].p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int64_t i = 0; i < n; ++i) hmask[(size_t)i] &= (uint8_t)2;
+  for (int64_t i = 0; i < count; ++i) {
+    hmask[(size_t)nodes[i]] |= (uint8_t)1;
+    hg[(size_t)nodes[i]] = vals[i];
+  }
+  PPH_HIP(ctx, hipMemcpyAsync(ctx->bcmask[field].p, hmask.data(), (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  PPH_HIP(ctx, hipMemcpyAsync(ctx->g[field].p, hg.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice,
+                              ctx->stream));
+  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PPH_OK;
+}
+
+// ---- assembly -----------------------------------------------------------------------------------
+int pph_assemble_dpp(pph_ctx* ctx, double k1, double k2, double beta, double mu, int monolithic) {
+  if (!ctx) return PPH_ERR_INVALID;
+  PPH_HIP(ctx, hipSetDevice(ctx->device));
+  PPH_REQUIRE(ctx, ctx->mesh_ok, "pph_assemble_dpp before pph_mesh_build");
+  PPH_REQUIRE(ctx, k1 > 0 && k2 > 0 && mu > 0 && beta >= 0, "need k1, k2, mu > 0 and beta >= 0");
+  release_system(ctx);
+  ctx->a = k1 / mu; ctx->b = beta / mu; ctx->c = k2 / mu;
+  float ms = 0.f;
+  // K and M depend only on the mesh: integrate once per mesh
+  if (!ctx->mesh.K.p) {
+    PPH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    PPH_TRY(pph_launch_assemble_KM(ctx, ctx->mesh));
+    PPH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    PPH_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    PPH_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->t_asm = ms;
+  }
+  PPH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  PPH_TRY(pph_launch_blocks(ctx, monolithic));
+  PPH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  PPH_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  PPH_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  ctx->t_bc = ms;
+  PPH_HIP(ctx, hipGetLastError());
+  ctx->asm_ok = true;
+  return PPH_OK;
+}
+
+// ---- export -------------------------------------------------------------------------------------
+static int select_csr(pph_ctx* ctx, int which, Csr* A) {
+  PPH_REQUIRE(ctx, ctx->mesh_ok, "no mesh");
+  const MeshData& m = ctx->mesh;
+  A->rowptr = m.rowptr.p; A->col = m.col.p; A->nrows = m.n; A->nnz = m.nnzb;
+  A->lanes = pph_pick_lanes(ctx, A->nnz, A->nrows);
+  switch (which) {
+    case 0:
+      PPH_REQUIRE(ctx, ctx->mono_ok, "monolithic CSR not assembled (pph_assemble_dpp(..., monolithic=1))");
+      A->rowptr = ctx->mrowptr.p; A->col = ctx->mcol.p; A->val = ctx->mval.p; A->nrows = 2 * m.n; A->nnz = 4 * m.nnzb;
+      A->lanes = pph_pick_lanes(ctx, A->nnz, A->nrows);
+      return PPH_OK;
+    case 1: PPH_REQUIRE(ctx, m.K.p, "K not assembled"); A->val = m.K.p; return PPH_OK;
+    case 2: PPH_REQUIRE(ctx, m.M.p, "M not assembled"); A->val = m.M.p; return PPH_OK;
+    case 3: PPH_REQUIRE(ctx, ctx->asm_ok, "blocks not assembled"); A->val = ctx->A11.p; return PPH_OK;
+    case 4: PPH_REQUIRE(ctx, ctx->asm_ok, "blocks not assembled"); A->val = ctx->A22.p; return PPH_OK;
+    case 5: PPH_REQUIRE(ctx, ctx->asm_ok, "blocks not assembled"); A->val = ctx->A12.p; return PPH_OK;
+    case 6: PPH_REQUIRE(ctx, ctx->asm_ok, "blocks not assembled"); A->val = ctx->A21.p; return PPH_OK;
+    default: pph_set_error(ctx, "unknown matrix selector %d", which); return PPH_ERR_INVALID;
+  }
+}
+
+int pph_csr_sizes(const pph_ctx* cctx, int which, int64_t* nrows, int64_t* nnz) {
+  pph_ctx* ctx = const_cast<pph_ctx*>(cctx);
+  if (!ctx) return PPH_ERR_INVALID;
+  Csr A;
+  PPH_TRY(select_csr(ctx, which, &A));
+  if (nrows) *nrows = A.nrows;
+  if (nnz) *nnz = A.nnz;
+  return PPH_OK;
+}
+
+int pph_get_csr(pph_ctx* ctx, int which, int64_t* rowptr, int32_t* col, double* val) {
+  if (!ctx) return PPH_ERR_INVALID;
+  Csr A;
+  PPH_TRY(select_csr(ctx, which, &A));
+  if (rowptr) PPH_HIP(ctx, hipMemcpyAsync(rowptr, A.rowptr, sizeof(int64_t) * (size_t)(A.nrows + 1), hipMemcpyDeviceToHost, ctx->stream));
+  if (col) PPH_HIP(ctx, hipMemcpyAsync(col, A.col, sizeof(int32_t) * (size_t)A.nnz, hipMemcpyDeviceToHost, ctx->stream));
+  if (val) PPH_HIP(ctx, hipMemcpyAsync(val, A.val, sizeof(double) * (size_t)A.nnz, hipMemcpyDeviceToHost, ctx->stream));
+  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PPH_OK;
+}
+
+int pph_get_rhs(pph_ctx* ctx, double* rhs_host, double* u0_host) {
+  if (!ctx) return PPH_ERR_INVALID;
+  PPH_REQUIRE(ctx, ctx->asm_ok, "pph_get_rhs before pph_assemble_dpp");
+  const size_t bytes = sizeof(double) * 2 * (size_t)ctx->n;
+  if (rhs_host) PPH_HIP(ctx, hipMemcpyAsync(rhs_host, ctx->rhs.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  if (u0_host) PPH_HIP(ctx, hipMemcpyAsync(u0_host, ctx->u0.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PPH_OK;
+}
+
+int pph_spmv(pph_ctx* ctx, int which, const double* x_host, double* y_host) {
+  if (!ctx) return PPH_ERR_INVALID;
+  PPH_REQUIRE(ctx, x_host && y_host, "NULL vector");
+  PPH_HIP(ctx, hipSetDevice(ctx->device));
+  Csr A;
+  PPH_TRY(select_csr(ctx, which, &A));
+  DevBuf<double> x, y;
+  PPH_TRY(x.alloc(ctx, (size_t)A.nrows));
+  PPH_TRY(y.alloc(ctx, (size_t)A.nrows));
+  PPH_HIP(ctx, hipMemcpyAsync(x.p, x_host, sizeof(double) * (size_t)A.nrows, hipMemcpyHostToDevice, ctx->stream));
+  la_spmv(ctx, A, x.p, y.p);
+  PPH_HIP(ctx, hipMemcpyAsync(y_host, y.p, sizeof(double) * (size_t)A.nrows, hipMemcpyDeviceToHost, ctx->stream));
+  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  PPH_HIP(ctx, hipGetLastError());
+  x.release();
+  y.release();
+  return PPH_OK;
+}
+
+__global__ void k_fill_pattern(double* __restrict__ x, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    // cheap deterministic pseudo-random values in (-1, 1)
+    unsigned long long h = (unsigned long long)i * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+    h ^= h >> 29; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 32;
+    x[i] = (double)(h >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+  }
+}
+
+int pph_spmv_bench(pph_ctx* ctx, int which, int reps, double* avg_ms) {
+  if (!ctx) return PPH_ERR_INVALID;
+  PPH_REQUIRE(ctx, reps >= 1 && avg_ms, "reps must be >= 1 and avg_ms non-NULL");
+  PPH_HIP(ctx, hipSetDevice(ctx->device));
+  Csr A;
+  PPH_TRY(select_csr(ctx, which, &A));
+  A.lanes = pph_pick_lanes(ctx, A.nnz, A.nrows);
+  DevBuf<double> x, y;
+  PPH_TRY(x.alloc(ctx, (size_t)A.nrows));
+  PPH_TRY(y.alloc(ctx, (size_t)A.nrows));
+  hipLaunchKernelGGL(k_fill_pattern, dim3(2048), dim3(256), 0, ctx->stream, x.p, A.nrows);
+  for (int i = 0; i < 3; ++i) la_spmv(ctx, A, x.p, y.p);
+  PPH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  for (int i = 0; i < reps; ++i) la_spmv(ctx, A, x.p, y.p);
+  PPH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  PPH_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  PPH_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *avg_ms = (double)ms / reps;
+  PPH_HIP(ctx, hipGetLastError());
+  x.release();
+  y.release();
+  return PPH_OK;
+}
+
+int pph_set_option(pph_ctx* ctx, const char* name, double value) {
+  if (!ctx || !name) return PPH_ERR_INVALID;
+  if (!strcmp(name, "spmv_lanes")) {
+    const int v = (int)value;
+    PPH_REQUIRE(ctx, v == 0 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64, "spmv_lanes must be 0,4,8,16,32,64");
+    ctx->spmv_lanes_override = v;
+    return PPH_OK;
+  }
+  if (!strcmp(name, "time_spmv")) { ctx->time_spmv = value != 0.0; return PPH_OK; }
+  if (!strcmp(name, "invalidate_KM")) {
+    // forget the integrated K and M so that the next pph_assemble_dpp integrates again (benchmarks)
+    ctx->mesh.K.release();
+    ctx->mesh.M.release();
+    return PPH_OK;
+  }
+  pph_set_error(ctx, "unknown option '%s'", name);
+  return PPH_ERR_INVALID;
+}
+
+int pph_get_timers(pph_ctx* ctx, double* out, int n) {
+  if (!ctx || !out) return PPH_ERR_INVALID;
+  la_harvest_spmv_times(ctx);
+  const double v[10] = {ctx->t_mesh, ctx->t_asm, ctx->t_bc, ctx->t_solve,
+                        ctx->t_spmv[0], (double)ctx->n_spmv[0], ctx->spmv_bytes[0],
+                        ctx->t_spmv[1], (double)ctx->n_spmv[1], ctx->spmv_bytes[1]};
+  for (int i = 0; i < n && i < 10; ++i) out[i] = v[i];
+  return PPH_OK;
+}
+
+}  // extern "C"

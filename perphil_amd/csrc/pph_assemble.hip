@@ -1,0 +1,466 @@
+// K-ASM / K-BC: cell-local stiffness + mass integration, wavefront-segmented scatter-add into CSR,
+// Dirichlet elimination, DPP block formation and the lifted right-hand side.
+//
+// Replaces, for reference src/perphil/forms/dpp.py:57-58,89-90,129-130 (dpp_form) and :196-203
+// (dpp_delayed_form), the TSFC-generated element kernel + PyOP2 cell loop + PETSc MatSetValues +
+// Firedrake BC application that run inside solver.solve() (src/perphil/solvers/solver.py:71).
+//
+// Layout: one lane per (cell, local row a).  A 256-thread workgroup takes 256/NB cells per batch;
+// their cell->dof entries are read coalesced, nodal coordinates and the reference basis tables
+// (values + gradients at the 2^d Gauss points) are staged in LDS, each lane integrates row a of K_e
+// and M_e, and the rows are scattered into the scalar CSR arrays with fp64 atomics.  Lanes of
+// neighbouring cells in one wavefront that target the same CSR slot are merged by shuffle first
+// (segments found from the cell->dof map itself, so the merge is also correct on any other numbering).
+#include "pph_internal.h"
+#include <hip/hip_runtime.h>
+
+__device__ inline int64_t find_slot(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                    int32_t row, int32_t c) {
+  int64_t lo = rowptr[row], hi = rowptr[row + 1] - 1;
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if (col[mid] < c) lo = mid + 1; else hi = mid;
+  }
+  return lo;  // col[lo] == c by construction of the pattern
+}
+
+__device__ inline void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+// ------------------------------------------------------------------------------------------------
+// multilinear cells (Q1 quad: DIM 2, Q1 hex: DIM 3), 2-point Gauss per direction
+// ------------------------------------------------------------------------------------------------
+template <int DIM>
+__global__ __launch_bounds__(256) void k_asm_multilinear(const int32_t* __restrict__ cells,
+                                                          const double* __restrict__ cx,
+                                                          const double* __restrict__ cy,
+                                                          const double* __restrict__ cz,
+                                                          const int64_t* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ col, double* __restrict__ K,
+                                                          double* __restrict__ M, int64_t ncell) {
+  constexpr int NB = 1 << DIM;     // nodes per cell == Gauss points
+  constexpr int CPB = 256 / NB;    // cells per workgroup batch
+  constexpr int CPW = 64 / NB;     // cells per wavefront
+  __shared__ double sN[NB][NB];           // [q][b]   basis values
+  __shared__ double sdN[NB][NB][DIM];     // [q][b][e] reference gradients
+  __shared__ double sX[CPB][NB][DIM];     // nodal coordinates of the batch
+  __shared__ int32_t sC[CPB + 1][NB];     // cell->dof entries of the batch (+1 row: sentinel)
+
+  const int tid = threadIdx.x;
+  const int lc = tid / NB;  // cell inside the batch
+  const int a = tid % NB;   // local row
+  if (tid < NB * NB) {
+    const int q = tid / NB, b = tid % NB;
+    const double gp = 0.57735026918962576451;  // 1/sqrt(3)
+    double xi[DIM], s[DIM];
+#pragma unroll
+    for (int e = 0; e < DIM; ++e) {
+      xi[e] = ((q >> e) & 1) ? gp : -gp;
+      s[e] = ((b >> e) & 1) ? 1.0 : -1.0;
+    }
+    double nv = 1.0;
+#pragma unroll
+    for (int e = 0; e < DIM; ++e) nv *= 0.5 * (1.0 + s[e] * xi[e]);
+    sN[q][b] = nv;
+#pragma unroll
+    for (int e = 0; e < DIM; ++e) {
+      double d = 1.0;
+#pragma unroll
+      for (int f = 0; f < DIM; ++f) d *= (f == e) ? 0.5 * s[f] : 0.5 * (1.0 + s[f] * xi[f]);
+      sdN[q][b][e] = d;
+    }
+  }
+  if (tid < NB) sC[CPB][tid] = -1;
+
+  const int64_t nbatch = (ncell + CPB - 1) / CPB;
+  for (int64_t batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+    __syncthreads();  // previous batch fully consumed (also orders the table writes on the first pass)
+    const int64_t cell = batch * CPB + lc;
+    const bool valid = cell < ncell;
+    int32_t node = -1;
+    if (valid) {
+      node = cells[cell * NB + a];
+      sX[lc][a][0] = cx[node];
+      sX[lc][a][1] = cy[node];
+      if constexpr (DIM == 3) sX[lc][a][2] = cz[node];
+    }
+    sC[lc][a] = node;
+    __syncthreads();
+
+    double Kr[NB], Mr[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { Kr[b] = 0.0; Mr[b] = 0.0; }
+
+    if (valid) {
+#pragma unroll 1
+      for (int q = 0; q < NB; ++q) {
+        double J[DIM][DIM];  // J[e][d] = d x_d / d xi_e
+#pragma unroll
+        for (int e = 0; e < DIM; ++e)
+#pragma unroll
+          for (int d = 0; d < DIM; ++d) J[e][d] = 0.0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int e = 0; e < DIM; ++e)
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) J[e][d] += sdN[q][b][e] * sX[lc][b][d];
+        double det, I[DIM][DIM];  // I[d][e] = d xi_e / d x_d
+        if constexpr (DIM == 2) {
+          det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+          const double r = 1.0 / det;
+          I[0][0] = J[1][1] * r;  I[0][1] = -J[0][1] * r;
+          I[1][0] = -J[1][0] * r; I[1][1] = J[0][0] * r;
+        } else {
+          const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+          const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+          const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+          det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+          const double r = 1.0 / det;
+          // inverse of J (as a matrix indexed [e][d]) is Jinv[d][e]
+          I[0][0] = c00 * r;
+          I[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
+          I[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
+          I[1][0] = c01 * r;
+          I[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
+          I[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
+          I[2][0] = c02 * r;
+          I[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
+          I[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
+        }
+        const double wdet = fabs(det);  // Gauss weights are 1
+        double Ga[DIM];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) {
+          double g = 0.0;
+#pragma unroll
+          for (int e = 0; e < DIM; ++e) g += I[d][e] * sdN[q][a][e];
+          Ga[d] = g;
+        }
+        const double Na = sN[q][a];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          double dotg = 0.0;
+#pragma unroll
+          for (int d = 0; d < DIM; ++d) {
+            double g = 0.0;
+#pragma unroll
+            for (int e = 0; e < DIM; ++e) g += I[d][e] * sdN[q][b][e];
+            dotg += Ga[d] * g;
+          }
+          Kr[b] += wdet * dotg;
+          Mr[b] += wdet * Na * sN[q][b];
+        }
+      }
+    }
+
+    // ---- wavefront-segmented scatter-add -------------------------------------------------------
+    // Entry (a,b) of cell c and entry (a-1,b-1) of cell c+1 hit the same CSR slot when the two cells
+    // share the corresponding nodes (x-neighbours in the lexicographic cell order).  The left lane
+    // (a odd) takes the right lane's value by shuffle and issues one atomic for both.
+    const int lane = tid & 63;
+    const int cw = lane / NB;  // cell inside the wavefront
+    const bool has_right = (cw + 1 < CPW);
+    const bool has_left = (cw > 0);
+    const int32_t row = valid ? sC[lc][a] : -1;
+    // does my row coincide with the partner's row?
+    const bool a_odd = (a & 1) != 0;
+    const int32_t right_row = (a_odd && has_right) ? sC[lc + 1][a - 1] : -2;   // sentinel row holds -1
+    const int32_t left_row = (!a_odd && has_left && lc > 0) ? sC[lc - 1][a + 1] : -2;
+    const bool row_recv = valid && a_odd && right_row == row;
+    const bool row_give = valid && !a_odd && left_row == row;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      double kv = Kr[b], mv = Mr[b];
+      bool emit = valid;
+      if (b & 1) {
+        // candidate receiver: partner lane = lane + NB - 1 holds entry (a-1, b-1) of the next cell
+        const double kp = __shfl(Kr[b - 1], lane + NB - 1, 64);
+        const double mp = __shfl(Mr[b - 1], lane + NB - 1, 64);
+        if (row_recv && sC[lc + 1][b - 1] == sC[lc][b]) { kv += kp; mv += mp; }
+      } else {
+        // candidate giver: my (a, b) with a even, b even is merged into the previous cell's (a+1, b+1)
+        if (row_give && sC[lc - 1][b + 1] == sC[lc][b]) emit = false;
+      }
+      if (emit) {
+        const int64_t slot = find_slot(rowptr, col, row, sC[lc][b]);
+        atomic_add_f64(K + slot, kv);
+        atomic_add_f64(M + slot, mv);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// simplices (P1 triangle: DIM 2, P1 tetrahedron: DIM 3): constant gradients, closed-form mass
+// one lane per (cell, local row); 4 lanes per cell (triangles leave the 4th lane idle)
+// ------------------------------------------------------------------------------------------------
+template <int DIM>
+__global__ __launch_bounds__(256) void k_asm_simplex(const int32_t* __restrict__ cells,
+                                                     const double* __restrict__ cx, const double* __restrict__ cy,
+                                                     const double* __restrict__ cz,
+                                                     const int64_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ col, double* __restrict__ K,
+                                                     double* __restrict__ M, int64_t ncell) {
+  constexpr int NB = DIM + 1;
+  const int64_t total = ncell * 4;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t cell = t >> 2;
+    const int a = (int)(t & 3);
+    if (a >= NB) continue;
+    int32_t nd[NB];
+    double X[NB][DIM];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      nd[b] = cells[cell * NB + b];
+      X[b][0] = cx[nd[b]];
+      X[b][1] = cy[nd[b]];
+      if constexpr (DIM == 3) X[b][2] = cz[nd[b]];
+    }
+    double E[DIM][DIM];  // E[r][d] = X[r+1][d] - X[0][d]
+#pragma unroll
+    for (int r = 0; r < DIM; ++r)
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) E[r][d] = X[r + 1][d] - X[0][d];
+    double det, G[NB][DIM];  // G[b][d] = d lambda_b / d x_d ; columns of E^-1 for b >= 1
+    if constexpr (DIM == 2) {
+      det = E[0][0] * E[1][1] - E[0][1] * E[1][0];
+      const double r = 1.0 / det;
+      // E^-1 = 1/det [[E11, -E01], [-E10, E00]] ; G[b][d] = Einv[d][b-1]
+      G[1][0] = E[1][1] * r;  G[1][1] = -E[1][0] * r;
+      G[2][0] = -E[0][1] * r; G[2][1] = E[0][0] * r;
+    } else {
+      const double c00 = E[1][1] * E[2][2] - E[1][2] * E[2][1];
+      const double c01 = E[1][2] * E[2][0] - E[1][0] * E[2][2];
+      const double c02 = E[1][0] * E[2][1] - E[1][1] * E[2][0];
+      det = E[0][0] * c00 + E[0][1] * c01 + E[0][2] * c02;
+      const double r = 1.0 / det;
+      double Inv[3][3];  // Inv = E^-1, Inv[d][r]
+      Inv[0][0] = c00 * r;
+      Inv[0][1] = (E[0][2] * E[2][1] - E[0][1] * E[2][2]) * r;
+      Inv[0][2] = (E[0][1] * E[1][2] - E[0][2] * E[1][1]) * r;
+      Inv[1][0] = c01 * r;
+      Inv[1][1] = (E[0][0] * E[2][2] - E[0][2] * E[2][0]) * r;
+      Inv[1][2] = (E[0][2] * E[1][0] - E[0][0] * E[1][2]) * r;
+      Inv[2][0] = c02 * r;
+      Inv[2][1] = (E[0][1] * E[2][0] - E[0][0] * E[2][1]) * r;
+      Inv[2][2] = (E[0][0] * E[1][1] - E[0][1] * E[1][0]) * r;
+#pragma unroll
+      for (int b = 1; b < NB; ++b)
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) G[b][d] = Inv[d][b - 1];
+    }
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+      double s = 0.0;
+#pragma unroll
+      for (int b = 1; b < NB; ++b) s += G[b][d];
+      G[0][d] = -s;
+    }
+    const double vol = fabs(det) / (DIM == 2 ? 2.0 : 6.0);
+    const double mfac = vol / (double)((DIM + 1) * (DIM + 2));
+    double Ga[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) {
+      double g = 0.0;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) g = (b == a) ? G[b][d] : g;
+      Ga[d] = g;
+    }
+    int32_t row = 0;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) row = (b == a) ? nd[b] : row;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      double dotg = 0.0;
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) dotg += Ga[d] * G[b][d];
+      const int64_t slot = find_slot(rowptr, col, row, nd[b]);
+      atomic_add_f64(K + slot, vol * dotg);
+      atomic_add_f64(M + slot, (b == a) ? 2.0 * mfac : mfac);
+    }
+  }
+}
+
+int pph_launch_assemble_KM(pph_ctx* ctx_, MeshData& mesh) {
+  pph_ctx* ctx = ctx_;
+  PPH_TRY(mesh.K.alloc(ctx, (size_t)mesh.nnzb));
+  PPH_TRY(mesh.M.alloc(ctx, (size_t)mesh.nnzb));
+  PPH_HIP(ctx, hipMemsetAsync(mesh.K.p, 0, sizeof(double) * mesh.nnzb, ctx->stream));
+  PPH_HIP(ctx, hipMemsetAsync(mesh.M.p, 0, sizeof(double) * mesh.nnzb, ctx->stream));
+  const int64_t ncell = mesh.ncell;
+  if (mesh.kind == PPH_CELL_QUAD || mesh.kind == PPH_CELL_HEX) {
+    const int cpb = 256 / mesh.m;
+    int64_t nbatch = ceil_div64(ncell, cpb);
+    int grid = (int)(nbatch < 256 * 16 ? nbatch : 256 * 16);
+    if (mesh.kind == PPH_CELL_QUAD)
+      hipLaunchKernelGGL(k_asm_multilinear<2>, dim3(grid), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p,
+                         mesh.cy.p, mesh.cz.p, mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, ncell);
+    else
+      hipLaunchKernelGGL(k_asm_multilinear<3>, dim3(grid), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p,
+                         mesh.cy.p, mesh.cz.p, mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, ncell);
+  } else {
+    int64_t nthreads = ncell * 4;
+    int64_t nb = ceil_div64(nthreads, 256);
+    int grid = (int)(nb < 256 * 16 ? nb : 256 * 16);
+    if (mesh.kind == PPH_CELL_TRI)
+      hipLaunchKernelGGL(k_asm_simplex<2>, dim3(grid), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p,
+                         mesh.cy.p, mesh.cz.p, mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, ncell);
+    else
+      hipLaunchKernelGGL(k_asm_simplex<3>, dim3(grid), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p,
+                         mesh.cy.p, mesh.cz.p, mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, ncell);
+  }
+  PPH_HIP(ctx, hipGetLastError());
+  return PPH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-BC: lifted right-hand side and Dirichlet-eliminated blocks (8 lanes per row)
+// mask bits: 1 = Dirichlet dof, 2 = ghost dof (row owned by the neighbouring slab)
+// ------------------------------------------------------------------------------------------------
+#define BC_LANES 8
+
+__global__ __launch_bounds__(256) void k_lift_rhs(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                  const double* __restrict__ K, const double* __restrict__ M,
+                                                  const uint8_t* __restrict__ m1, const uint8_t* __restrict__ m2,
+                                                  const double* __restrict__ g1, const double* __restrict__ g2,
+                                                  double a, double b, double c, int64_t n,
+                                                  double* __restrict__ rhs, double* __restrict__ u0) {
+  const int sub = threadIdx.x % BC_LANES;
+  for (int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / BC_LANES; row < n;
+       row += ((int64_t)gridDim.x * blockDim.x) / BC_LANES) {
+    double sK1 = 0, sK2 = 0, sM = 0;
+    for (int64_t k = rowptr[row] + sub; k < rowptr[row + 1]; k += BC_LANES) {
+      const int32_t j = col[k];
+      const double v1 = g1[j], v2 = g2[j];
+      const double kk = K[k], mm = M[k];
+      sK1 += kk * v1; sK2 += kk * v2; sM += mm * (v1 - v2);
+    }
+#pragma unroll
+    for (int o = BC_LANES / 2; o > 0; o >>= 1) {
+      sK1 += __shfl_down(sK1, o, BC_LANES);
+      sK2 += __shfl_down(sK2, o, BC_LANES);
+      sM += __shfl_down(sM, o, BC_LANES);
+    }
+    if (sub == 0) {
+      rhs[row] = (m1[row] != 0) ? 0.0 : -(a * sK1 + b * sM);
+      rhs[n + row] = (m2[row] != 0) ? 0.0 : -(c * sK2 - b * sM);
+      u0[row] = g1[row];
+      u0[n + row] = g2[row];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_blocks(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                const double* __restrict__ K, const double* __restrict__ M,
+                                                const uint8_t* __restrict__ m1, const uint8_t* __restrict__ m2,
+                                                double a, double b, double c, int64_t n, double* __restrict__ A11,
+                                                double* __restrict__ A22, double* __restrict__ A12,
+                                                double* __restrict__ A21) {
+  const int sub = threadIdx.x % BC_LANES;
+  for (int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / BC_LANES; row < n;
+       row += ((int64_t)gridDim.x * blockDim.x) / BC_LANES) {
+    const uint8_t r1 = m1[row], r2 = m2[row];
+    for (int64_t k = rowptr[row] + sub; k < rowptr[row + 1]; k += BC_LANES) {
+      const int32_t j = col[k];
+      const double kk = K[k], mm = M[k];
+      const bool diag = (j == (int32_t)row);
+      const bool c1 = (m1[j] & 1) != 0, c2 = (m2[j] & 1) != 0;
+      A11[k] = (r1 != 0) ? (diag ? 1.0 : 0.0) : (c1 ? 0.0 : a * kk + b * mm);
+      A22[k] = (r2 != 0) ? (diag ? 1.0 : 0.0) : (c2 ? 0.0 : c * kk + b * mm);
+      A12[k] = (r1 != 0 || c2) ? 0.0 : -b * mm;
+      A21[k] = (r2 != 0 || c1) ? 0.0 : -b * mm;
+    }
+  }
+}
+
+// monolithic field-major CSR: row i < n = [A11 row | A12 row], row n+i = [A21 row | A22 row]
+__global__ __launch_bounds__(256) void k_mono_rowptr(const int64_t* __restrict__ rowptr, int64_t n, int64_t nnzb,
+                                                     int64_t* __restrict__ mrowptr) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i <= n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    mrowptr[i] = 2 * rowptr[i];
+    mrowptr[n + i] = 2 * nnzb + 2 * rowptr[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_mono_fill(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                   const double* __restrict__ A11, const double* __restrict__ A22,
+                                                   const double* __restrict__ A12, const double* __restrict__ A21,
+                                                   int64_t n, int64_t nnzb, int32_t* __restrict__ mcol,
+                                                   double* __restrict__ mval) {
+  const int sub = threadIdx.x % BC_LANES;
+  for (int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / BC_LANES; row < n;
+       row += ((int64_t)gridDim.x * blockDim.x) / BC_LANES) {
+    const int64_t s = rowptr[row], e = rowptr[row + 1], len = e - s;
+    const int64_t o1 = 2 * s, o2 = 2 * nnzb + 2 * s;
+    for (int64_t k = s + sub; k < e; k += BC_LANES) {
+      const int32_t j = col[k];
+      const int64_t q = k - s;
+      mcol[o1 + q] = j;            mval[o1 + q] = A11[k];
+      mcol[o1 + len + q] = j + (int32_t)n; mval[o1 + len + q] = A12[k];
+      mcol[o2 + q] = j;            mval[o2 + q] = A21[k];
+      mcol[o2 + len + q] = j + (int32_t)n; mval[o2 + len + q] = A22[k];
+    }
+  }
+}
+
+int pph_launch_blocks(pph_ctx* ctx, int monolithic) {
+  const int64_t n = ctx->n, nnzb = ctx->nnzb;
+  PPH_TRY(ctx->A11.alloc(ctx, (size_t)nnzb));
+  PPH_TRY(ctx->A22.alloc(ctx, (size_t)nnzb));
+  PPH_TRY(ctx->A12.alloc(ctx, (size_t)nnzb));
+  PPH_TRY(ctx->A21.alloc(ctx, (size_t)nnzb));
+  PPH_TRY(ctx->rhs.alloc(ctx, (size_t)(2 * n)));
+  PPH_TRY(ctx->u0.alloc(ctx, (size_t)(2 * n)));
+  PPH_TRY(ctx->sol.alloc(ctx, (size_t)(2 * n)));
+  int64_t nb = ceil_div64(n * BC_LANES, 256);
+  int grid = (int)(nb < 256 * 16 ? nb : 256 * 16);
+  hipLaunchKernelGGL(k_lift_rhs, dim3(grid), dim3(256), 0, ctx->stream, ctx->mesh.rowptr.p, ctx->mesh.col.p, ctx->mesh.K.p,
+                     ctx->mesh.M.p, ctx->bcmask[0].p, ctx->bcmask[1].p, ctx->g[0].p, ctx->g[1].p, ctx->a, ctx->b, ctx->c,
+                     n, ctx->rhs.p, ctx->u0.p);
+  hipLaunchKernelGGL(k_blocks, dim3(grid), dim3(256), 0, ctx->stream, ctx->mesh.rowptr.p, ctx->mesh.col.p, ctx->mesh.K.p, ctx->mesh.M.p,
+                     ctx->bcmask[0].p, ctx->bcmask[1].p, ctx->a, ctx->b, ctx->c, n, ctx->A11.p, ctx->A22.p,
+                     ctx->A12.p, ctx->A21.p);
+  PPH_HIP(ctx, hipGetLastError());
+  ctx->mono_ok = false;
+  if (monolithic) {
+    PPH_REQUIRE(ctx, 4 * nnzb < (int64_t)2147483647 * 4 && 2 * n < (int64_t)2147483647,
+                "monolithic system too large for int32 columns");
+    PPH_TRY(ctx->mrowptr.alloc(ctx, (size_t)(2 * n + 1)));
+    PPH_TRY(ctx->mcol.alloc(ctx, (size_t)(4 * nnzb)));
+    PPH_TRY(ctx->mval.alloc(ctx, (size_t)(4 * nnzb)));
+    int g2 = (int)(ceil_div64(n + 1, 256) < 4096 ? ceil_div64(n + 1, 256) : 4096);
+    hipLaunchKernelGGL(k_mono_rowptr, dim3(g2), dim3(256), 0, ctx->stream, ctx->mesh.rowptr.p, n, nnzb, ctx->mrowptr.p);
+    hipLaunchKernelGGL(k_mono_fill, dim3(grid), dim3(256), 0, ctx->stream, ctx->mesh.rowptr.p, ctx->mesh.col.p, ctx->A11.p,
+                       ctx->A22.p, ctx->A12.p, ctx->A21.p, n, nnzb, ctx->mcol.p, ctx->mval.p);
+    PPH_HIP(ctx, hipGetLastError());
+    ctx->mono_ok = true;
+  }
+  return PPH_OK;
+}
+
+// one Dirichlet-eliminated scalar operator coefK*K + coefM*M on any level (multigrid coarse operators)
+__global__ __launch_bounds__(256) void k_scalar_block(const int64_t* __restrict__ rowptr,
+                                                      const int32_t* __restrict__ col, const double* __restrict__ K,
+                                                      const double* __restrict__ M, const uint8_t* __restrict__ mask,
+                                                      double coefK, double coefM, int64_t n, double* __restrict__ out) {
+  const int sub = threadIdx.x % BC_LANES;
+  for (int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / BC_LANES; row < n;
+       row += ((int64_t)gridDim.x * blockDim.x) / BC_LANES) {
+    const uint8_t r = mask[row];
+    for (int64_t k = rowptr[row] + sub; k < rowptr[row + 1]; k += BC_LANES) {
+      const int32_t j = col[k];
+      const bool diag = (j == (int32_t)row);
+      out[k] = (r != 0) ? (diag ? 1.0 : 0.0) : (((mask[j] & 1) != 0) ? 0.0 : coefK * K[k] + coefM * M[k]);
+    }
+  }
+}
+
+void pph_launch_scalar_block(pph_ctx* ctx, const MeshData& mesh, const uint8_t* mask, double coefK, double coefM,
+                             double* out) {
+  int64_t nb = ceil_div64(mesh.n * BC_LANES, 256);
+  int grid = (int)(nb < 256 * 16 ? nb : 256 * 16);
+  hipLaunchKernelGGL(k_scalar_block, dim3(grid), dim3(256), 0, ctx->stream, mesh.rowptr.p, mesh.col.p, mesh.K.p,
+                     mesh.M.p, mask, coefK, coefM, mesh.n, out);
+}

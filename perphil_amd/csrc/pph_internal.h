@@ -1,0 +1,197 @@
+// Internal declarations shared by the translation units of libperphil_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/perphil_hip.h"
+
+#define PPH_WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing: HIP failures become a negative status + message, never an abort
+// ---------------------------------------------------------------------------------------------
+void pph_set_error(pph_ctx* ctx, const char* fmt, ...);
+
+#define PPH_HIP(ctx, call)                                                                     \
+  do {                                                                                         \
+    hipError_t e__ = (call);                                                                   \
+    if (e__ != hipSuccess) {                                                                   \
+      pph_set_error((ctx), "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__,   \
+                    __LINE__);                                                                 \
+      return (e__ == hipErrorOutOfMemory) ? PPH_ERR_NOMEM : PPH_ERR_HIP;                       \
+    }                                                                                          \
+  } while (0)
+
+#define PPH_TRY(expr)           \
+  do {                          \
+    int s__ = (expr);           \
+    if (s__ < 0) return s__;    \
+  } while (0)
+
+#define PPH_REQUIRE(ctx, cond, ...)        \
+  do {                                     \
+    if (!(cond)) {                         \
+      pph_set_error((ctx), __VA_ARGS__);   \
+      return PPH_ERR_INVALID;              \
+    }                                      \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// device buffers
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  int alloc(pph_ctx* ctx, size_t count);
+  void release();
+};
+
+struct Csr {  // device CSR view (no ownership)
+  const int64_t* rowptr = nullptr;
+  const int32_t* col = nullptr;
+  const double* val = nullptr;
+  int64_t nrows = 0;
+  int64_t nnz = 0;
+  int lanes = 8;  // lanes per row used by the SpMV kernel
+};
+
+// one structured mesh level (local box): geometry, cell->dof map, scalar pattern, K and M
+struct MeshData {
+  int dim = 0, kind = -1, m = 0;        // m = nodes per cell
+  int nx = 0, ny = 0, nz = 0;           // global cells of this level
+  int z0 = 0, nzl = 0;                  // local slab: first cell layer, layer count
+  int px = 0, py = 0, pzl = 0;          // local node dims
+  int64_t n = 0, ncell = 0, nnzb = 0;   // nodes, cells, nnz of one scalar block
+  DevBuf<double> cx, cy, cz;            // nodal coordinates (SoA)
+  DevBuf<int32_t> cells;                // cell -> dof map [ncell][m]
+  DevBuf<int64_t> rowptr;               // scalar CSR pattern
+  DevBuf<int32_t> col;
+  DevBuf<double> K, M;                  // scalar stiffness / mass values
+  void release_geometry() { cx.release(); cy.release(); cz.release(); cells.release(); K.release(); M.release(); }
+  void release_all() { release_geometry(); rowptr.release(); col.release(); }
+};
+
+// one level of the geometric multigrid hierarchy for a scalar block (structured, coarsening 2)
+struct MgLevel {
+  MeshData mesh;                 // coarse levels own their mesh; level 0 aliases the context's
+  const int64_t* rowptr = nullptr;
+  const int32_t* col = nullptr;
+  const double* val[2] = {nullptr, nullptr};   // A11-like and A22-like operators on this level
+  int64_t n = 0, nnz = 0;
+  int px = 0, py = 0, pz = 0;
+  DevBuf<double> own_val[2];     // storage of val[] on coarse levels
+  DevBuf<double> dinv[2];
+  DevBuf<uint8_t> mask[2];       // per field: non-zero where the dof is constrained
+  const uint8_t* maskp[2] = {nullptr, nullptr};
+  DevBuf<double> x, b, r, d, t, w;  // work vectors of the V-cycle (x, b unused on level 0)
+  double lam[2] = {0, 0};        // upper bound of the spectrum of D^-1 A
+};
+
+struct pph_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+
+  // mesh (local box)
+  MeshData mesh;
+  int ghost_lo = 0, ghost_hi = 0;
+  int64_t n = 0, nnzb = 0;              // copies of mesh.n / mesh.nnzb
+  bool mesh_ok = false, asm_ok = false, mono_ok = false;
+  DevBuf<uint8_t> bcmask[2];            // per field: 1 Dirichlet, 2 ghost, 0 free
+  DevBuf<double> g[2];                  // per field Dirichlet values (dense, 0 elsewhere)
+  DevBuf<double> A11, A22, A12, A21;    // eliminated blocks on the scalar pattern
+  DevBuf<double> rhs, u0, sol;          // length 2n
+  DevBuf<int64_t> mrowptr;              // monolithic CSR
+  DevBuf<int32_t> mcol;
+  DevBuf<double> mval;
+  double a = 0, b = 0, c = 0;           // k1/mu, beta/mu, k2/mu
+
+  // solver workspace
+  DevBuf<double> scal;                  // device scalars / reduction partials
+  double* h_scal = nullptr;             // pinned host mirror
+  std::vector<DevBuf<double>> work;     // named work vectors, grown on demand
+  std::vector<MgLevel> mg;              // multigrid hierarchy (level 0 = fine)
+  bool mg_ok = false;
+
+  // timers (ms)
+  double t_mesh = 0, t_asm = 0, t_bc = 0, t_solve = 0;
+  // SpMV accounting of the last solve, per kernel variant (0: k_spmv<G,false>, 1: k_spmv<G,true>):
+  // launches, algorithmic bytes (12 nnz + 20 nrows per launch) and, when time_spmv is on, the sum of
+  // the per-launch durations taken with HIP event pairs recorded on the context stream
+  double t_spmv[2] = {0, 0};
+  double spmv_bytes[2] = {0, 0};
+  int64_t n_spmv[2] = {0, 0};
+  bool time_spmv = false;
+  struct EvPair { hipEvent_t e0, e1; int variant; };
+  std::vector<EvPair> ev_pool;          // reusable event pairs
+  size_t ev_used = 0;                   // pairs recorded since the last harvest
+  int spmv_lanes_override = 0;          // 0: pick from the mean row length
+};
+
+// lanes per row of the CSR-vector SpMV for a matrix with the given mean row length
+static inline int pph_pick_lanes(const pph_ctx* ctx, int64_t nnz, int64_t nrows) {
+  if (ctx->spmv_lanes_override > 0) return ctx->spmv_lanes_override;
+  const double avg = (double)nnz / (double)(nrows > 0 ? nrows : 1);
+  return avg > 40 ? 16 : (avg > 12 ? 8 : 4);
+}
+
+// ---------------------------------------------------------------------------------------------
+// kernels / launchers (pph_mesh.hip, pph_assemble.hip, pph_la.hip)
+// ---------------------------------------------------------------------------------------------
+int pph_launch_mesh(pph_ctx* ctx, MeshData& mesh);
+int pph_launch_pattern(pph_ctx* ctx, int dim, int kind, int px, int py, int pz, DevBuf<int64_t>& rowptr,
+                       DevBuf<int32_t>& col, int64_t* nnz_out);
+int pph_launch_assemble_KM(pph_ctx* ctx, MeshData& mesh);
+int pph_launch_blocks(pph_ctx* ctx, int monolithic);
+
+// linear algebra on the context stream; all results that feed control flow go through ctx->scal
+void la_spmv(pph_ctx* ctx, const Csr& A, const double* x, double* y);
+// y = A x and partial sums of dot(x, y) -> scal slot
+void la_spmv_dot(pph_ctx* ctx, const Csr& A, const double* x, double* y, int slot);
+void la_set(pph_ctx* ctx, double* x, double v, int64_t n);
+void la_copy(pph_ctx* ctx, double* dst, const double* src, int64_t n);
+void la_axpy(pph_ctx* ctx, double* y, double alpha, const double* x, int64_t n);          // y += alpha x
+void la_axpby(pph_ctx* ctx, double* y, double alpha, const double* x, double beta, int64_t n);  // y = alpha x + beta y
+void la_scale(pph_ctx* ctx, double* y, double alpha, int64_t n);
+void la_pointwise_mult(pph_ctx* ctx, double* z, const double* d, const double* r, int64_t n);  // z = d .* r
+void la_sub(pph_ctx* ctx, double* z, const double* a, const double* b, int64_t n);          // z = a - b
+void la_block2_apply(pph_ctx* ctx, double* z, const double* binv /*[4][n]*/, const double* r, int64_t n);
+// k dots in one pass: out[slot+i] = dot(V_i, w), i < k  (V_i = V + i*ld)
+void la_mdot(pph_ctx* ctx, const double* V, int64_t ld, int k, const double* w, int64_t n, int slot);
+// w -= sum_i h[i] V_i   (h on host)
+void la_maxpy_neg(pph_ctx* ctx, double* w, const double* V, int64_t ld, int k, const double* h, int64_t n);
+// x += sum_i y[i] V_i
+void la_maxpy(pph_ctx* ctx, double* x, const double* V, int64_t ld, int k, const double* y, int64_t n);
+void la_dot(pph_ctx* ctx, const double* x, const double* y, int64_t n, int slot);
+void la_dot2(pph_ctx* ctx, const double* x, const double* y, const double* z, int64_t n, int slot);  // x.y , z.z
+// fused CG update with Jacobi-type PC: x += alpha p; r -= alpha q; z = dinv.*r (dinv may be null: z=r);
+// scal[slot] = r.z, scal[slot+1] = z.z
+void la_cg_update(pph_ctx* ctx, double* x, double* r, double* z, const double* p, const double* q,
+                  const double* dinv, double alpha, int64_t n, int slot);
+void la_extract_diag_inv(pph_ctx* ctx, const Csr& A, double* dinv);
+// fetch `count` reduction results starting at slot into ctx->h_scal (synchronises the stream)
+int la_fetch(pph_ctx* ctx, int slot, int count);
+// adds the elapsed times of all event pairs recorded since the last call to ctx->t_spmv (synchronises)
+void la_harvest_spmv_times(pph_ctx* ctx);
+void la_reset_spmv_stats(pph_ctx* ctx);
+
+// block values + Dirichlet elimination on any level: out = (row constrained) ? I : coefK*K + coefM*M with
+// constrained columns zeroed
+void pph_launch_scalar_block(pph_ctx* ctx, const MeshData& mesh, const uint8_t* mask, double coefK, double coefM,
+                             double* out);
+// Jacobi-preconditioned CG on caller-supplied work vectors (used by the multigrid coarsest level)
+int pph_cg_jacobi(pph_ctx* ctx, const Csr& A, const double* b, double* x, const double* dinv, double rtol, double atol,
+                  int max_it, double* r, double* z, double* p, double* q, int* its);
+// multigrid (pph_mg.hip)
+int mg_setup(pph_ctx* ctx);
+void mg_release(pph_ctx* ctx);
+// z = Vcycle(r) for block `which` (0: A11, 1: A22); r and z have fine-level length n
+void mg_vcycle(pph_ctx* ctx, int which, const double* r, double* z, int nsmooth);
+
+static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+#define PPH_MAX_SCAL 4096  // reduction slots in ctx->scal

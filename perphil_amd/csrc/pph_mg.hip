@@ -1,0 +1,311 @@
+// Geometric multigrid V-cycle for the scalar blocks A11 = (k1/mu)K + (beta/mu)M and
+// A22 = (k2/mu)K + (beta/mu)M: the GPU stand-in for the LU block solves of the reference's
+// field-split / Picard configurations (reference src/perphil/solvers/parameters.py:30-37, :79-85).
+//
+// Hierarchy: nx/2^l structured meshes, operators re-discretised on every level with the same
+// K-ASM kernels (equal to the Galerkin product for the nested CG-1 spaces), Dirichlet masks injected.
+// Smoother: Chebyshev-Jacobi on [lam/4, lam], lam = max row sum of |D^-1 A|.  Transfers: the
+// interpolation of the CG-1 basis (multilinear for Q1, edge-midpoint averaging for the Kuhn /
+// left-diagonal P1 triangulations) and its transpose.  The cycle is symmetric, so it is a valid CG
+// preconditioner.  oracle/dpp_mg_oracle.py restates it for the parity tests.
+#include "pph_internal.h"
+#include <cmath>
+#include <cstring>
+
+#define MG_CHEB_LOWER 0.25
+
+struct TStencil {
+  int count;
+  int8_t d[27][3];
+  double w[27];
+};
+
+static TStencil make_transfer_stencil(int kind) {
+  TStencil s;
+  s.count = 0;
+  auto push = [&](int dx, int dy, int dz) {
+    const int nzc = (dx != 0) + (dy != 0) + (dz != 0);
+    double w;
+    if (kind == PPH_CELL_QUAD || kind == PPH_CELL_HEX) w = std::ldexp(1.0, -nzc);
+    else w = (nzc == 0) ? 1.0 : 0.5;
+    s.d[s.count][0] = (int8_t)dx; s.d[s.count][1] = (int8_t)dy; s.d[s.count][2] = (int8_t)dz;
+    s.w[s.count] = w;
+    s.count++;
+  };
+  if (kind == PPH_CELL_QUAD) {
+    for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) push(dx, dy, 0);
+  } else if (kind == PPH_CELL_TRI) {
+    push(0, -1, 0); push(1, -1, 0); push(-1, 0, 0); push(0, 0, 0); push(1, 0, 0); push(-1, 1, 0); push(0, 1, 0);
+  } else if (kind == PPH_CELL_HEX) {
+    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) push(dx, dy, dz);
+  } else {
+    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+      const bool pos = dx >= 0 && dy >= 0 && dz >= 0, neg = dx <= 0 && dy <= 0 && dz <= 0;
+      if (pos || neg) push(dx, dy, dz);
+    }
+  }
+  return s;
+}
+
+#define NODE_LOOP(id, n) \
+  for (int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; id < (n); id += (int64_t)gridDim.x * blockDim.x)
+
+__global__ void k_inject_mask(uint8_t* __restrict__ mc, const uint8_t* __restrict__ mf, int pxc, int pyc, int pzc,
+                              int pxf, int pyf) {
+  const int64_t nc = (int64_t)pxc * pyc * pzc;
+  NODE_LOOP(id, nc) {
+    const int I = (int)(id % pxc);
+    const int64_t t = id / pxc;
+    const int J = (int)(t % pyc), K = (int)(t / pyc);
+    mc[id] = mf[2 * I + (int64_t)pxf * (2 * J + (int64_t)pyf * (2 * K))];
+  }
+}
+
+// b_c[C] = sum_d w_d r_f[2C + d]   (0 on constrained coarse dofs)
+__global__ void k_restrict(double* __restrict__ bc, const double* __restrict__ rf, TStencil st,
+                           const uint8_t* __restrict__ mc, const uint8_t* __restrict__ mf, int pxc, int pyc, int pzc,
+                           int pxf, int pyf, int pzf) {
+  const int64_t nc = (int64_t)pxc * pyc * pzc;
+  NODE_LOOP(id, nc) {
+    const int I = (int)(id % pxc);
+    const int64_t t = id / pxc;
+    const int J = (int)(t % pyc), K = (int)(t / pyc);
+    double s = 0.0;
+    if (mc[id] == 0) {
+      for (int q = 0; q < st.count; ++q) {
+        const int i = 2 * I + st.d[q][0], j = 2 * J + st.d[q][1], k = 2 * K + st.d[q][2];
+        if (i >= 0 && i < pxf && j >= 0 && j < pyf && k >= 0 && k < pzf) {
+          const int64_t f = i + (int64_t)pxf * (j + (int64_t)pyf * k);
+          if (mf[f] == 0) s += st.w[q] * rf[f];
+        }
+      }
+    }
+    bc[id] = s;
+  }
+}
+
+// x_f[f] += sum over (C, d) with 2C + d = f of w_d x_c[C]   (constrained fine dofs untouched)
+__global__ void k_prolong_add(double* __restrict__ xf, const double* __restrict__ xc, TStencil st,
+                              const uint8_t* __restrict__ mf, int pxc, int pyc, int pzc, int pxf, int pyf, int pzf) {
+  const int64_t nf = (int64_t)pxf * pyf * pzf;
+  NODE_LOOP(id, nf) {
+    if (mf[id] != 0) continue;
+    const int i = (int)(id % pxf);
+    const int64_t t = id / pxf;
+    const int j = (int)(t % pyf), k = (int)(t / pyf);
+    double s = 0.0;
+    for (int q = 0; q < st.count; ++q) {
+      const int ci = i - st.d[q][0], cj = j - st.d[q][1], ck = k - st.d[q][2];
+      if (((ci | cj | ck) & 1) != 0) continue;
+      const int I = ci >> 1, J = cj >> 1, K = ck >> 1;
+      if (ci >= 0 && I < pxc && cj >= 0 && J < pyc && ck >= 0 && K < pzc)
+        s += st.w[q] * xc[I + (int64_t)pxc * (J + (int64_t)pyc * K)];
+    }
+    xf[id] += s;
+  }
+}
+
+// max over rows of sum_j |a_ij| / a_ii, accumulated with an integer atomic max on the bit pattern
+__global__ void k_lam_bound(const int64_t* __restrict__ rowptr, const double* __restrict__ val,
+                            const double* __restrict__ dinv, int64_t n, unsigned long long* __restrict__ out) {
+  double best = 0.0;
+  NODE_LOOP(row, n) {
+    double s = 0.0;
+    for (int64_t k = rowptr[row]; k < rowptr[row + 1]; ++k) s += fabs(val[k]);
+    s *= fabs(dinv[row]);
+    best = s > best ? s : best;
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const double t = __shfl_down(best, o, 64);
+    best = t > best ? t : best;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMax(out, (unsigned long long)__double_as_longlong(best));
+}
+
+// d = dinv .* r / theta ; x = d (zero guess) or x += d
+__global__ void k_cheb_init(double* __restrict__ x, double* __restrict__ d, const double* __restrict__ r,
+                            const double* __restrict__ dinv, double inv_theta, int zero_guess, int64_t n) {
+  NODE_LOOP(i, n) {
+    const double di = dinv[i] * r[i] * inv_theta;
+    d[i] = di;
+    x[i] = zero_guess ? di : x[i] + di;
+  }
+}
+
+// r -= t ; d = c1 d + c2 dinv .* r ; x += d      (t = A d_old)
+__global__ void k_cheb_step(double* __restrict__ x, double* __restrict__ d, double* __restrict__ r,
+                            const double* __restrict__ t, const double* __restrict__ dinv, double c1, double c2,
+                            int64_t n) {
+  NODE_LOOP(i, n) {
+    const double ri = r[i] - t[i];
+    r[i] = ri;
+    const double di = c1 * d[i] + c2 * dinv[i] * ri;
+    d[i] = di;
+    x[i] += di;
+  }
+}
+
+static inline int mg_grid(int64_t n) {
+  int64_t b = ceil_div64(n, 256);
+  if (b < 1) b = 1;
+  if (b > 2048) b = 2048;
+  return (int)b;
+}
+
+static Csr level_csr(const pph_ctx* ctx, const MgLevel& L, int which) {
+  Csr A;
+  A.rowptr = L.rowptr; A.col = L.col; A.val = L.val[which]; A.nrows = L.n; A.nnz = L.nnz;
+  A.lanes = pph_pick_lanes(ctx, A.nnz, A.nrows);
+  return A;
+}
+
+void mg_release(pph_ctx* ctx) {
+  for (size_t l = 0; l < ctx->mg.size(); ++l) {
+    MgLevel& L = ctx->mg[l];
+    if (l > 0) L.mesh.release_all();
+    for (int f = 0; f < 2; ++f) { L.own_val[f].release(); L.dinv[f].release(); L.mask[f].release(); }
+    L.x.release(); L.b.release(); L.r.release(); L.d.release(); L.t.release(); L.w.release();
+  }
+  ctx->mg.clear();
+  ctx->mg_ok = false;
+}
+
+int mg_setup(pph_ctx* ctx) {
+  if (ctx->mg_ok) return PPH_OK;
+  mg_release(ctx);
+  const MeshData& fm = ctx->mesh;
+  PPH_REQUIRE(ctx, ctx->ghost_lo == 0 && ctx->ghost_hi == 0, "multigrid on slab-decomposed meshes is not available");
+  // count levels: halve while every direction stays even and keeps >= 2 cells
+  int nlev = 1;
+  {
+    int nx = fm.nx, ny = fm.ny, nz = fm.nzl;
+    while (nx % 2 == 0 && ny % 2 == 0 && (fm.dim == 2 || nz % 2 == 0) && nx / 2 >= 2 && ny / 2 >= 2 &&
+           (fm.dim == 2 || nz / 2 >= 2)) {
+      nx /= 2; ny /= 2; nz /= 2; nlev++;
+    }
+  }
+  ctx->mg.resize(nlev);
+  DevBuf<unsigned long long> lamdev;
+  PPH_TRY(lamdev.alloc(ctx, 2));
+  const double coefK[2] = {ctx->a, ctx->c};
+  for (int l = 0; l < nlev; ++l) {
+    MgLevel& L = ctx->mg[l];
+    if (l == 0) {
+      L.rowptr = fm.rowptr.p; L.col = fm.col.p; L.val[0] = ctx->A11.p; L.val[1] = ctx->A22.p;
+      L.n = fm.n; L.nnz = fm.nnzb; L.px = fm.px; L.py = fm.py; L.pz = fm.pzl;
+      L.maskp[0] = ctx->bcmask[0].p; L.maskp[1] = ctx->bcmask[1].p;
+    } else {
+      const MgLevel& F = ctx->mg[l - 1];
+      MeshData& m = L.mesh;
+      m.dim = fm.dim; m.kind = fm.kind;
+      m.nx = fm.nx >> l; m.ny = fm.ny >> l; m.nz = (fm.dim == 3) ? (fm.nz >> l) : 0;
+      m.z0 = 0; m.nzl = (fm.dim == 3) ? (fm.nzl >> l) : 0;
+      PPH_TRY(pph_launch_mesh(ctx, m));
+      PPH_TRY(pph_launch_assemble_KM(ctx, m));
+      L.rowptr = m.rowptr.p; L.col = m.col.p; L.n = m.n; L.nnz = m.nnzb; L.px = m.px; L.py = m.py; L.pz = m.pzl;
+      for (int f = 0; f < 2; ++f) {
+        PPH_TRY(L.mask[f].alloc(ctx, (size_t)L.n));
+        hipLaunchKernelGGL(k_inject_mask, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, L.mask[f].p, F.maskp[f], L.px,
+                           L.py, L.pz, F.px, F.py);
+        L.maskp[f] = L.mask[f].p;
+        PPH_TRY(L.own_val[f].alloc(ctx, (size_t)L.nnz));
+        pph_launch_scalar_block(ctx, m, L.maskp[f], coefK[f], ctx->b, L.own_val[f].p);
+        L.val[f] = L.own_val[f].p;
+      }
+      PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      m.release_geometry();
+    }
+    for (int f = 0; f < 2; ++f) {
+      PPH_TRY(L.dinv[f].alloc(ctx, (size_t)L.n));
+      la_extract_diag_inv(ctx, level_csr(ctx, L, f), L.dinv[f].p);
+    }
+    PPH_HIP(ctx, hipMemsetAsync(lamdev.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    for (int f = 0; f < 2; ++f)
+      hipLaunchKernelGGL(k_lam_bound, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, L.rowptr, L.val[f], L.dinv[f].p,
+                         L.n, lamdev.p + f);
+    unsigned long long bits[2];
+    PPH_HIP(ctx, hipMemcpyAsync(bits, lamdev.p, sizeof(bits), hipMemcpyDeviceToHost, ctx->stream));
+    PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int f = 0; f < 2; ++f) {
+      double v;
+      memcpy(&v, &bits[f], sizeof(double));
+      L.lam[f] = v;
+      PPH_REQUIRE(ctx, v > 0.0 && v == v, "multigrid level %d: bad spectral bound %g", l, v);
+    }
+    if (l > 0) { PPH_TRY(L.x.alloc(ctx, (size_t)L.n)); PPH_TRY(L.b.alloc(ctx, (size_t)L.n)); }
+    PPH_TRY(L.r.alloc(ctx, (size_t)L.n));
+    PPH_TRY(L.d.alloc(ctx, (size_t)L.n));
+    PPH_TRY(L.t.alloc(ctx, (size_t)L.n));
+    if (l == nlev - 1) PPH_TRY(L.w.alloc(ctx, (size_t)L.n));
+  }
+  lamdev.release();
+  PPH_HIP(ctx, hipGetLastError());
+  ctx->mg_ok = true;
+  return PPH_OK;
+}
+
+// `steps` Chebyshev-Jacobi steps on A x = b.  zero_guess: x is overwritten, no initial SpMV.
+static void chebyshev(pph_ctx* ctx, MgLevel& L, int which, const double* b, double* x, int steps, bool zero_guess) {
+  const Csr A = level_csr(ctx, L, which);
+  const double hi = L.lam[which], lo = MG_CHEB_LOWER * hi;
+  const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo);
+  const double sigma = theta / delta;
+  double rho = 1.0 / sigma;
+  double* r = L.r.p;
+  const int grid = mg_grid(L.n);
+  if (zero_guess) {
+    la_copy(ctx, r, b, L.n);
+  } else {
+    la_spmv(ctx, A, x, L.t.p);
+    la_sub(ctx, r, b, L.t.p, L.n);
+  }
+  hipLaunchKernelGGL(k_cheb_init, dim3(grid), dim3(256), 0, ctx->stream, x, L.d.p, r, L.dinv[which].p, 1.0 / theta,
+                     zero_guess ? 1 : 0, L.n);
+  for (int s = 1; s < steps; ++s) {
+    la_spmv(ctx, A, L.d.p, L.t.p);
+    const double rho_new = 1.0 / (2.0 * sigma - rho);
+    hipLaunchKernelGGL(k_cheb_step, dim3(grid), dim3(256), 0, ctx->stream, x, L.d.p, r, L.t.p, L.dinv[which].p,
+                       rho_new * rho, 2.0 * rho_new / delta, L.n);
+    rho = rho_new;
+  }
+}
+
+void mg_vcycle(pph_ctx* ctx, int which, const double* rin, double* zout, int nsmooth) {
+  std::vector<MgLevel>& mg = ctx->mg;
+  const int nlev = (int)mg.size();
+  const TStencil st = make_transfer_stencil(ctx->mesh.kind);
+  if (nlev == 1) {
+    // mesh cannot be coarsened: polynomial (Chebyshev) preconditioner only
+    chebyshev(ctx, mg[0], which, rin, zout, nsmooth > 2 ? nsmooth : 2, true);
+    return;
+  }
+  // downward leg
+  for (int l = 0; l < nlev - 1; ++l) {
+    MgLevel& L = mg[l];
+    MgLevel& C = mg[l + 1];
+    const double* b = (l == 0) ? rin : L.b.p;
+    double* x = (l == 0) ? zout : L.x.p;
+    chebyshev(ctx, L, which, b, x, nsmooth, true);
+    la_spmv(ctx, level_csr(ctx, L, which), x, L.t.p);
+    la_sub(ctx, L.r.p, b, L.t.p, L.n);
+    hipLaunchKernelGGL(k_restrict, dim3(mg_grid(C.n)), dim3(256), 0, ctx->stream, C.b.p, L.r.p, st, C.maskp[which],
+                       L.maskp[which], C.px, C.py, C.pz, L.px, L.py, L.pz);
+  }
+  // coarsest level: Jacobi-CG to 1e-12 (a handful of unknowns)
+  {
+    MgLevel& C = mg[nlev - 1];
+    int its = 0;
+    pph_cg_jacobi(ctx, level_csr(ctx, C, which), C.b.p, C.x.p, C.dinv[which].p, 1e-12, 0.0, 500, C.r.p, C.d.p, C.t.p,
+                  C.w.p, &its);
+  }
+  // upward leg
+  for (int l = nlev - 2; l >= 0; --l) {
+    MgLevel& L = mg[l];
+    MgLevel& C = mg[l + 1];
+    const double* b = (l == 0) ? rin : L.b.p;
+    double* x = (l == 0) ? zout : L.x.p;
+    hipLaunchKernelGGL(k_prolong_add, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, x, C.x.p, st, L.maskp[which],
+                       C.px, C.py, C.pz, L.px, L.py, L.pz);
+    chebyshev(ctx, L, which, b, x, nsmooth, false);
+  }
+}

@@ -1,0 +1,498 @@
+// Host-side Krylov / preconditioner / Picard drivers over the device kernels of pph_la.hip.
+//
+// Replaces KSPSolve (GMRES(30) / CG), PCApply (none, jacobi, fieldsplit multiplicative) and the
+// SNES(ksponly) wrapper that reference src/perphil/solvers/solver.py:67-74 drives through
+// LinearVariationalSolver; the Picard loop is the block iteration stated by dpp_delayed_form
+// (reference src/perphil/forms/dpp.py:196-203).  PETSc semantics kept: left preconditioning,
+// convergence test on the preconditioned residual, ||r|| <= max(rtol*||P^-1 b||, atol), restart 30,
+// classical Gram-Schmidt without refinement, zero initial guess for KSP solves.
+#include "pph_internal.h"
+#include <cmath>
+#include <functional>
+
+// slots in ctx->scal used by the drivers
+enum { S_A = 0, S_B = 2, S_C = 4, S_INNER = 8, S_COARSE = 16, S_MDOT = 64 };
+
+// work vector ids
+enum {
+  W_R = 0, W_Z, W_P, W_Q, W_T,          // outer CG
+  W_IR, W_IZ, W_IP, W_IQ,               // inner CG (block solves)
+  W_GV, W_GW, W_GT,                     // GMRES basis / work
+  W_FS1, W_FS2,                         // field-split temporaries
+  W_DINV_M, W_DINV_1, W_DINV_2, W_BINV, // preconditioner data
+  W_DU, W_PB,                           // Picard correction, block rhs
+  W_COUNT
+};
+
+static int work(pph_ctx* ctx, int id, size_t n, double** out) {
+  if ((int)ctx->work.size() < W_COUNT) ctx->work.resize(W_COUNT);
+  DevBuf<double>& b = ctx->work[id];
+  if (b.n < n) {
+    b.release();
+    PPH_TRY(b.alloc(ctx, n));
+  }
+  *out = b.p;
+  return PPH_OK;
+}
+
+typedef std::function<void(const double*, double*)> ApplyFn;
+
+struct KspOut {
+  int its = 0;
+  double res = 0.0;
+  bool converged = false;
+  bool breakdown = false;
+};
+
+static Csr block_csr(pph_ctx* ctx, const double* val) {
+  Csr A;
+  A.rowptr = ctx->mesh.rowptr.p; A.col = ctx->mesh.col.p; A.val = val; A.nrows = ctx->n; A.nnz = ctx->nnzb;
+  A.lanes = pph_pick_lanes(ctx, A.nnz, A.nrows);
+  return A;
+}
+
+static Csr mono_csr(pph_ctx* ctx) {
+  Csr A;
+  A.rowptr = ctx->mrowptr.p; A.col = ctx->mcol.p; A.val = ctx->mval.p; A.nrows = 2 * ctx->n; A.nnz = 4 * ctx->nnzb;
+  A.lanes = pph_pick_lanes(ctx, A.nnz, A.nrows);
+  return A;
+}
+
+// ------------------------------------------------------------------------------------------------
+// preconditioned CG.  `dinv` != null selects the fused Jacobi path; otherwise `pc` (may be empty =
+// identity) is called.  x holds the initial guess when warm != 0, else it is zeroed here.
+// work vectors r,z,p,q are supplied by the caller (inner and outer solves use disjoint sets).
+// ------------------------------------------------------------------------------------------------
+static int cg_solve(pph_ctx* ctx, const Csr& A, const double* b, double* x, const double* dinv, const ApplyFn& pc,
+                    double rtol, double atol, int max_it, bool warm, double* r, double* z, double* p, double* q,
+                    int slot, KspOut* out, double* hist, int hist_cap) {
+  const int64_t n = A.nrows;
+  const bool fused = (dinv != nullptr) || !pc;
+  auto apply_pc = [&](const double* in, double* o) {
+    if (dinv) la_pointwise_mult(ctx, o, dinv, in, n);
+    else if (pc) pc(in, o);
+    else la_copy(ctx, o, in, n);
+  };
+  double bnorm;
+  if (warm) {
+    // tolerance is relative to ||P^-1 b|| also with a non-zero guess (KSPConvergedDefault)
+    apply_pc(b, z);
+    la_dot(ctx, z, z, n, slot);
+    PPH_TRY(la_fetch(ctx, slot, 1));
+    bnorm = std::sqrt(ctx->h_scal[slot]);
+    la_spmv(ctx, A, x, q);
+    la_sub(ctx, r, b, q, n);
+  } else {
+    la_set(ctx, x, 0.0, n);
+    la_copy(ctx, r, b, n);
+    bnorm = -1.0;
+  }
+  apply_pc(r, z);
+  la_dot2(ctx, r, z, z, n, slot);
+  PPH_TRY(la_fetch(ctx, slot, 2));
+  double rz = ctx->h_scal[slot];
+  double res = std::sqrt(ctx->h_scal[slot + 1]);
+  if (bnorm < 0.0) bnorm = res;
+  const double tol = std::fmax(rtol * bnorm, atol);
+  out->its = 0; out->res = res; out->converged = false; out->breakdown = false;
+  if (hist && hist_cap > 0) hist[0] = res;
+  if (!(res == res)) { out->breakdown = true; return PPH_OK; }
+  if (res <= tol) { out->converged = true; return PPH_OK; }
+  la_copy(ctx, p, z, n);
+  int its = 0;
+  while (its < max_it) {
+    la_spmv_dot(ctx, A, p, q, slot);
+    PPH_TRY(la_fetch(ctx, slot, 1));
+    const double pq = ctx->h_scal[slot];
+    if (!(pq > 0.0) || !(rz == rz)) { out->breakdown = true; break; }
+    const double alpha = rz / pq;
+    double rz_new;
+    if (fused) {
+      la_cg_update(ctx, x, r, z, p, q, dinv, alpha, n, slot);
+    } else {
+      la_axpy(ctx, x, alpha, p, n);
+      la_axpy(ctx, r, -alpha, q, n);
+      pc(r, z);
+      la_dot2(ctx, r, z, z, n, slot);
+    }
+    PPH_TRY(la_fetch(ctx, slot, 2));
+    rz_new = ctx->h_scal[slot];
+    res = std::sqrt(ctx->h_scal[slot + 1]);
+    ++its;
+    if (hist && its < hist_cap) hist[its] = res;
+    if (!(res == res)) { out->breakdown = true; break; }
+    if (res <= tol) { out->converged = true; break; }
+    const double beta = rz_new / rz;
+    la_axpby(ctx, p, 1.0, z, beta, n);
+    rz = rz_new;
+  }
+  out->its = its;
+  out->res = res;
+  return PPH_OK;
+}
+
+int pph_cg_jacobi(pph_ctx* ctx, const Csr& A, const double* b, double* x, const double* dinv, double rtol, double atol,
+                  int max_it, double* r, double* z, double* p, double* q, int* its) {
+  KspOut ko;
+  PPH_TRY(cg_solve(ctx, A, b, x, dinv, ApplyFn(), rtol, atol, max_it, false, r, z, p, q, S_COARSE, &ko, nullptr, 0));
+  if (its) *its = ko.its;
+  return PPH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// left-preconditioned restarted GMRES, classical Gram-Schmidt (one fused multi-dot + one multi-axpy
+// per step), Givens recurrence on the host
+// ------------------------------------------------------------------------------------------------
+static int gmres_solve(pph_ctx* ctx, const ApplyFn& Aop, int64_t n, const double* b, double* x, const ApplyFn& pc,
+                       int restart, double rtol, double atol, int max_it, KspOut* out, double* hist, int hist_cap) {
+  double *V, *w, *t;
+  PPH_TRY(work(ctx, W_GV, (size_t)(restart + 1) * (size_t)n, &V));
+  PPH_TRY(work(ctx, W_GW, (size_t)n, &w));
+  PPH_TRY(work(ctx, W_GT, (size_t)n, &t));
+  auto apply_pc = [&](const double* in, double* o) {
+    if (pc) pc(in, o); else la_copy(ctx, o, in, n);
+  };
+  std::vector<double> H((size_t)(restart + 1) * restart, 0.0), cs(restart), sn(restart), g(restart + 1), y(restart),
+      hcol(restart + 2);
+  auto Hat = [&](int i, int k) -> double& { return H[(size_t)k * (restart + 1) + i]; };
+  la_set(ctx, x, 0.0, n);
+  // r0 = P^-1 b  (zero initial guess)
+  apply_pc(b, V);
+  la_dot(ctx, V, V, n, S_A);
+  PPH_TRY(la_fetch(ctx, S_A, 1));
+  double beta = std::sqrt(ctx->h_scal[S_A]);
+  const double tol = std::fmax(rtol * beta, atol);
+  out->its = 0; out->res = beta; out->converged = false; out->breakdown = false;
+  if (hist && hist_cap > 0) hist[0] = beta;
+  if (!(beta == beta)) { out->breakdown = true; return PPH_OK; }
+  if (beta <= tol) { out->converged = true; return PPH_OK; }
+  int its = 0;
+  double res = beta;
+  bool first = true;
+  while (its < max_it) {
+    if (!first) {
+      // r = P^-1 (b - A x)
+      Aop(x, t);
+      la_sub(ctx, t, b, t, n);
+      apply_pc(t, V);
+      la_dot(ctx, V, V, n, S_A);
+      PPH_TRY(la_fetch(ctx, S_A, 1));
+      beta = std::sqrt(ctx->h_scal[S_A]);
+    }
+    first = false;
+    la_scale(ctx, V, 1.0 / beta, n);
+    std::fill(g.begin(), g.end(), 0.0);
+    g[0] = beta;
+    int kused = 0;
+    bool done = false;
+    for (int k = 0; k < restart; ++k) {
+      double* vk = V + (size_t)k * n;
+      double* vk1 = V + (size_t)(k + 1) * n;
+      Aop(vk, t);
+      apply_pc(t, w);
+      la_mdot(ctx, V, n, k + 1, w, n, S_MDOT);
+      PPH_TRY(la_fetch(ctx, S_MDOT, k + 1));
+      for (int i = 0; i <= k; ++i) hcol[i] = ctx->h_scal[S_MDOT + i];
+      la_maxpy_neg(ctx, w, V, n, k + 1, hcol.data(), n);
+      la_dot(ctx, w, w, n, S_A);
+      PPH_TRY(la_fetch(ctx, S_A, 1));
+      const double hn = std::sqrt(ctx->h_scal[S_A]);
+      for (int i = 0; i <= k; ++i) Hat(i, k) = hcol[i];
+      Hat(k + 1, k) = hn;
+      if (hn > 0.0) {
+        la_copy(ctx, vk1, w, n);
+        la_scale(ctx, vk1, 1.0 / hn, n);
+      }
+      for (int i = 0; i < k; ++i) {
+        const double tmp = cs[i] * Hat(i, k) + sn[i] * Hat(i + 1, k);
+        Hat(i + 1, k) = -sn[i] * Hat(i, k) + cs[i] * Hat(i + 1, k);
+        Hat(i, k) = tmp;
+      }
+      const double d = std::hypot(Hat(k, k), Hat(k + 1, k));
+      if (!(d > 0.0) || !(d == d)) { out->breakdown = true; done = true; kused = k; break; }
+      cs[k] = Hat(k, k) / d;
+      sn[k] = Hat(k + 1, k) / d;
+      Hat(k, k) = d;
+      Hat(k + 1, k) = 0.0;
+      g[k + 1] = -sn[k] * g[k];
+      g[k] = cs[k] * g[k];
+      ++its;
+      kused = k + 1;
+      res = std::fabs(g[k + 1]);
+      if (hist && its < hist_cap) hist[its] = res;
+      if (res <= tol || its >= max_it) { done = true; break; }
+    }
+    // back substitution and update
+    for (int i = kused - 1; i >= 0; --i) {
+      double s = g[i];
+      for (int j = i + 1; j < kused; ++j) s -= Hat(i, j) * y[j];
+      y[i] = s / Hat(i, i);
+    }
+    if (kused > 0) la_maxpy(ctx, x, V, n, kused, y.data(), n);
+    if (done) break;
+  }
+  out->its = its;
+  out->res = res;
+  out->converged = (res <= tol) && !out->breakdown;
+  return PPH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// preconditioner data
+// ------------------------------------------------------------------------------------------------
+__global__ void k_block2_build(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                               const double* __restrict__ A11, const double* __restrict__ A22,
+                               const double* __restrict__ A12, const double* __restrict__ A21, int64_t n,
+                               double* __restrict__ binv) {
+  for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < n;
+       row += (int64_t)gridDim.x * blockDim.x) {
+    int64_t lo = rowptr[row], hi = rowptr[row + 1] - 1;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if ((int64_t)col[mid] < row) lo = mid + 1; else hi = mid;
+    }
+    const double d11 = A11[lo], d22 = A22[lo], d12 = A12[lo], d21 = A21[lo];
+    const double det = d11 * d22 - d12 * d21;
+    const double r = 1.0 / det;
+    binv[row] = d22 * r;          // z1 <- r1
+    binv[n + row] = -d12 * r;     // z1 <- r2
+    binv[2 * n + row] = -d21 * r; // z2 <- r1
+    binv[3 * n + row] = d11 * r;  // z2 <- r2
+  }
+}
+
+struct BlockSolver {
+  // solves A_which z = rhs for one scalar block with an inner preconditioned CG
+  pph_ctx* ctx;
+  const pph_solver_cfg* cfg;
+  Csr A[2];
+  double* dinv[2] = {nullptr, nullptr};
+  int total_its = 0;
+  bool failed = false;
+
+  int setup() {
+    A[0] = block_csr(ctx, ctx->A11.p);
+    A[1] = block_csr(ctx, ctx->A22.p);
+    if (cfg->inner_pc_type == PPH_PC_JACOBI) {
+      PPH_TRY(work(ctx, W_DINV_1, (size_t)ctx->n, &dinv[0]));
+      PPH_TRY(work(ctx, W_DINV_2, (size_t)ctx->n, &dinv[1]));
+      la_extract_diag_inv(ctx, A[0], dinv[0]);
+      la_extract_diag_inv(ctx, A[1], dinv[1]);
+    } else if (cfg->inner_pc_type == PPH_PC_MG) {
+      PPH_TRY(mg_setup(ctx));
+    } else if (cfg->inner_pc_type != PPH_PC_NONE) {
+      pph_set_error(ctx, "inner pc_type %d not supported for block solves (none, jacobi, mg)", cfg->inner_pc_type);
+      return PPH_ERR_INVALID;
+    }
+    return PPH_OK;
+  }
+
+  int solve(int which, const double* rhs, double* z, bool warm) {
+    const int64_t n = ctx->n;
+    double *r, *zz, *p, *q;
+    PPH_TRY(work(ctx, W_IR, (size_t)n, &r));
+    PPH_TRY(work(ctx, W_IZ, (size_t)n, &zz));
+    PPH_TRY(work(ctx, W_IP, (size_t)n, &p));
+    PPH_TRY(work(ctx, W_IQ, (size_t)n, &q));
+    ApplyFn pc;
+    const int ns = cfg->mg_smooth > 0 ? cfg->mg_smooth : 2;
+    if (cfg->inner_pc_type == PPH_PC_MG) pc = [this, which, ns](const double* in, double* o) { mg_vcycle(ctx, which, in, o, ns); };
+    KspOut ko;
+    if (cfg->inner_ksp_type == PPH_KSP_PREONLY) {
+      // one application of the inner preconditioner
+      if (dinv[which]) la_pointwise_mult(ctx, z, dinv[which], rhs, n);
+      else if (pc) pc(rhs, z);
+      else la_copy(ctx, z, rhs, n);
+      return PPH_OK;
+    }
+    PPH_TRY(cg_solve(ctx, A[which], rhs, z, dinv[which], pc, cfg->inner_rtol, cfg->inner_atol, cfg->inner_max_it,
+                     warm, r, zz, p, q, S_INNER, &ko, nullptr, 0));
+    total_its += ko.its;
+    if (ko.breakdown || !ko.converged) failed = true;
+    return PPH_OK;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// the solve entry point
+// ------------------------------------------------------------------------------------------------
+__global__ void k_add2(double* __restrict__ out, const double* __restrict__ a, const double* __restrict__ b,
+                       int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = a[i] + b[i];
+}
+
+static int validate_cfg(pph_ctx* ctx, const pph_solver_cfg* cfg) {
+  PPH_REQUIRE(ctx, cfg != nullptr, "solver cfg is NULL");
+  PPH_REQUIRE(ctx, cfg->ksp_type >= PPH_KSP_PREONLY && cfg->ksp_type <= PPH_KSP_GMRES, "unknown ksp_type %d",
+              cfg->ksp_type);
+  PPH_REQUIRE(ctx, cfg->pc_type >= PPH_PC_NONE && cfg->pc_type <= PPH_PC_MG, "unknown pc_type %d", cfg->pc_type);
+  PPH_REQUIRE(ctx, cfg->restart >= 1 && cfg->restart <= 30, "GMRES restart %d outside [1,30]", cfg->restart);
+  PPH_REQUIRE(ctx, cfg->max_it >= 0 && cfg->inner_max_it >= 0 && cfg->picard_max_it >= 0, "negative max_it");
+  PPH_REQUIRE(ctx, cfg->rtol >= 0 && cfg->atol >= 0 && cfg->inner_rtol >= 0 && cfg->inner_atol >= 0, "negative tolerance");
+  PPH_REQUIRE(ctx, cfg->inner_ksp_type == PPH_KSP_PREONLY || cfg->inner_ksp_type == PPH_KSP_CG,
+              "inner ksp_type %d not supported (preonly, cg)", cfg->inner_ksp_type);
+  if (!cfg->picard) {
+    PPH_REQUIRE(ctx, cfg->pc_type != PPH_PC_MG, "pc_type mg applies to the scalar blocks: use it as inner_pc_type");
+    PPH_REQUIRE(ctx, ctx->mono_ok, "monolithic Krylov solve needs pph_assemble_dpp(..., monolithic=1)");
+  }
+  return PPH_OK;
+}
+
+int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* info, double* hist, int hist_cap) {
+  if (!ctx) return PPH_ERR_INVALID;
+  PPH_REQUIRE(ctx, ctx->asm_ok, "pph_solve before pph_assemble_dpp");
+  PPH_TRY(validate_cfg(ctx, cfg));
+  PPH_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t n = ctx->n, N = 2 * n;
+  la_reset_spmv_stats(ctx);
+  PPH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+
+  pph_solve_info inf;
+  inf.iterations = 0; inf.inner_iterations = 0; inf.converged = 0; inf.reserved = 0; inf.resnorm = 0; inf.rhs_norm = 0;
+  la_dot(ctx, ctx->rhs.p, ctx->rhs.p, N, S_A);
+  PPH_TRY(la_fetch(ctx, S_A, 1));
+  inf.rhs_norm = std::sqrt(ctx->h_scal[S_A]);
+
+  double* du;
+  PPH_TRY(work(ctx, W_DU, (size_t)N, &du));
+  BlockSolver bs;
+  bs.ctx = ctx; bs.cfg = cfg;
+  const Csr A12 = block_csr(ctx, ctx->A12.p), A21 = block_csr(ctx, ctx->A21.p);
+  int status = PPH_OK;
+
+  if (cfg->picard) {
+    // block Picard / fixed-stress sweeps on the correction du (homogeneous BCs):
+    //   A11 du1 = b1 - A12 du2_old ;  A22 du2 = b2 - A21 du1_new        (dpp.py:196-203)
+    PPH_TRY(bs.setup());
+    double *pb, *t;
+    PPH_TRY(work(ctx, W_PB, (size_t)n, &pb));
+    PPH_TRY(work(ctx, W_T, (size_t)n, &t));
+    const double* b1 = ctx->rhs.p;
+    const double* b2 = ctx->rhs.p + n;
+    double* du1 = du;
+    double* du2 = du + n;
+    la_set(ctx, du, 0.0, N);
+    const double r0 = inf.rhs_norm;
+    const double tol = std::fmax(cfg->picard_rtol * r0, cfg->picard_atol);
+    double res = r0;
+    if (hist && hist_cap > 0) hist[0] = res;
+    int its = 0;
+    while (res > tol && its < cfg->picard_max_it) {
+      la_spmv(ctx, A12, du2, t);
+      la_sub(ctx, pb, b1, t, n);
+      PPH_TRY(bs.solve(0, pb, du1, its > 0));
+      la_spmv(ctx, A21, du1, t);
+      la_sub(ctx, pb, b2, t, n);
+      PPH_TRY(bs.solve(1, pb, du2, its > 0));
+      ++its;
+      // monolithic residual: r2 is the inner residual of the sweep's last solve, r1 picks up the new du2
+      la_spmv(ctx, bs.A[0], du1, t);
+      la_sub(ctx, pb, b1, t, n);
+      la_spmv(ctx, A12, du2, t);
+      la_axpy(ctx, pb, -1.0, t, n);
+      la_dot(ctx, pb, pb, n, S_A);
+      la_spmv(ctx, A21, du1, t);
+      la_sub(ctx, pb, b2, t, n);
+      la_spmv(ctx, bs.A[1], du2, t);
+      la_axpy(ctx, pb, -1.0, t, n);
+      la_dot(ctx, pb, pb, n, S_A + 1);
+      PPH_TRY(la_fetch(ctx, S_A, 2));
+      res = std::sqrt(ctx->h_scal[S_A] + ctx->h_scal[S_A + 1]);
+      if (hist && its < hist_cap) hist[its] = res;
+      if (!(res == res)) break;
+    }
+    inf.iterations = its;
+    inf.inner_iterations = bs.total_its;
+    inf.resnorm = res;
+    inf.converged = (res <= tol) ? 1 : 0;
+    if (!inf.converged) status = PPH_ERR_DIVERGED;
+  } else {
+    const Csr A = mono_csr(ctx);
+    ApplyFn Aop = [&](const double* x, double* y) { la_spmv(ctx, A, x, y); };
+    ApplyFn pc;
+    double* dinv = nullptr;
+    if (cfg->pc_type == PPH_PC_JACOBI) {
+      PPH_TRY(work(ctx, W_DINV_M, (size_t)N, &dinv));
+      la_extract_diag_inv(ctx, A, dinv);
+      pc = [&, dinv](const double* in, double* o) { la_pointwise_mult(ctx, o, dinv, in, N); };
+    } else if (cfg->pc_type == PPH_PC_BLOCK2) {
+      double* binv;
+      PPH_TRY(work(ctx, W_BINV, (size_t)(4 * n), &binv));
+      int grid = (int)(ceil_div64(n, 256) < 2048 ? ceil_div64(n, 256) : 2048);
+      hipLaunchKernelGGL(k_block2_build, dim3(grid), dim3(256), 0, ctx->stream, ctx->mesh.rowptr.p, ctx->mesh.col.p,
+                         ctx->A11.p, ctx->A22.p, ctx->A12.p, ctx->A21.p, n, binv);
+      pc = [&, binv](const double* in, double* o) { la_block2_apply(ctx, o, binv, in, n); };
+    } else if (cfg->pc_type == PPH_PC_FIELDSPLIT) {
+      // multiplicative: z1 = A11^-1 r1 ; z2 = A22^-1 (r2 - A21 z1)   (parameters.py:30-37)
+      PPH_TRY(bs.setup());
+      double *f1, *f2;
+      PPH_TRY(work(ctx, W_FS1, (size_t)n, &f1));
+      PPH_TRY(work(ctx, W_FS2, (size_t)n, &f2));
+      pc = [&, f1, f2](const double* in, double* o) {
+        bs.solve(0, in, o, false);
+        la_spmv(ctx, A21, o, f1);
+        la_sub(ctx, f2, in + n, f1, n);
+        bs.solve(1, f2, o + n, false);
+      };
+    }
+    KspOut ko;
+    if (cfg->ksp_type == PPH_KSP_PREONLY) {
+      if (pc) pc(ctx->rhs.p, du); else la_copy(ctx, du, ctx->rhs.p, N);
+      ko.its = 1; ko.res = 0.0; ko.converged = true;
+    } else if (cfg->ksp_type == PPH_KSP_CG) {
+      double *r, *z, *p, *q;
+      PPH_TRY(work(ctx, W_R, (size_t)N, &r));
+      PPH_TRY(work(ctx, W_Z, (size_t)N, &z));
+      PPH_TRY(work(ctx, W_P, (size_t)N, &p));
+      PPH_TRY(work(ctx, W_Q, (size_t)N, &q));
+      PPH_TRY(cg_solve(ctx, A, ctx->rhs.p, du, dinv, dinv ? ApplyFn() : pc, cfg->rtol, cfg->atol, cfg->max_it, false,
+                       r, z, p, q, S_B, &ko, hist, hist_cap));
+    } else {
+      PPH_TRY(gmres_solve(ctx, Aop, N, ctx->rhs.p, du, pc, cfg->restart, cfg->rtol, cfg->atol, cfg->max_it, &ko, hist,
+                          hist_cap));
+    }
+    inf.iterations = ko.its;
+    inf.inner_iterations = bs.total_its;
+    inf.resnorm = ko.res;
+    inf.converged = (ko.converged && !bs.failed) ? 1 : 0;
+    if (!ko.converged || ko.breakdown) status = PPH_ERR_DIVERGED;
+  }
+
+  // u = u0 + du
+  {
+    int grid = (int)(ceil_div64(N, 256) < 2048 ? ceil_div64(N, 256) : 2048);
+    hipLaunchKernelGGL(k_add2, dim3(grid), dim3(256), 0, ctx->stream, ctx->sol.p, ctx->u0.p, du, N);
+  }
+  PPH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  PPH_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  PPH_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  ctx->t_solve = ms;
+  la_harvest_spmv_times(ctx);
+  PPH_HIP(ctx, hipGetLastError());
+  if (info) *info = inf;
+  if (status == PPH_ERR_DIVERGED)
+    pph_set_error(ctx, "solver did not converge: %d iterations, residual %.3e", inf.iterations, inf.resnorm);
+  return status;
+}
+
+int pph_get_solution(pph_ctx* ctx, double* x_host) {
+  if (!ctx) return PPH_ERR_INVALID;
+  PPH_REQUIRE(ctx, ctx->asm_ok && ctx->sol.p, "no solution available");
+  PPH_REQUIRE(ctx, x_host != nullptr, "x_host is NULL");
+  PPH_HIP(ctx, hipMemcpyAsync(x_host, ctx->sol.p, sizeof(double) * 2 * (size_t)ctx->n, hipMemcpyDeviceToHost,
+                              ctx->stream));
+  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PPH_OK;
+}
+
+int pph_solve(pph_ctx* ctx, const pph_solver_cfg* cfg, double* x_host, pph_solve_info* info, double* hist,
+              int hist_cap) {
+  if (!ctx) return PPH_ERR_INVALID;
+  PPH_REQUIRE(ctx, x_host != nullptr, "x_host is NULL");
+  int st = pph_solve_device(ctx, cfg, info, hist, hist_cap);
+  if (st < 0 && st != PPH_ERR_DIVERGED) return st;
+  PPH_TRY(pph_get_solution(ctx, x_host));
+  return st;
+}

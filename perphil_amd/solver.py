@@ -1,0 +1,208 @@
+"""
+``solve_dpp`` / ``solve_dpp_nonlinear`` / ``Solution`` — mirror of reference
+``src/perphil/solvers/solver.py:14-128`` over the HIP library (no Firedrake/PETSc, no CPU fallback).
+
+Same call surface: ``solve_dpp(W, model_params, bcs, solver_parameters={}, options_prefix="dpp")``
+returns ``Solution(solution, iteration_number, residual_error)``; ``ValueError`` unless ``W`` is a
+2-field mixed space (solver.py:61-62).  PETSc options are translated by ``translate_options``:
+
+=====================================  =============================================================
+reference option                        MI355X path
+=====================================  =============================================================
+ksp_type gmres | cg                     GMRES(30), classical Gram-Schmidt / CG on the monolithic CSR
+pc_type none | jacobi                   same
+pc_type fieldsplit (multiplicative)     same; block solves = inner CG with multigrid or Jacobi PC
+ksp_type preonly + pc_type lu (MUMPS)   "direct-equivalent": field-split GMRES with multigrid-CG
+                                        block solves run to 1e-13 relative residual; reports
+                                        iteration_number 1 and residual 0.0 like PETSc's preonly
+pc_type ilu                             no GPU counterpart: substituted (with a warning) by 2x2
+                                        node-block Jacobi (monolithic) or multigrid (blocks)
+snes_type ngs | nrichardson             block Picard (fixed-stress) sweeps per dpp_delayed_form
+                                        (dpp.py:196-203); the reference's PETSc secant-NGS history is
+                                        not reproduced, the fixed point is
+=====================================  =============================================================
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Dict, List, Tuple
+
+import attr
+import numpy as np
+
+from . import _ffi, fd
+from .forms import dpp_form, dpp_splitted_form
+from .parameters import DPPParameters
+
+_DIRECT_RTOL = 1e-13
+
+
+@attr.define(frozen=True)
+class Solution:
+    """Result of a solve (reference solver.py:14-27) + ``info`` with what actually ran."""
+    solution: fd.Function | Tuple[fd.Function, fd.Function]
+    iteration_number: int
+    residual_error: float | np.float64
+    info: dict = attr.field(factory=dict, eq=False)
+
+
+def _sub_options(params: Dict, idx: int) -> Dict:
+    """Options of block `idx`: nested dict ``fieldsplit_i`` and/or flattened ``fieldsplit_i_*`` keys."""
+    out = dict(params.get(f"fieldsplit_{idx}", {}) or {})
+    pre = f"fieldsplit_{idx}_"
+    for k, v in params.items():
+        if isinstance(k, str) and k.startswith(pre):
+            out[k[len(pre):]] = v
+    return out
+
+
+def _inner_cfg(cfg: _ffi.SolverCfg, subs: List[Dict], notes: List[str]) -> None:
+    """Block-solve settings from the fieldsplit sub-options (both blocks share one setting)."""
+    ksp = {s.get("ksp_type", "preonly") for s in subs}
+    pc = {s.get("pc_type", "lu") for s in subs}
+    rtols = [float(s["ksp_rtol"]) for s in subs if "ksp_rtol" in s]
+    atols = [float(s["ksp_atol"]) for s in subs if "ksp_atol" in s]
+    maxits = [int(s["ksp_max_it"]) for s in subs if "ksp_max_it" in s]
+    k = ksp.pop() if len(ksp) == 1 else "cg"
+    p = pc.pop() if len(pc) == 1 else "mg"
+    cfg.inner_ksp_type = _ffi.KSP_CG
+    cfg.inner_max_it = min(maxits) if maxits else 50000
+    cfg.inner_atol = min(atols) if atols else 1e-50
+    if p in ("lu", "cholesky"):
+        # exact block solve of the reference -> multigrid-CG to a tight tolerance
+        cfg.inner_pc_type, cfg.inner_rtol = _ffi.PC_MG, 1e-12
+        notes.append("block LU -> CG + geometric multigrid, rtol 1e-12")
+        return
+    if p == "ilu":
+        warnings.warn("pc_type ilu has no GPU counterpart; block solves use CG + geometric multigrid", stacklevel=4)
+        notes.append("block ILU -> geometric multigrid")
+        p = "mg"
+    if p not in ("mg", "jacobi", "none"):
+        raise NotImplementedError(f"fieldsplit block pc_type {p!r} is not supported (lu, ilu, mg, jacobi, none)")
+    cfg.inner_pc_type = {"mg": _ffi.PC_MG, "jacobi": _ffi.PC_JACOBI, "none": _ffi.PC_NONE}[p]
+    if k == "preonly":
+        cfg.inner_ksp_type = _ffi.KSP_PREONLY
+    elif k in ("gmres", "cg", "fgmres"):
+        if k != "cg":
+            notes.append(f"block {k} -> CG (blocks are SPD)")
+    else:
+        raise NotImplementedError(f"fieldsplit block ksp_type {k!r} is not supported")
+    cfg.inner_rtol = min(rtols) if rtols else 1e-5  # PETSc default ksp_rtol
+
+
+def translate_options(params: Dict, nonlinear: bool = False) -> Tuple[_ffi.SolverCfg, dict]:
+    """PETSc option dict -> (pph_solver_cfg, notes).  Unknown keys that do not change the algebra
+    (mat_type, monitors, pc_factor_*) are ignored; unsupported algorithms raise NotImplementedError."""
+    params = dict(params or {})
+    notes: List[str] = []
+    cfg = _ffi.SolverCfg()
+    cfg.restart = int(params.get("ksp_gmres_restart", 30))
+    cfg.max_it = int(params.get("ksp_max_it", 10000))
+    cfg.rtol = float(params.get("ksp_rtol", 1e-5 if params.get("ksp_type") else 1e-7))
+    cfg.atol = float(params.get("ksp_atol", 1e-50))
+    cfg.inner_ksp_type, cfg.inner_pc_type = _ffi.KSP_CG, _ffi.PC_MG
+    cfg.inner_rtol, cfg.inner_atol, cfg.inner_max_it = 1e-10, 1e-50, 50000
+    cfg.picard = 0
+    cfg.picard_rtol = float(params.get("snes_rtol", 1e-8))
+    cfg.picard_atol = float(params.get("snes_atol", 1e-50))
+    cfg.picard_max_it = int(params.get("snes_max_it", 50))
+    cfg.mg_smooth = int(params.get("pph_mg_smooth", 2))
+    info = {"direct_equivalent": False}
+
+    ksp = params.get("ksp_type", "preonly" if not nonlinear else "gmres")
+    pc = params.get("pc_type", "lu" if ksp == "preonly" else "ilu")
+    if pc == "fieldsplit" and params.get("pc_fieldsplit_type", "multiplicative") != "multiplicative":
+        raise NotImplementedError("only pc_fieldsplit_type multiplicative is supported")
+
+    if nonlinear or params.get("pph_picard"):
+        snes = params.get("snes_type", "ngs")
+        if snes not in ("ngs", "nrichardson", "ksponly", "newtonls"):
+            raise NotImplementedError(f"snes_type {snes!r} is not supported")
+        cfg.picard = 1
+        cfg.ksp_type, cfg.pc_type = _ffi.KSP_GMRES, _ffi.PC_FIELDSPLIT
+        subs = [_sub_options(params, 0), _sub_options(params, 1)]
+        _inner_cfg(cfg, subs, notes)
+        notes.append("block Picard (fixed-stress) sweeps per dpp_delayed_form")
+        info["notes"] = notes
+        return cfg, info
+
+    if ksp == "preonly" and pc in ("lu", "cholesky"):
+        # direct solve of the reference -> iterate to direct-solver accuracy
+        cfg.ksp_type, cfg.pc_type = _ffi.KSP_GMRES, _ffi.PC_FIELDSPLIT
+        cfg.rtol, cfg.atol, cfg.max_it = _DIRECT_RTOL, 1e-300, 200
+        cfg.inner_ksp_type, cfg.inner_pc_type = _ffi.KSP_CG, _ffi.PC_MG
+        cfg.inner_rtol, cfg.inner_atol = 1e-12, 1e-300
+        info["direct_equivalent"] = True
+        notes.append("preonly+lu -> field-split GMRES with multigrid-CG block solves to 1e-13")
+        info["notes"] = notes
+        return cfg, info
+
+    cfg.ksp_type = {"preonly": _ffi.KSP_PREONLY, "cg": _ffi.KSP_CG, "gmres": _ffi.KSP_GMRES,
+                    "fgmres": _ffi.KSP_GMRES}.get(ksp, -1)
+    if cfg.ksp_type < 0:
+        raise NotImplementedError(f"ksp_type {ksp!r} is not supported (preonly, cg, gmres)")
+    if pc == "ilu":
+        warnings.warn("pc_type ilu has no GPU counterpart; using the 2x2 node-block Jacobi preconditioner",
+                      stacklevel=3)
+        notes.append("ILU(0) -> 2x2 node-block Jacobi")
+        pc = "pph_block2"
+    if pc in ("lu", "cholesky"):
+        raise NotImplementedError("pc_type lu is only supported with ksp_type preonly (direct-equivalent solve)")
+    table = {"none": _ffi.PC_NONE, "jacobi": _ffi.PC_JACOBI, "pph_block2": _ffi.PC_BLOCK2,
+             "fieldsplit": _ffi.PC_FIELDSPLIT}
+    if pc not in table:
+        raise NotImplementedError(f"pc_type {pc!r} is not supported")
+    cfg.pc_type = table[pc]
+    if pc == "fieldsplit":
+        _inner_cfg(cfg, [_sub_options(params, 0), _sub_options(params, 1)], notes)
+    info["notes"] = notes
+    return cfg, info
+
+
+def _apply_bcs(ctx: _ffi.Context, W, bcs: List[fd.DirichletBC]) -> None:
+    per_field = {0: (np.zeros(0, np.int64), np.zeros(0)), 1: (np.zeros(0, np.int64), np.zeros(0))}
+    for bc in bcs or []:
+        V = bc.function_space()
+        if getattr(V, "parent", None) is not W:
+            raise ValueError("DirichletBC must be built on W.sub(i) of the space being solved")
+        per_field[bc.field] = bc.nodes_and_values()
+    for f in (0, 1):
+        ctx.set_dirichlet(f, *per_field[f])
+
+
+def _run(W, model_params: DPPParameters, bcs, solver_parameters: Dict, nonlinear: bool, device: int = 0) -> Solution:
+    cfg, info = translate_options(solver_parameters, nonlinear=nonlinear)
+    mesh = W.mesh()
+    ctx = mesh.context(device)
+    _apply_bcs(ctx, W, bcs)
+    need_mono = not cfg.picard
+    ctx.assemble(float(model_params.k1), float(model_params.k2), float(model_params.beta), float(model_params.mu),
+                 monolithic=need_mono)
+    x, sinfo, _ = ctx.solve(cfg, fetch=True)
+    solution = fd.Function(W, x, name="dpp_solution")
+    info.update(iterations=int(sinfo.iterations), inner_iterations=int(sinfo.inner_iterations),
+                residual=float(sinfo.resnorm), rhs_norm=float(sinfo.rhs_norm), timers=ctx.timers())
+    if info.get("direct_equivalent"):
+        return Solution(solution, 1, 0.0, info)
+    return Solution(solution, int(sinfo.iterations), float(sinfo.resnorm), info)
+
+
+def solve_dpp(W, model_params: DPPParameters, bcs: List[fd.DirichletBC], solver_parameters: Dict = {},
+              options_prefix: str = "dpp") -> Solution:
+    """Solve the monolithic / preconditioned DPP linear system (reference solver.py:30-76)."""
+    if not hasattr(W, "num_sub_spaces") or W.num_sub_spaces() != 2:
+        raise ValueError(f"Expected a 2-field MixedFunctionSpace, got {type(W)}")
+    dpp_form(W, model_params)  # same guard + form description as the reference
+    return _run(W, model_params, bcs, solver_parameters, nonlinear=False)
+
+
+def solve_dpp_nonlinear(W, model_params: DPPParameters, bcs: List[fd.DirichletBC], solver_parameters: Dict = {},
+                        options_prefix: str = "dpp_nonlinear") -> Solution:
+    """Fixed-point (Picard) solve of the split system (reference solver.py:79-128): block
+    Gauss-Seidel sweeps over the two scales; returns sweeps and the final residual norm."""
+    if not hasattr(W, "num_sub_spaces") or W.num_sub_spaces() != 2:
+        raise ValueError(f"Expected a 2-field MixedFunctionSpace, got {type(W)}")
+    dpp_splitted_form(W, model_params)
+    sol = _run(W, model_params, bcs, solver_parameters, nonlinear=True)
+    assert isinstance(sol, Solution)
+    return sol

@@ -1,0 +1,180 @@
+"""Pins the CPU oracle against the reference's own committed outputs.
+All quantities are invariant under dof renumbering."""
+import numpy as np
+import pytest
+
+from oracle import dpp_oracle as o
+
+P = o.Params(k1=1.0, k2=0.01, beta=1.0, mu=1.0)
+
+
+@pytest.fixture(scope="module")
+def sys10():
+    m = o.build_mesh(2, o.CELL_QUAD, 10, 10)
+    return m, o.build_system(m, P)
+
+
+def test_G1_initial_residual(sys10, goldens):
+    _, s = sys10
+    assert np.linalg.norm(s.rhs) == pytest.approx(goldens["G1_initial_residual_10x10"], rel=5e-13)
+
+
+def test_G2_slice_monolithic_direct(sys10, goldens):
+    m, s = sys10
+    u = o.solve_direct(s)
+    g = goldens["G2_slice_x05_monolithic_10x10"]
+    y, p1 = o.slice_along_x(m, u[: s.n], 0.5)
+    _, p2 = o.slice_along_x(m, u[s.n:], 0.5)
+    np.testing.assert_allclose(y, g["y"], atol=1e-12)
+    np.testing.assert_allclose(p1, g["p1"], rtol=5e-9)   # stored with 9 significant digits
+    np.testing.assert_allclose(p2, g["p2"], rtol=5e-9)
+
+
+def test_G3_condition_numbers(sys10, goldens):
+    _, s = sys10
+    g = goldens["G3_condition_numbers_10x10"]
+    n = s.n
+    assert o.condition_number(s.A) == pytest.approx(g["monolithic"], rel=1e-11)
+    assert o.condition_number(s.A[:n, :n]) == pytest.approx(g["macro"], rel=1e-11)
+    assert o.condition_number(s.A[n:, n:]) == pytest.approx(g["micro"], rel=1e-11)
+
+
+@pytest.mark.parametrize("row", [0, 1, 2])
+def test_G4_conditioning_2d(goldens, row):
+    g = goldens["G4_conditioning_2d"][row]
+    N = int(g["N"])
+    m = o.build_mesh(2, o.CELL_QUAD, N, N)
+    s = o.build_system(m, P, mms=False)  # homogeneous BCs (iterative_bench.default_bcs)
+    n = s.n
+    assert o.condition_number(s.A) == pytest.approx(g["cond_monolithic"], rel=1e-10)
+    assert o.condition_number(s.A[:n, :n]) == pytest.approx(g["cond_macro"], rel=1e-10)
+    assert o.condition_number(s.A[n:, n:]) == pytest.approx(g["cond_micro"], rel=1e-10)
+
+
+@pytest.mark.parametrize("row", [0, 1])
+def test_G5_conditioning_3d_hex(goldens, row):
+    g = goldens["G5_conditioning_3d_hex"][row]
+    N = int(g["N"])
+    m = o.build_mesh(3, o.CELL_HEX, N, N, N)
+    s = o.build_system(m, P)
+    n = s.n
+    assert 2 * n == int(g["n_dofs"]) and n == int(g["n0"]) == int(g["n1"])
+    assert o.condition_number(s.A) == pytest.approx(g["cond_monolithic"], rel=1e-10)
+    assert o.condition_number(s.A[:n, :n]) == pytest.approx(g["cond_macro"], rel=1e-10)
+    assert o.condition_number(s.A[n:, n:]) == pytest.approx(g["cond_micro"], rel=1e-10)
+
+
+def _perf(goldens, key, approach, nx):
+    return next(r for r in goldens[key] if r["approach"] == approach and r["nx"] == nx)
+
+
+@pytest.mark.parametrize("nx", [4, 8, 12])
+def test_G6_plain_gmres_3d_tets(goldens, nx):
+    g = _perf(goldens, "G6_G9_perf_3d_tets", "GMRES", nx)
+    m = o.build_mesh(3, o.CELL_TET, nx, nx, nx)
+    s = o.build_system(m, P)
+    assert 2 * s.n == g["dofs"] and m.num_cells == g["num_cells"]
+    r = o.gmres(s.A, s.rhs)
+    assert r.its == g["iterations"]
+    assert r.resnorm == pytest.approx(g["residual"], rel=0.1)
+
+
+@pytest.mark.parametrize("nx", [4, 8, 16, 32])
+def test_G7_plain_gmres_2d_q1(goldens, nx):
+    g = _perf(goldens, "G7_G9_perf_2d_q1", "GMRES", nx)
+    m = o.build_mesh(2, o.CELL_QUAD, nx, nx)
+    s = o.build_system(m, P)
+    assert 2 * s.n == g["dofs"] and m.num_cells == g["num_cells"]
+    r = o.gmres(s.A, s.rhs)
+    assert r.its == g["iterations"]
+
+
+def test_G8_histories(sys10, goldens):
+    _, s = sys10
+    # the stored notebook run converged to ~1e-12 relative (older tolerance); compare the histories
+    r = o.gmres(s.A, s.rhs, rtol=1e-12)
+    ref = np.array(goldens["G8_gmres_history_10x10"])
+    assert abs(r.its - (len(ref) - 1)) <= 1
+    # identical to ~1e-13 inside the first restart cycle; later cycles drift with the orthogonalisation
+    # variant (PETSc: classical Gram-Schmidt, here: modified) but stay on the same curve
+    np.testing.assert_allclose(r.history[:31], ref[:31], rtol=1e-9)
+    np.testing.assert_allclose(np.log10(r.history[:140]), np.log10(ref[:140]), atol=0.1)
+    r = o.gmres(s.A, s.rhs, o.fieldsplit_multiplicative_apply(s.A, s.n), rtol=1e-12)
+    ref = np.array(goldens["G8_fieldsplit_lu_history_10x10"])
+    assert r.its == len(ref) - 1
+    np.testing.assert_allclose(r.history[:6], ref[:6], rtol=1e-6)
+
+
+@pytest.mark.parametrize("key,kind,dim,nx", [("G7_G9_perf_2d_q1", o.CELL_QUAD, 2, 4), ("G7_G9_perf_2d_q1", o.CELL_QUAD, 2, 16),
+                                             ("G7_G9_perf_2d_q1", o.CELL_QUAD, 2, 32), ("G6_G9_perf_3d_tets", o.CELL_TET, 3, 8)])
+def test_G9_fieldsplit_lu_gmres_is_4_iterations(goldens, key, kind, dim, nx):
+    g = _perf(goldens, key, "Scale-Splitting GMRES", nx)
+    m = o.build_mesh(dim, kind, nx, nx, nx if dim == 3 else 0)
+    s = o.build_system(m, P)
+    r = o.gmres(s.A, s.rhs, o.fieldsplit_multiplicative_apply(s.A, s.n))
+    assert r.its == g["iterations"] == 4
+    assert r.resnorm == pytest.approx(g["residual"], rel=1e-4)
+
+
+def test_G10_error_norms_2d(goldens):
+    import math
+
+    g = next(r for r in goldens["G10_convergence_2d"] if r["solver"] == "Monolithic LU with MUMPS" and int(r["N"]) == 16)
+    Pd = o.Params()  # convergence_2d uses DPPParameters() defaults
+    m = o.build_mesh(2, o.CELL_QUAD, 16, 16)
+    s = o.build_system(m, Pd)
+    u = o.solve_direct(s)
+    eta, pi = Pd.eta, math.pi
+
+    def mk(sign, k):
+        ex = lambda X: (Pd.mu / pi) * np.exp(pi * X[:, 0]) * np.sin(pi * X[:, 1]) + sign * (Pd.mu / (Pd.beta * k)) * np.exp(eta * X[:, 1])
+        gr = lambda X: np.stack([Pd.mu * np.exp(pi * X[:, 0]) * np.sin(pi * X[:, 1]),
+                                 Pd.mu * np.exp(pi * X[:, 0]) * np.cos(pi * X[:, 1]) + sign * (Pd.mu / (Pd.beta * k)) * eta * np.exp(eta * X[:, 1])], 1)
+        return ex, gr
+
+    e1, h1 = o.error_norms(m, u[: s.n], *mk(-1.0, Pd.k1))
+    e2, h2 = o.error_norms(m, u[s.n:], *mk(+1.0, Pd.k2))
+    # the reference integrates exp/sin with Firedrake's estimated quadrature degree: agree to ~1e-4
+    assert e1 == pytest.approx(g["e1_L2"], rel=2e-3)
+    assert e2 == pytest.approx(g["e2_L2"], rel=2e-3)
+    assert h1 == pytest.approx(g["e1_H1s"], rel=2e-3)
+    assert h2 == pytest.approx(g["e2_H1s"], rel=2e-3)
+
+
+def test_G11_picard_fixed_point(sys10, goldens):
+    m, s = sys10
+    u, its, res, _ = o.picard(s)
+    g = goldens["G11_slice_x05_picard_10x10"]
+    _, p1 = o.slice_along_x(m, u[: s.n], 0.5)
+    _, p2 = o.slice_along_x(m, u[s.n:], 0.5)
+    # the reference's PETSc secant-NGS stops at snes_rtol=1e-8 of a different residual: same fixed
+    # point within its tolerance
+    np.testing.assert_allclose(p1, g["p1"], rtol=3e-4)
+    np.testing.assert_allclose(p2, g["p2"], rtol=3e-4)
+    ud = o.solve_direct(s)
+    assert np.abs(u - ud).max() / np.abs(ud).max() < 1e-8
+
+
+def test_G12_structure(goldens):
+    g = goldens["G12_structure"]
+    m = o.build_mesh(2, o.CELL_QUAD, 2, 2)
+    assert 2 * m.num_nodes == g["mesh_2x2_dofs"] and m.num_cells == g["mesh_2x2_num_cells"]
+
+
+def test_closed_form_element_matrices():
+    """Independent check of the quadrature: closed-form Q1 quad K_e/M_e."""
+    m = o.build_mesh(2, o.CELL_QUAD, 5, 5)
+    K, M = o.element_matrices(m)
+    h = 0.2
+    # local order here is lexicographic (v0, +x, +y, +x+y); the closed form is usually quoted counter-clockwise
+    perm = [0, 1, 3, 2]
+    Kc = np.array([[4, -1, -2, -1], [-1, 4, -1, -2], [-2, -1, 4, -1], [-1, -2, -1, 4]]) / 6.0
+    Mc = np.array([[4, 2, 1, 2], [2, 4, 2, 1], [1, 2, 4, 2], [2, 1, 2, 4]]) * h * h / 36.0
+    np.testing.assert_allclose(K[0][np.ix_(perm, perm)], Kc, atol=1e-14)
+    np.testing.assert_allclose(M[0][np.ix_(perm, perm)], Mc, atol=1e-16)
+    for kind, dim in ((o.CELL_HEX, 3), (o.CELL_TET, 3), (o.CELL_TRI, 2)):
+        mm = o.build_mesh(dim, kind, 3, 3, 3 if dim == 3 else 0)
+        Kg, Mg = o.assemble_scalar(mm)
+        assert abs(Kg @ np.ones(mm.num_nodes)).max() < 1e-13   # constants are in the kernel of K
+        assert Mg.sum() == pytest.approx(1.0, rel=1e-13)          # volume of the unit square/cube
+        assert abs(Kg - Kg.T).max() < 1e-14
