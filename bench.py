@@ -183,7 +183,7 @@ def main():
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-        "kernel": "k_spmv<8,*> (CSR-vector SpMV, all multigrid levels of one step)",
+        "kernel": "k_spmv_wide<8,*,2> (aligned-wide CSR-vector SpMV, all multigrid levels of one step)",
         "launches_per_step": int(launches), "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
         "algorithmic_bytes_per_launch": round(byts / max(launches, 1), 0),
         "fine_level": {"avg_launch_ms": round(fine_ms, 4), "algorithmic_bytes": fine_bytes,

@@ -7,6 +7,7 @@
 #include <new>
 
 static thread_local std::string g_last_error;
+void la_set_spmv_blocks(int b);
 
 void pph_set_error(pph_ctx* ctx, const char* fmt, ...) {
   char buf[1024];
@@ -23,7 +24,8 @@ int DevBuf<T>::alloc(pph_ctx* ctx, size_t count) {
   release();
   if (count == 0) count = 1;
   void* q = nullptr;
-  hipError_t e = hipMalloc(&q, count * sizeof(T));
+  // 64 bytes of slack: the aligned-wide SpMV reads whole 16-byte groups around a row's range
+  hipError_t e = hipMalloc(&q, count * sizeof(T) + 64);
   if (e != hipSuccess) {
     pph_set_error(ctx, "hipMalloc of %zu bytes failed: %s", count * sizeof(T), hipGetErrorString(e));
     (void)hipGetLastError();
@@ -275,11 +277,13 @@ static int select_csr(pph_ctx* ctx, int which, Csr* A) {
   const MeshData& m = ctx->mesh;
   A->rowptr = m.rowptr.p; A->col = m.col.p; A->nrows = m.n; A->nnz = m.nnzb;
   A->lanes = pph_pick_lanes(ctx, A->nnz, A->nrows);
+  A->max_row = m.max_row;
   switch (which) {
     case 0:
       PPH_REQUIRE(ctx, ctx->mono_ok, "monolithic CSR not assembled (pph_assemble_dpp(..., monolithic=1))");
       A->rowptr = ctx->mrowptr.p; A->col = ctx->mcol.p; A->val = ctx->mval.p; A->nrows = 2 * m.n; A->nnz = 4 * m.nnzb;
       A->lanes = pph_pick_lanes(ctx, A->nnz, A->nrows);
+      A->max_row = 2 * m.max_row;
       return PPH_OK;
     case 1: PPH_REQUIRE(ctx, m.K.p, "K not assembled"); A->val = m.K.p; return PPH_OK;
     case 2: PPH_REQUIRE(ctx, m.M.p, "M not assembled"); A->val = m.M.p; return PPH_OK;
@@ -383,6 +387,13 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
     ctx->spmv_lanes_override = v;
     return PPH_OK;
   }
+  if (!strcmp(name, "spmv_kernel")) {
+    const int v = (int)value;
+    PPH_REQUIRE(ctx, (v >= 0 && v <= 8) || v == 10 || v == 11, "spmv_kernel: 0 vector, 1 vector+preload, 2 LDS stream, 3 aligned-wide (default), 4 LDS-transposed, 5-7 multi-row, 8 aligned-wide XCD-contiguous, 10 no-gather probe");
+    ctx->spmv_kernel = v;
+    return PPH_OK;
+  }
+  if (!strcmp(name, "spmv_blocks")) { la_set_spmv_blocks((int)value); return PPH_OK; }
   if (!strcmp(name, "time_spmv")) { ctx->time_spmv = value != 0.0; return PPH_OK; }
   if (!strcmp(name, "invalidate_KM")) {
     // forget the integrated K and M so that the next pph_assemble_dpp integrates again (benchmarks)
@@ -405,3 +416,43 @@ int pph_get_timers(pph_ctx* ctx, double* out, int n) {
 }
 
 }  // extern "C"
+
+// ---- bandwidth calibration (no reference counterpart; used by tools/ and DESIGN.md) -------------------
+__global__ __launch_bounds__(256) void k_bw_read(const double2* __restrict__ a, int64_t n2, double* __restrict__ out) {
+  double s = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {
+    const double2 v = a[i];
+    s += v.x + v.y;
+  }
+  if (s == 1.2345e300) out[0] = s;  // keeps the loads alive
+}
+__global__ __launch_bounds__(256) void k_bw_copy(const double2* __restrict__ a, double2* __restrict__ b, int64_t n2) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x)
+    b[i] = a[i];
+}
+
+extern "C" int pph_bw_probe(pph_ctx* ctx, int64_t bytes, int mode, int blocks, double* ms_out) {
+  if (!ctx || !ms_out || bytes < 4096) return PPH_ERR_INVALID;
+  PPH_HIP(ctx, hipSetDevice(ctx->device));
+  DevBuf<double> a, b;
+  const size_t n = (size_t)(bytes / 8);
+  PPH_TRY(a.alloc(ctx, n));
+  if (mode == 1) PPH_TRY(b.alloc(ctx, n));
+  PPH_HIP(ctx, hipMemsetAsync(a.p, 0, n * 8, ctx->stream));
+  const int reps = 10;
+  for (int it = 0; it < 2 + reps; ++it) {
+    if (it == 2) PPH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    if (mode == 0)
+      hipLaunchKernelGGL(k_bw_read, dim3(blocks), dim3(256), 0, ctx->stream, (const double2*)a.p, (int64_t)(n / 2), ctx->scal.p);
+    else
+      hipLaunchKernelGGL(k_bw_copy, dim3(blocks), dim3(256), 0, ctx->stream, (const double2*)a.p, (double2*)b.p, (int64_t)(n / 2));
+  }
+  PPH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  PPH_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  PPH_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *ms_out = ms / reps;
+  a.release();
+  b.release();
+  return PPH_OK;
+}

@@ -55,7 +55,8 @@ struct Csr {  // device CSR view (no ownership)
   const double* val = nullptr;
   int64_t nrows = 0;
   int64_t nnz = 0;
-  int lanes = 8;  // lanes per row used by the SpMV kernel
+  int lanes = 8;    // lanes per row used by the CSR-vector SpMV kernel
+  int max_row = 0;  // longest row (0: unknown) - selects the CSR-stream kernel geometry
 };
 
 // one structured mesh level (local box): geometry, cell->dof map, scalar pattern, K and M
@@ -65,6 +66,7 @@ struct MeshData {
   int z0 = 0, nzl = 0;                  // local slab: first cell layer, layer count
   int px = 0, py = 0, pzl = 0;          // local node dims
   int64_t n = 0, ncell = 0, nnzb = 0;   // nodes, cells, nnz of one scalar block
+  int max_row = 0;                      // stencil size = longest row of the scalar pattern
   DevBuf<double> cx, cy, cz;            // nodal coordinates (SoA)
   DevBuf<int32_t> cells;                // cell -> dof map [ncell][m]
   DevBuf<int64_t> rowptr;               // scalar CSR pattern
@@ -130,6 +132,7 @@ struct pph_ctx {
   std::vector<EvPair> ev_pool;          // reusable event pairs
   size_t ev_used = 0;                   // pairs recorded since the last harvest
   int spmv_lanes_override = 0;          // 0: pick from the mean row length
+  int spmv_kernel = 3;                  // 3: aligned-wide CSR-vector (default); 0,1,2,4..8,10: variants kept for A/B runs
 };
 
 // lanes per row of the CSR-vector SpMV for a matrix with the given mean row length
@@ -150,6 +153,7 @@ int pph_launch_blocks(pph_ctx* ctx, int monolithic);
 
 // linear algebra on the context stream; all results that feed control flow go through ctx->scal
 void la_spmv(pph_ctx* ctx, const Csr& A, const double* x, double* y);
+void la_spmv_resid(pph_ctx* ctx, const Csr& A, const double* x, const double* b, double* y);  // y = b - A x
 // y = A x and partial sums of dot(x, y) -> scal slot
 void la_spmv_dot(pph_ctx* ctx, const Csr& A, const double* x, double* y, int slot);
 void la_set(pph_ctx* ctx, double* x, double v, int64_t n);

@@ -8,7 +8,8 @@
 #include "pph_internal.h"
 
 #define RED_BLOCKS 1024        // grid of the BLAS-1 reduction kernels
-#define SPMV_MAX_BLOCKS 2048   // grid cap of the persistent SpMV kernel (multiple of 8 XCDs)
+#define SPMV_MAX_BLOCKS 2048   // upper limit of the persistent SpMV grid (multiple of 8 XCDs)
+#define SPMV_DEF_BLOCKS 1024   // default grid: 4 workgroups per CU measured fastest (tools/spmv_probe.py)
 #define PART_STRIDE 2048       // partial sums per reduction slot
 #define PART_SLOTS 32          // concurrent reduction slots (GMRES restart 30 + 2)
 
@@ -39,10 +40,11 @@ __device__ inline double block_sum(double v, double* lds) {
 // workgroups with equal (blockIdx % 8) share an XCD (and its 4 MiB L2), so each XCD walks one
 // contiguous eighth of the rows and the x entries its rows gather stay in that XCD's L2.
 // ------------------------------------------------------------------------------------------------
-template <int G, bool DOT>
+template <int G, bool DOT, int U>
 __global__ __launch_bounds__(256) void k_spmv(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                               const double* __restrict__ val, const double* __restrict__ x,
-                                              double* __restrict__ y, int64_t nrows, double* __restrict__ part) {
+                                              const double* __restrict__ bvec, double* __restrict__ y, int64_t nrows,
+                                              double* __restrict__ part) {
   constexpr int RPB = 256 / G;  // rows per workgroup per step
   __shared__ double lds[4];
   const int sub = threadIdx.x % G;
@@ -60,14 +62,310 @@ __global__ __launch_bounds__(256) void k_spmv(const int64_t* __restrict__ rowptr
     double sum = 0.0;
     if (row < nrows) {
       const int64_t s = rowptr[row], e = rowptr[row + 1];
-      for (int64_t k = s + sub; k < e; k += G) sum += val[k] * x[col[k]];
+      if (U == 1) {
+        for (int64_t k = s + sub; k < e; k += G) sum += val[k] * x[col[k]];
+      } else {
+        // issue U column + U value loads per lane before the first gather (more bytes in flight per wave)
+        for (int64_t k0 = s + sub; k0 < e; k0 += (int64_t)U * G) {
+          int32_t c[U];
+          double v[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int64_t k = k0 + (int64_t)u * G;
+            const bool ok = k < e;
+            c[u] = ok ? col[k] : 0;
+            v[u] = ok ? val[k] : 0.0;
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) sum += v[u] * x[c[u]];
+        }
+      }
     }
 #pragma unroll
     for (int o = G / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, G);
     if (sub == 0 && row < nrows) {
-      y[row] = sum;
+      y[row] = bvec ? bvec[row] - sum : sum;
       if (DOT) acc += sum * x[row];
     }
+  }
+  if (DOT) {
+    acc = block_sum(acc, lds);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+  }
+}
+
+// Aligned-wide CSR-vector variant: every lane reads 4 consecutive non-zeros per step with 16-byte loads
+// (one dwordx4 of columns, two dwordx4 of values) from the row start rounded DOWN to a multiple of 4;
+// entries outside [rowptr[row], rowptr[row+1]) are masked.  8-byte and 4-byte-per-lane streams reach a
+// markedly lower share of the HBM rate than 16-byte-per-lane streams on gfx950.  Device buffers carry
+// 64 bytes of slack, so the rounded reads stay inside the allocations.
+template <int G, bool DOT, int MODE = 0>
+__global__ __launch_bounds__(256) void k_spmv_wide(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                   const double* __restrict__ val, const double* __restrict__ x,
+                                                   const double* __restrict__ bvec, double* __restrict__ y,
+                                                   int64_t nrows, double* __restrict__ part) {
+  constexpr int RPB = 256 / G;
+  __shared__ double lds[4];
+  const int sub = threadIdx.x % G;
+  const int grp = threadIdx.x / G;
+  const int64_t nchunks = (nrows + RPB - 1) / RPB;
+  const int xcd = blockIdx.x & 7;
+  const int bx = blockIdx.x >> 3;
+  const int bpx = gridDim.x >> 3;
+  const int64_t cpx = (nchunks + 7) >> 3;
+  // MODE 2 (experiment): plain grid-stride chunk order instead of one contiguous eighth per XCD
+  const int64_t c_begin = (MODE == 2) ? 0 : (int64_t)xcd * cpx;
+  const int64_t c_end = (MODE == 2) ? nchunks : ((c_begin + cpx < nchunks) ? c_begin + cpx : nchunks);
+  const int64_t c_first = (MODE == 2) ? blockIdx.x : c_begin + bx;
+  const int64_t c_step = (MODE == 2) ? gridDim.x : bpx;
+  double acc = 0.0;
+  for (int64_t ch = c_first; ch < c_end; ch += c_step) {
+    const int64_t row = ch * RPB + grp;
+    double sum = 0.0;
+    if (row < nrows) {
+      const int64_t s = rowptr[row], e = rowptr[row + 1];
+      const int32_t safe = 0;  // column used by masked lanes (x[0] is always valid)
+      for (int64_t base = (s & ~(int64_t)3) + 4 * sub; base < e; base += 4 * G) {
+        const int4 c = *reinterpret_cast<const int4*>(col + base);
+        const double2 v01 = *reinterpret_cast<const double2*>(val + base);
+        const double2 v23 = *reinterpret_cast<const double2*>(val + base + 2);
+        const bool k0 = base >= s, k1 = base + 1 >= s && base + 1 < e, k2 = base + 2 >= s && base + 2 < e,
+                   k3 = base + 3 < e && base + 3 >= s;
+        double x0, x1, x2, x3;
+        if (MODE == 1) {  // experiment: no gather (streams the matrix only); results are wrong on purpose
+          x0 = x1 = x2 = x3 = (double)(c.x + c.y + c.z + c.w);
+        } else {
+          x0 = x[k0 ? c.x : safe]; x1 = x[k1 ? c.y : safe]; x2 = x[k2 ? c.z : safe]; x3 = x[k3 ? c.w : safe];
+        }
+        sum += (k0 ? v01.x : 0.0) * x0 + (k1 ? v01.y : 0.0) * x1 + (k2 ? v23.x : 0.0) * x2 + (k3 ? v23.y : 0.0) * x3;
+      }
+    }
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, G);
+    if (sub == 0 && row < nrows) {
+      y[row] = bvec ? bvec[row] - sum : sum;
+      if (DOT) acc += sum * x[row];
+    }
+  }
+  if (DOT) {
+    acc = block_sum(acc, lds);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+  }
+}
+
+// Aligned-wide CSR-vector kernel with UR rows in flight per lane group: the dependent chain
+// rowptr -> (columns, values) -> x gather is latency-bound when a wave carries one row per group
+// (about 3 KB in flight), so every group walks UR row-chunks at once: all row pointers are requested
+// first, then all 16-byte column/value loads, then all gathers.
+template <int G, bool DOT, int UR>
+__global__ __launch_bounds__(256) void k_spmv_wide_u(const int64_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ col,
+                                                     const double* __restrict__ val, const double* __restrict__ x,
+                                                     const double* __restrict__ bvec, double* __restrict__ y,
+                                                     int64_t nrows, double* __restrict__ part) {
+  constexpr int RPB = 256 / G;
+  __shared__ double lds[4];
+  const int sub = threadIdx.x % G;
+  const int grp = threadIdx.x / G;
+  const int64_t nchunks = (nrows + RPB - 1) / RPB;
+  double acc = 0.0;
+  for (int64_t ch0 = blockIdx.x; ch0 < nchunks; ch0 += (int64_t)UR * gridDim.x) {
+    int64_t row[UR], s[UR], e[UR], base[UR];
+    double sum[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      const int64_t ch = ch0 + (int64_t)u * gridDim.x;
+      row[u] = ch * RPB + grp;
+      const bool ok = ch < nchunks && row[u] < nrows;
+      if (!ok) row[u] = -1;
+      s[u] = ok ? rowptr[row[u]] : 0;
+      e[u] = ok ? rowptr[row[u] + 1] : 0;
+      sum[u] = 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < UR; ++u) base[u] = (s[u] & ~(int64_t)3) + 4 * sub;
+    bool more = false;
+#pragma unroll
+    for (int u = 0; u < UR; ++u) more = more || (base[u] < e[u]);
+    while (more) {
+      int4 c[UR];
+      double2 va[UR], vb[UR];
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        const bool act = base[u] < e[u];
+        const int64_t b = act ? base[u] : 0;
+        c[u] = *reinterpret_cast<const int4*>(col + b);
+        va[u] = *reinterpret_cast<const double2*>(val + b);
+        vb[u] = *reinterpret_cast<const double2*>(val + b + 2);
+      }
+      double xg[UR][4];
+      bool kk[UR][4];
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        const int64_t b = base[u];
+        kk[u][0] = b >= s[u] && b < e[u];
+        kk[u][1] = b + 1 >= s[u] && b + 1 < e[u];
+        kk[u][2] = b + 2 >= s[u] && b + 2 < e[u];
+        kk[u][3] = b + 3 >= s[u] && b + 3 < e[u];
+        xg[u][0] = x[kk[u][0] ? c[u].x : 0];
+        xg[u][1] = x[kk[u][1] ? c[u].y : 0];
+        xg[u][2] = x[kk[u][2] ? c[u].z : 0];
+        xg[u][3] = x[kk[u][3] ? c[u].w : 0];
+      }
+      more = false;
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        sum[u] += (kk[u][0] ? va[u].x : 0.0) * xg[u][0] + (kk[u][1] ? va[u].y : 0.0) * xg[u][1] +
+                  (kk[u][2] ? vb[u].x : 0.0) * xg[u][2] + (kk[u][3] ? vb[u].y : 0.0) * xg[u][3];
+        base[u] += 4 * G;
+        more = more || (base[u] < e[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UR; ++u) {
+      double t = sum[u];
+#pragma unroll
+      for (int o = G / 2; o > 0; o >>= 1) t += __shfl_down(t, o, G);
+      if (sub == 0 && row[u] >= 0) {
+        y[row[u]] = bvec ? bvec[row[u]] - t : t;
+        if (DOT) acc += t * x[row[u]];
+      }
+    }
+  }
+  if (DOT) {
+    acc = block_sum(acc, lds);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+  }
+}
+
+// LDS-transposed CSR variant ("stream in by non-zero, consume by row"): a 64-lane workgroup (one wavefront)
+// takes RB = 64/T consecutive rows, copies their contiguous column/value ranges into LDS with 16-byte
+// coalesced loads, then every lane walks ONE row (T = 1; T lanes share a row for long rows) out of LDS.
+// Consecutive lanes hold consecutive rows, so for a stencil-like matrix the x gathers of one wave
+// instruction fall on a few consecutive cache lines instead of one line per lane group, and y is written
+// coalesced without any cross-lane reduction.  Needs max_row <= 32 T (at most SPMV_LDS_N entries per step).
+#define SPMV_LDS_N 2048
+template <int T, bool DOT>
+__global__ __launch_bounds__(64) void k_spmv_lds(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                 const double* __restrict__ val, const double* __restrict__ x,
+                                                 const double* __restrict__ bvec, double* __restrict__ y,
+                                                 int64_t nrows, double* __restrict__ part) {
+  constexpr int RB = 64 / T;
+  __shared__ __attribute__((aligned(16))) int32_t sc[SPMV_LDS_N + 8];
+  __shared__ __attribute__((aligned(16))) double sv[SPMV_LDS_N + 8];
+  const int lane = threadIdx.x;
+  const int64_t nchunks = (nrows + RB - 1) / RB;
+  double acc = 0.0;
+  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const int64_t R0 = ch * RB;
+    const int64_t Rend = (R0 + RB < nrows) ? R0 + RB : nrows;
+    const int64_t s = rowptr[R0];
+    const int64_t s4 = s & ~(int64_t)3;
+    const int span = (int)(rowptr[Rend] - s4);
+    for (int i = lane * 4; i < span; i += 256) {
+      const int4 c = *reinterpret_cast<const int4*>(col + s4 + i);
+      const double2 v01 = *reinterpret_cast<const double2*>(val + s4 + i);
+      const double2 v23 = *reinterpret_cast<const double2*>(val + s4 + i + 2);
+      *reinterpret_cast<int4*>(sc + i) = c;
+      *reinterpret_cast<double2*>(sv + i) = v01;
+      *reinterpret_cast<double2*>(sv + i + 2) = v23;
+    }
+    __syncthreads();
+    const int rl = lane / T, j = lane % T;
+    const int64_t row = R0 + rl;
+    double sum = 0.0;
+    if (row < Rend) {
+      const int b = (int)(rowptr[row] - s4), e = (int)(rowptr[row + 1] - s4);
+      const int per = (e - b + T - 1) / T;
+      const int b2 = b + j * per;
+      const int e2 = (b2 + per < e) ? b2 + per : e;
+      for (int i = b2; i < e2; i += 8) {
+        double xv[8], vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const bool ok = i + u < e2;
+          const int32_t c = ok ? sc[i + u] : 0;
+          vv[u] = ok ? sv[i + u] : 0.0;
+          xv[u] = x[c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum += vv[u] * xv[u];
+      }
+    }
+#pragma unroll
+    for (int o = T / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, T);
+    if (j == 0 && row < Rend) {
+      y[row] = bvec ? bvec[row] - sum : sum;
+      if (DOT) acc += sum * x[row];
+    }
+    __syncthreads();
+  }
+  if (DOT) {
+    acc = wave_sum(acc);
+    if (lane == 0) part[blockIdx.x] = acc;
+  }
+}
+
+// CSR-stream variant: a workgroup takes RB = 256/T consecutive rows, streams their (contiguous) column
+// and value ranges with fully coalesced loads, parks the products in LDS and lets T lanes per row sum
+// them.  Requires max row length <= 8 T (launcher picks T), i.e. at most SPMV_LB products per chunk.
+#define SPMV_LB 2048
+template <int T, bool DOT>
+__global__ __launch_bounds__(256) void k_spmv_stream(const int64_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ col,
+                                                     const double* __restrict__ val, const double* __restrict__ x,
+                                                     const double* __restrict__ bvec, double* __restrict__ y,
+                                                     int64_t nrows, double* __restrict__ part) {
+  constexpr int RB = 256 / T;
+  constexpr int U = SPMV_LB / 256;
+  __shared__ double prod[SPMV_LB];
+  __shared__ int64_t rp[RB + 1];
+  __shared__ double lds[4];
+  const int tid = threadIdx.x;
+  const int64_t nchunks = (nrows + RB - 1) / RB;
+  const int xcd = blockIdx.x & 7;
+  const int bx = blockIdx.x >> 3;
+  const int bpx = gridDim.x >> 3;
+  const int64_t cpx = (nchunks + 7) >> 3;
+  const int64_t c_begin = (int64_t)xcd * cpx;
+  const int64_t c_end = (c_begin + cpx < nchunks) ? c_begin + cpx : nchunks;
+  double acc = 0.0;
+  for (int64_t ch = c_begin + bx; ch < c_end; ch += bpx) {
+    const int64_t R0 = ch * RB;
+    if (tid <= RB) {
+      const int64_t r = R0 + tid;
+      rp[tid] = rowptr[r < nrows ? r : nrows];
+    }
+    __syncthreads();
+    const int64_t s = rp[0];
+    const int cnt = (int)(rp[RB] - s);
+    int32_t c[U];
+    double v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = tid + u * 256;
+      const bool ok = k < cnt;
+      c[u] = ok ? col[s + k] : 0;
+      v[u] = ok ? val[s + k] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = tid + u * 256;
+      if (k < cnt) prod[k] = v[u] * x[c[u]];
+    }
+    __syncthreads();
+    const int rl = tid / T, j = tid % T;
+    const int b = (int)(rp[rl] - s), e = (int)(rp[rl + 1] - s);
+    double sum = 0.0;
+    for (int i = b + j; i < e; i += T) sum += prod[i];
+#pragma unroll
+    for (int o = T / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, T);
+    const int64_t row = R0 + rl;
+    if (j == 0 && row < nrows) {
+      y[row] = bvec ? bvec[row] - sum : sum;
+      if (DOT) acc += sum * x[row];
+    }
+    __syncthreads();
   }
   if (DOT) {
     acc = block_sum(acc, lds);
@@ -85,17 +383,26 @@ __global__ __launch_bounds__(256) void k_reduce_final(const double* __restrict__
   if (threadIdx.x == 0) out[blockIdx.x] = v;
 }
 
-static int spmv_grid(int64_t nrows, int G) {
-  int64_t nchunks = ceil_div64(nrows, 256 / G);
-  int64_t g = nchunks < SPMV_MAX_BLOCKS ? nchunks : SPMV_MAX_BLOCKS;
+static int g_spmv_blocks = SPMV_DEF_BLOCKS;  // tuning knob (option "spmv_blocks")
+void la_set_spmv_blocks(int b) { g_spmv_blocks = (b >= 8 && b <= SPMV_MAX_BLOCKS) ? (b / 8) * 8 : SPMV_DEF_BLOCKS; }
+
+static int spmv_grid(int64_t nrows, int rows_per_block) {
+  int64_t nchunks = ceil_div64(nrows, rows_per_block);
+  int64_t g = nchunks < g_spmv_blocks ? nchunks : g_spmv_blocks;
   g = ((g + 7) / 8) * 8;
   return (int)g;
 }
 
+// lanes per row of the reduction phase of the stream kernel: smallest T with 8 T >= max_row
+static int stream_T(int max_row) {
+  int T = 4;
+  while (8 * T < max_row && T < 64) T *= 2;
+  return T;
+}
+
+// returns the grid used (number of partial sums written when DOT)
 template <bool DOT>
-static void spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, double* y, double* part) {
-  const int G = A.lanes;
-  const int grid = spmv_grid(A.nrows, G);
+static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const double* bvec, double* y, double* part) {
   const int variant = DOT ? 1 : 0;
   pph_ctx::EvPair* ev = nullptr;
   if (ctx->time_spmv) {
@@ -110,25 +417,95 @@ static void spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, double* y
       (void)hipEventRecord(ev->e0, ctx->stream);
     }
   }
-#define PPH_SPMV_CASE(GG)                                                                                    \
-  case GG:                                                                                                   \
-    hipLaunchKernelGGL((k_spmv<GG, DOT>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, y, \
-                       A.nrows, part);                                                                       \
+  int grid = 8;
+  const bool can_stream = A.max_row > 0 && A.max_row <= 8 * 64;
+  if (ctx->spmv_kernel == 2 && can_stream) {
+    const int T = stream_T(A.max_row);
+    grid = spmv_grid(A.nrows, 256 / T);
+#define PPH_STREAM_CASE(TT)                                                                                       \
+  case TT:                                                                                                        \
+    hipLaunchKernelGGL((k_spmv_stream<TT, DOT>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, \
+                       bvec, y, A.nrows, part);                                                                   \
     break;
-  switch (G) {
-    PPH_SPMV_CASE(4)
-    PPH_SPMV_CASE(8)
-    PPH_SPMV_CASE(16)
-    PPH_SPMV_CASE(32)
-    PPH_SPMV_CASE(64)
-    default:
-      hipLaunchKernelGGL((k_spmv<8, DOT>), dim3(spmv_grid(A.nrows, 8)), dim3(256), 0, ctx->stream, A.rowptr, A.col,
-                         A.val, x, y, A.nrows, part);
-  }
+    switch (T) {
+      PPH_STREAM_CASE(4)
+      PPH_STREAM_CASE(8)
+      PPH_STREAM_CASE(16)
+      PPH_STREAM_CASE(32)
+      default:
+        hipLaunchKernelGGL((k_spmv_stream<64, DOT>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x,
+                           bvec, y, A.nrows, part);
+    }
+#undef PPH_STREAM_CASE
+  } else if (ctx->spmv_kernel == 4 && A.max_row > 0 && A.max_row <= 32 * 4) {
+    const int T = A.max_row <= 32 ? 1 : (A.max_row <= 64 ? 2 : 4);
+    const int64_t nchunks = ceil_div64(A.nrows, 64 / T);
+    grid = (int)(nchunks < SPMV_MAX_BLOCKS ? nchunks : SPMV_MAX_BLOCKS);
+    if (T == 1)
+      hipLaunchKernelGGL((k_spmv_lds<1, DOT>), dim3(grid), dim3(64), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
+    else if (T == 2)
+      hipLaunchKernelGGL((k_spmv_lds<2, DOT>), dim3(grid), dim3(64), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
+    else
+      hipLaunchKernelGGL((k_spmv_lds<4, DOT>), dim3(grid), dim3(64), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
+  } else if (ctx->spmv_kernel >= 5 && ctx->spmv_kernel <= 7) {
+    grid = spmv_grid(A.nrows, 256 / 8);
+    if (ctx->spmv_kernel == 5)
+      hipLaunchKernelGGL((k_spmv_wide_u<8, DOT, 2>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
+    else if (ctx->spmv_kernel == 6)
+      hipLaunchKernelGGL((k_spmv_wide_u<8, DOT, 4>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
+    else
+      hipLaunchKernelGGL((k_spmv_wide_u<4, DOT, 4>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
+  } else if (ctx->spmv_kernel == 10) {
+    grid = spmv_grid(A.nrows, 256 / 8);
+    hipLaunchKernelGGL((k_spmv_wide<8, DOT, 1>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
+  } else if (ctx->spmv_kernel == 3 || ctx->spmv_kernel == 8 || ctx->spmv_kernel == 11) {
+    // lanes per row: one 4-wide step covers 4 G entries; rows of up to 29 entries fit G = 8
+    int G = ctx->spmv_lanes_override > 0 ? ctx->spmv_lanes_override : (A.max_row > 0 && A.max_row + 3 <= 16 ? 4 : 8);
+    if (G != 4 && G != 8 && G != 16 && G != 32 && G != 64) G = 8;
+    grid = spmv_grid(A.nrows, 256 / G);
+#define PPH_WIDE_CASE(GG)                                                                                       \
+  case GG:                                                                                                      \
+    if (ctx->spmv_kernel == 8)                                                                                  \
+      hipLaunchKernelGGL((k_spmv_wide<GG, DOT, 0>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, \
+                         bvec, y, A.nrows, part);                                                               \
+    else                                                                                                        \
+      hipLaunchKernelGGL((k_spmv_wide<GG, DOT, 2>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, \
+                         bvec, y, A.nrows, part);                                                               \
+    break;
+    switch (G) {
+      PPH_WIDE_CASE(4)
+      PPH_WIDE_CASE(8)
+      PPH_WIDE_CASE(16)
+      PPH_WIDE_CASE(32)
+      PPH_WIDE_CASE(64)
+    }
+#undef PPH_WIDE_CASE
+  } else {
+    int G = A.lanes;
+    if (G != 4 && G != 8 && G != 16 && G != 32 && G != 64) G = 8;
+    grid = spmv_grid(A.nrows, 256 / G);
+#define PPH_SPMV_CASE(GG)                                                                                          \
+  case GG:                                                                                                         \
+    if (ctx->spmv_kernel == 0)                                                                                     \
+      hipLaunchKernelGGL((k_spmv<GG, DOT, 1>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, \
+                         y, A.nrows, part);                                                                        \
+    else                                                                                                           \
+      hipLaunchKernelGGL((k_spmv<GG, DOT, 4>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, \
+                         y, A.nrows, part);                                                                        \
+    break;
+    switch (G) {
+      PPH_SPMV_CASE(4)
+      PPH_SPMV_CASE(8)
+      PPH_SPMV_CASE(16)
+      PPH_SPMV_CASE(32)
+      PPH_SPMV_CASE(64)
+    }
 #undef PPH_SPMV_CASE
+  }
   if (ev) (void)hipEventRecord(ev->e1, ctx->stream);
   ctx->n_spmv[variant]++;
   ctx->spmv_bytes[variant] += 12.0 * (double)A.nnz + 20.0 * (double)A.nrows;
+  return grid;
 }
 
 void la_harvest_spmv_times(pph_ctx* ctx) {
@@ -149,13 +526,17 @@ void la_reset_spmv_stats(pph_ctx* ctx) {
 
 
 void la_spmv(pph_ctx* ctx, const Csr& A, const double* x, double* y) {
-  spmv_dispatch<false>(ctx, A, x, y, nullptr);
+  spmv_dispatch<false>(ctx, A, x, nullptr, y, nullptr);
+}
+
+// y = b - A x
+void la_spmv_resid(pph_ctx* ctx, const Csr& A, const double* x, const double* b, double* y) {
+  spmv_dispatch<false>(ctx, A, x, b, y, nullptr);
 }
 
 void la_spmv_dot(pph_ctx* ctx, const Csr& A, const double* x, double* y, int slot) {
   double* part = partials(ctx);
-  spmv_dispatch<true>(ctx, A, x, y, part);
-  const int grid = spmv_grid(A.nrows, A.lanes);
+  const int grid = spmv_dispatch<true>(ctx, A, x, nullptr, y, part);
   hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, ctx->stream, part, grid, ctx->scal.p + slot);
 }
 

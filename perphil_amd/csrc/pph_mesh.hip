@@ -245,6 +245,7 @@ int pph_launch_pattern(pph_ctx* ctx, int dim, int kind, int px, int py, int pz, 
 // cell->dof map and the scalar CSR pattern on the device
 int pph_launch_mesh(pph_ctx* ctx, MeshData& mesh) {
   mesh.m = (mesh.kind == PPH_CELL_QUAD) ? 4 : (mesh.kind == PPH_CELL_TRI) ? 3 : (mesh.kind == PPH_CELL_HEX) ? 8 : 4;
+  mesh.max_row = (mesh.kind == PPH_CELL_QUAD) ? 9 : (mesh.kind == PPH_CELL_TRI) ? 7 : (mesh.kind == PPH_CELL_HEX) ? 27 : 15;
   mesh.px = mesh.nx + 1;
   mesh.py = mesh.ny + 1;
   mesh.pzl = (mesh.dim == 3) ? mesh.nzl + 1 : 1;

@@ -84,36 +84,65 @@ __global__ void k_restrict(double* __restrict__ bc, const double* __restrict__ r
   }
 }
 
-// x_f[f] += sum over (C, d) with 2C + d = f of w_d x_c[C]   (constrained fine dofs untouched)
-__global__ void k_prolong_add(double* __restrict__ xf, const double* __restrict__ xc, TStencil st,
-                              const uint8_t* __restrict__ mf, int pxc, int pyc, int pzc, int pxf, int pyf, int pzf) {
+// x_f[f] += (P x_c)[f]   (constrained fine dofs untouched).  Closed form of the transpose of k_restrict:
+// a fine node f = 2c + o (o = parity vector) interpolates
+//   Q1 (TK 0)         : the 2^|o| coarse nodes c + s, s <= o component-wise, weight 2^-|o|
+//   Kuhn P1 (TK 1)    : 1/2 (x_c[c] + x_c[c + o])                         (o != 0)
+//   left-diag P1 (TK 2): o = (1,1): 1/2 (x_c[c + x] + x_c[c + y]), else as Kuhn
+template <int TK>
+__global__ __launch_bounds__(256) void k_prolong_add(double* __restrict__ xf, const double* __restrict__ xc,
+                                                     const uint8_t* __restrict__ mf, int pxc, int pyc, int pxf,
+                                                     int pyf, int pzf) {
   const int64_t nf = (int64_t)pxf * pyf * pzf;
   NODE_LOOP(id, nf) {
     if (mf[id] != 0) continue;
     const int i = (int)(id % pxf);
     const int64_t t = id / pxf;
     const int j = (int)(t % pyf), k = (int)(t / pyf);
-    double s = 0.0;
-    for (int q = 0; q < st.count; ++q) {
-      const int ci = i - st.d[q][0], cj = j - st.d[q][1], ck = k - st.d[q][2];
-      if (((ci | cj | ck) & 1) != 0) continue;
-      const int I = ci >> 1, J = cj >> 1, K = ck >> 1;
-      if (ci >= 0 && I < pxc && cj >= 0 && J < pyc && ck >= 0 && K < pzc)
-        s += st.w[q] * xc[I + (int64_t)pxc * (J + (int64_t)pyc * K)];
+    const int ox = i & 1, oy = j & 1, oz = k & 1;
+    const int64_t sx = 1, sy = pxc, sz = (int64_t)pxc * pyc;
+    const int64_t c = (i >> 1) + sy * (j >> 1) + sz * (k >> 1);
+    double s;
+    if (TK == 0) {
+      // tensor product of 1D interpolations
+      double a0 = xc[c], a1 = ox ? xc[c + sx] : a0;
+      double v00 = 0.5 * (a0 + a1);
+      if (!(oy | oz)) {
+        s = v00;
+      } else {
+        double v10 = v00, v01 = v00, v11 = v00;
+        if (oy) { a0 = xc[c + sy]; a1 = ox ? xc[c + sy + sx] : a0; v10 = 0.5 * (a0 + a1); }
+        if (oz) { a0 = xc[c + sz]; a1 = ox ? xc[c + sz + sx] : a0; v01 = 0.5 * (a0 + a1); }
+        if (oy && oz) { a0 = xc[c + sy + sz]; a1 = ox ? xc[c + sy + sz + sx] : a0; v11 = 0.5 * (a0 + a1); }
+        else v11 = oy ? v10 : v01;
+        if (oy && oz) s = 0.25 * (v00 + v10 + v01 + v11);
+        else s = 0.5 * (v00 + (oy ? v10 : v01));
+      }
+    } else {
+      const int64_t o = ox * sx + oy * sy + oz * sz;
+      if (TK == 2 && ox && oy) s = 0.5 * (xc[c + sx] + xc[c + sy]);
+      else s = (o == 0) ? xc[c] : 0.5 * (xc[c] + xc[c + o]);
     }
     xf[id] += s;
   }
 }
 
-// max over rows of sum_j |a_ij| / a_ii, accumulated with an integer atomic max on the bit pattern
-__global__ void k_lam_bound(const int64_t* __restrict__ rowptr, const double* __restrict__ val,
-                            const double* __restrict__ dinv, int64_t n, unsigned long long* __restrict__ out) {
+// max over rows of sum_j |a_ij| / a_ii (8 lanes per row), accumulated with an integer atomic max on the
+// bit pattern of the non-negative double
+__global__ __launch_bounds__(256) void k_lam_bound(const int64_t* __restrict__ rowptr, const double* __restrict__ val,
+                                                   const double* __restrict__ dinv, int64_t n,
+                                                   unsigned long long* __restrict__ out) {
+  const int sub = threadIdx.x & 7;
   double best = 0.0;
-  NODE_LOOP(row, n) {
+  for (int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 3; row < n;
+       row += ((int64_t)gridDim.x * blockDim.x) >> 3) {
     double s = 0.0;
-    for (int64_t k = rowptr[row]; k < rowptr[row + 1]; ++k) s += fabs(val[k]);
+    for (int64_t k = rowptr[row] + sub; k < rowptr[row + 1]; k += 8) s += fabs(val[k]);
+    s += __shfl_down(s, 4, 8);
+    s += __shfl_down(s, 2, 8);
+    s += __shfl_down(s, 1, 8);
     s *= fabs(dinv[row]);
-    best = s > best ? s : best;
+    best = (sub == 0 && s > best) ? s : best;
   }
   for (int o = 32; o > 0; o >>= 1) {
     const double t = __shfl_down(best, o, 64);
@@ -155,6 +184,7 @@ static inline int mg_grid(int64_t n) {
 static Csr level_csr(const pph_ctx* ctx, const MgLevel& L, int which) {
   Csr A;
   A.rowptr = L.rowptr; A.col = L.col; A.val = L.val[which]; A.nrows = L.n; A.nnz = L.nnz;
+  A.max_row = ctx->mesh.max_row;
   A.lanes = pph_pick_lanes(ctx, A.nnz, A.nrows);
   return A;
 }
@@ -221,7 +251,7 @@ int mg_setup(pph_ctx* ctx) {
     }
     PPH_HIP(ctx, hipMemsetAsync(lamdev.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
     for (int f = 0; f < 2; ++f)
-      hipLaunchKernelGGL(k_lam_bound, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, L.rowptr, L.val[f], L.dinv[f].p,
+      hipLaunchKernelGGL(k_lam_bound, dim3(mg_grid(L.n * 8)), dim3(256), 0, ctx->stream, L.rowptr, L.val[f], L.dinv[f].p,
                          L.n, lamdev.p + f);
     unsigned long long bits[2];
     PPH_HIP(ctx, hipMemcpyAsync(bits, lamdev.p, sizeof(bits), hipMemcpyDeviceToHost, ctx->stream));
@@ -256,8 +286,7 @@ static void chebyshev(pph_ctx* ctx, MgLevel& L, int which, const double* b, doub
   if (zero_guess) {
     la_copy(ctx, r, b, L.n);
   } else {
-    la_spmv(ctx, A, x, L.t.p);
-    la_sub(ctx, r, b, L.t.p, L.n);
+    la_spmv_resid(ctx, A, x, b, r);
   }
   hipLaunchKernelGGL(k_cheb_init, dim3(grid), dim3(256), 0, ctx->stream, x, L.d.p, r, L.dinv[which].p, 1.0 / theta,
                      zero_guess ? 1 : 0, L.n);
@@ -286,8 +315,7 @@ void mg_vcycle(pph_ctx* ctx, int which, const double* rin, double* zout, int nsm
     const double* b = (l == 0) ? rin : L.b.p;
     double* x = (l == 0) ? zout : L.x.p;
     chebyshev(ctx, L, which, b, x, nsmooth, true);
-    la_spmv(ctx, level_csr(ctx, L, which), x, L.t.p);
-    la_sub(ctx, L.r.p, b, L.t.p, L.n);
+    la_spmv_resid(ctx, level_csr(ctx, L, which), x, b, L.r.p);
     hipLaunchKernelGGL(k_restrict, dim3(mg_grid(C.n)), dim3(256), 0, ctx->stream, C.b.p, L.r.p, st, C.maskp[which],
                        L.maskp[which], C.px, C.py, C.pz, L.px, L.py, L.pz);
   }
@@ -304,8 +332,16 @@ void mg_vcycle(pph_ctx* ctx, int which, const double* rin, double* zout, int nsm
     MgLevel& C = mg[l + 1];
     const double* b = (l == 0) ? rin : L.b.p;
     double* x = (l == 0) ? zout : L.x.p;
-    hipLaunchKernelGGL(k_prolong_add, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, x, C.x.p, st, L.maskp[which],
-                       C.px, C.py, C.pz, L.px, L.py, L.pz);
+    const int kind = ctx->mesh.kind;
+    if (kind == PPH_CELL_QUAD || kind == PPH_CELL_HEX)
+      hipLaunchKernelGGL(k_prolong_add<0>, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, x, C.x.p, L.maskp[which], C.px,
+                         C.py, L.px, L.py, L.pz);
+    else if (kind == PPH_CELL_TET)
+      hipLaunchKernelGGL(k_prolong_add<1>, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, x, C.x.p, L.maskp[which], C.px,
+                         C.py, L.px, L.py, L.pz);
+    else
+      hipLaunchKernelGGL(k_prolong_add<2>, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, x, C.x.p, L.maskp[which], C.px,
+                         C.py, L.px, L.py, L.pz);
     chebyshev(ctx, L, which, b, x, nsmooth, false);
   }
 }

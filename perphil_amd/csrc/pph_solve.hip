@@ -20,7 +20,7 @@ enum {
   W_GV, W_GW, W_GT,                     // GMRES basis / work
   W_FS1, W_FS2,                         // field-split temporaries
   W_DINV_M, W_DINV_1, W_DINV_2, W_BINV, // preconditioner data
-  W_DU, W_PB,                           // Picard correction, block rhs
+  W_DU, W_PB, W_T12, W_R1,              // Picard correction, block rhs, coupling term, macro residual
   W_COUNT
 };
 
@@ -42,11 +42,13 @@ struct KspOut {
   double res = 0.0;
   bool converged = false;
   bool breakdown = false;
+  double bnorm = 0.0;  // ||P^-1 b|| the tolerance was relative to
 };
 
 static Csr block_csr(pph_ctx* ctx, const double* val) {
   Csr A;
   A.rowptr = ctx->mesh.rowptr.p; A.col = ctx->mesh.col.p; A.val = val; A.nrows = ctx->n; A.nnz = ctx->nnzb;
+  A.max_row = ctx->mesh.max_row;
   A.lanes = pph_pick_lanes(ctx, A.nnz, A.nrows);
   return A;
 }
@@ -54,6 +56,7 @@ static Csr block_csr(pph_ctx* ctx, const double* val) {
 static Csr mono_csr(pph_ctx* ctx) {
   Csr A;
   A.rowptr = ctx->mrowptr.p; A.col = ctx->mcol.p; A.val = ctx->mval.p; A.nrows = 2 * ctx->n; A.nnz = 4 * ctx->nnzb;
+  A.max_row = 2 * ctx->mesh.max_row;
   A.lanes = pph_pick_lanes(ctx, A.nnz, A.nrows);
   return A;
 }
@@ -65,7 +68,7 @@ static Csr mono_csr(pph_ctx* ctx) {
 // ------------------------------------------------------------------------------------------------
 static int cg_solve(pph_ctx* ctx, const Csr& A, const double* b, double* x, const double* dinv, const ApplyFn& pc,
                     double rtol, double atol, int max_it, bool warm, double* r, double* z, double* p, double* q,
-                    int slot, KspOut* out, double* hist, int hist_cap) {
+                    int slot, KspOut* out, double* hist, int hist_cap, double bnorm_hint = -1.0) {
   const int64_t n = A.nrows;
   const bool fused = (dinv != nullptr) || !pc;
   auto apply_pc = [&](const double* in, double* o) {
@@ -75,13 +78,18 @@ static int cg_solve(pph_ctx* ctx, const Csr& A, const double* b, double* x, cons
   };
   double bnorm;
   if (warm) {
-    // tolerance is relative to ||P^-1 b|| also with a non-zero guess (KSPConvergedDefault)
-    apply_pc(b, z);
-    la_dot(ctx, z, z, n, slot);
-    PPH_TRY(la_fetch(ctx, slot, 1));
-    bnorm = std::sqrt(ctx->h_scal[slot]);
-    la_spmv(ctx, A, x, q);
-    la_sub(ctx, r, b, q, n);
+    // tolerance is relative to ||P^-1 b|| also with a non-zero guess (KSPConvergedDefault); callers that
+    // solve a sequence of nearby systems pass the norm of the first one instead of paying a
+    // preconditioner application per solve
+    if (bnorm_hint > 0.0) {
+      bnorm = bnorm_hint;
+    } else {
+      apply_pc(b, z);
+      la_dot(ctx, z, z, n, slot);
+      PPH_TRY(la_fetch(ctx, slot, 1));
+      bnorm = std::sqrt(ctx->h_scal[slot]);
+    }
+    la_spmv_resid(ctx, A, x, b, r);
   } else {
     la_set(ctx, x, 0.0, n);
     la_copy(ctx, r, b, n);
@@ -94,7 +102,7 @@ static int cg_solve(pph_ctx* ctx, const Csr& A, const double* b, double* x, cons
   double res = std::sqrt(ctx->h_scal[slot + 1]);
   if (bnorm < 0.0) bnorm = res;
   const double tol = std::fmax(rtol * bnorm, atol);
-  out->its = 0; out->res = res; out->converged = false; out->breakdown = false;
+  out->its = 0; out->res = res; out->converged = false; out->breakdown = false; out->bnorm = bnorm;
   if (hist && hist_cap > 0) hist[0] = res;
   if (!(res == res)) { out->breakdown = true; return PPH_OK; }
   if (res <= tol) { out->converged = true; return PPH_OK; }
@@ -269,6 +277,8 @@ struct BlockSolver {
   double* dinv[2] = {nullptr, nullptr};
   int total_its = 0;
   bool failed = false;
+  double bnorm_cache[2] = {-1.0, -1.0};  // ||P^-1 b|| of the first (cold) solve of each block
+  double* last_resid = nullptr;          // recurrence residual rhs - A z of the last CG solve (work vector)
 
   int setup() {
     A[0] = block_csr(ctx, ctx->A11.p);
@@ -306,7 +316,9 @@ struct BlockSolver {
       return PPH_OK;
     }
     PPH_TRY(cg_solve(ctx, A[which], rhs, z, dinv[which], pc, cfg->inner_rtol, cfg->inner_atol, cfg->inner_max_it,
-                     warm, r, zz, p, q, S_INNER, &ko, nullptr, 0));
+                     warm, r, zz, p, q, S_INNER, &ko, nullptr, 0, warm ? bnorm_cache[which] : -1.0));
+    if (!warm) bnorm_cache[which] = ko.bnorm;
+    last_resid = r;
     total_its += ko.its;
     if (ko.breakdown || !ko.converged) failed = true;
     return PPH_OK;
@@ -378,29 +390,56 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
     double res = r0;
     if (hist && hist_cap > 0) hist[0] = res;
     int its = 0;
+    // t12 holds A12 du2 of the previous sweep (zero at the start): it is both the coupling term of the
+    // next macro solve and what turns the macro CG's recurrence residual into the monolithic one:
+    //   r1 = b1 - A11 du1 - A12 du2_new = r_cg(A11) + A12 du2_old - A12 du2_new ;  r2 = r_cg(A22)
+    double *t12, *r1;
+    PPH_TRY(work(ctx, W_T12, (size_t)n, &t12));
+    PPH_TRY(work(ctx, W_R1, (size_t)n, &r1));
+    la_set(ctx, t12, 0.0, n);
+    const bool recur = (cfg->inner_ksp_type == PPH_KSP_CG);
     while (res > tol && its < cfg->picard_max_it) {
-      la_spmv(ctx, A12, du2, t);
-      la_sub(ctx, pb, b1, t, n);
+      la_sub(ctx, pb, b1, t12, n);
       PPH_TRY(bs.solve(0, pb, du1, its > 0));
-      la_spmv(ctx, A21, du1, t);
-      la_sub(ctx, pb, b2, t, n);
+      if (recur) {  // r1 = r_cg + A12 du2_old
+        la_copy(ctx, r1, bs.last_resid, n);
+        la_axpy(ctx, r1, 1.0, t12, n);
+      }
+      la_spmv_resid(ctx, A21, du1, b2, pb);
       PPH_TRY(bs.solve(1, pb, du2, its > 0));
       ++its;
-      // monolithic residual: r2 is the inner residual of the sweep's last solve, r1 picks up the new du2
-      la_spmv(ctx, bs.A[0], du1, t);
-      la_sub(ctx, pb, b1, t, n);
-      la_spmv(ctx, A12, du2, t);
-      la_axpy(ctx, pb, -1.0, t, n);
-      la_dot(ctx, pb, pb, n, S_A);
-      la_spmv(ctx, A21, du1, t);
-      la_sub(ctx, pb, b2, t, n);
-      la_spmv(ctx, bs.A[1], du2, t);
-      la_axpy(ctx, pb, -1.0, t, n);
-      la_dot(ctx, pb, pb, n, S_A + 1);
+      la_spmv(ctx, A12, du2, t12);
+      if (recur) {
+        la_axpy(ctx, r1, -1.0, t12, n);
+        la_dot(ctx, r1, r1, n, S_A);
+        la_dot(ctx, bs.last_resid, bs.last_resid, n, S_A + 1);
+      } else {
+        // inner "solves" without a residual recurrence (preonly): evaluate the monolithic residual
+        la_spmv_resid(ctx, bs.A[0], du1, b1, r1);
+        la_axpy(ctx, r1, -1.0, t12, n);
+        la_dot(ctx, r1, r1, n, S_A);
+        la_spmv_resid(ctx, A21, du1, b2, r1);
+        la_spmv(ctx, bs.A[1], du2, t);
+        la_axpy(ctx, r1, -1.0, t, n);
+        la_dot(ctx, r1, r1, n, S_A + 1);
+      }
       PPH_TRY(la_fetch(ctx, S_A, 2));
       res = std::sqrt(ctx->h_scal[S_A] + ctx->h_scal[S_A + 1]);
       if (hist && its < hist_cap) hist[its] = res;
       if (!(res == res)) break;
+      if (res <= tol && recur) {
+        // confirm with the true residual once; keep sweeping if the recurrence was optimistic
+        la_spmv_resid(ctx, bs.A[0], du1, b1, r1);
+        la_axpy(ctx, r1, -1.0, t12, n);
+        la_dot(ctx, r1, r1, n, S_A);
+        la_spmv_resid(ctx, A21, du1, b2, r1);
+        la_spmv(ctx, bs.A[1], du2, t);
+        la_axpy(ctx, r1, -1.0, t, n);
+        la_dot(ctx, r1, r1, n, S_A + 1);
+        PPH_TRY(la_fetch(ctx, S_A, 2));
+        res = std::sqrt(ctx->h_scal[S_A] + ctx->h_scal[S_A + 1]);
+        if (hist && its < hist_cap) hist[its] = res;
+      }
     }
     inf.iterations = its;
     inf.inner_iterations = bs.total_its;

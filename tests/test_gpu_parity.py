@@ -133,12 +133,15 @@ def test_G1_initial_residual_and_spmv(gpu_ctx_factory, goldens):
     assert np.linalg.norm(rhs) == pytest.approx(goldens["G1_initial_residual_10x10"], rel=1e-12)
     rng = np.random.default_rng(20260313)
     x = rng.uniform(-1, 1, 2 * osys.n)
-    for lanes in (0, 4, 8, 16, 32, 64):
-        ctx.set_option("spmv_lanes", lanes)
-        y = ctx.spmv(f.MAT_MONO, x)
-        ref = osys.A @ x
-        assert np.abs(y - ref).max() <= 1e-13 * np.abs(ref).max()
+    ref = osys.A @ x
+    for kern in (0, 1, 2, 3, 4, 5, 6, 7, 8):   # CSR-vector, with preload, CSR-stream, aligned-wide, LDS-transposed
+        ctx.set_option("spmv_kernel", kern)
+        for lanes in (0, 4, 8, 16, 32, 64):
+            ctx.set_option("spmv_lanes", lanes)
+            y = ctx.spmv(f.MAT_MONO, x)
+            assert np.abs(y - ref).max() <= 1e-13 * np.abs(ref).max(), (kern, lanes)
     ctx.set_option("spmv_lanes", 0)
+    ctx.set_option("spmv_kernel", 3)
     xs = x[: osys.n]
     for which, ref in ((f.MAT_A11, osys.A[: osys.n, : osys.n]), (f.MAT_A21, osys.A[osys.n:, : osys.n])):
         y = ctx.spmv(which, xs)
