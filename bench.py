@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=256, help="cells per direction of the unit cube")
+    ap.add_argument("--cells", type=int, default=256, help="cells per direction of the unit cube")
     ap.add_argument("--cpu-sample-n", type=int, default=48)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inner-rtol", type=float, default=1e-10)
@@ -119,7 +119,7 @@ def main():
 
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    N = args.n
+    N = args.cells
     k1, k2, beta, mu = 1.0, 1e-2, 1.0, 1.0
 
     if world > 1:

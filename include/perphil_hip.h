@@ -153,12 +153,28 @@ int pph_spmv(pph_ctx* ctx, int which, const double* x_host, double* y_host);
 /* `reps` back-to-back device SpMVs on resident vectors, average kernel ms via HIP events */
 int pph_spmv_bench(pph_ctx* ctx, int which, int reps, double* avg_ms);
 
+/* ---- multi-GPU communication hooks -------------------------------------------------------------
+ * replaces: PETSc's implicit VecScatter halo exchange and VecDot all-reduce under mpiexec (never run in
+ * the reference).  One context per rank holds one cell slab (pph_mesh_build with
+ * z_cell_begin/z_cell_count/ghost_lo/ghost_hi).  The library calls
+ *   halo(user, vec, plane_elems, send_lo, recv_lo, send_hi, recv_hi): offsets (in elements, -1 = no
+ *        neighbour) into the DEVICE vector `vec`: send [send_lo, +plane) to rank-1 and receive its
+ *        top owned plane into [recv_lo, +plane); likewise send_hi/recv_hi with rank+1.  The context
+ *        stream is idle when the callback runs; the callback returns when the data have arrived.
+ *   allreduce(user, vals, count): sum `count` HOST doubles over all ranks, in place.
+ * Both return 0 on success.  perphil_amd/distributed.py implements them over torch.distributed. */
+typedef int (*pph_halo_fn)(void* user, double* vec, int64_t plane_elems, int64_t send_lo, int64_t recv_lo,
+                           int64_t send_hi, int64_t recv_hi);
+typedef int (*pph_allreduce_fn)(void* user, double* vals, int64_t count);
+int pph_comm_set_callbacks(pph_ctx* ctx, int rank, int world, pph_halo_fn halo, pph_allreduce_fn allreduce,
+                           void* user);
+
 /* ---- stats ---------------------------------------------------------------------------------
  * replaces: PETSc -log_view event times scraped by reference src/perphil/experiments/petsc_profiling.py:302-447.
  * out[0] mesh+pattern ms, [1] K/M integration+scatter ms, [2] BC elimination/blocks ms, [3] last solve ms;
  * SpMV accounting of the last solve per kernel variant v (0: plain, 1: fused with the p.Ap dot):
  * out[4+3v] sum of per-launch durations in ms (0 unless option "time_spmv" is on), out[5+3v] launches,
- * out[6+3v] algorithmic bytes (12 nnz + 20 nrows per launch). */
+ * out[6+3v] algorithmic bytes (12 nnz + 20 nrows per launch); out[10] halo exchanges of the last solve. */
 int pph_get_timers(pph_ctx* ctx, double* out, int n);
 /* tuning / profiling switches (no reference counterpart): "spmv_lanes" (0 = automatic, 4..64 lanes per
  * CSR row), "time_spmv" (1: bracket every SpMV launch of a solve with a HIP event pair on the context

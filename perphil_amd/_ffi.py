@@ -32,8 +32,11 @@ EXPORTS = [
     "pph_set_dirichlet", "pph_assemble_dpp",
     "pph_solve", "pph_solve_device", "pph_get_solution",
     "pph_csr_sizes", "pph_get_csr", "pph_get_rhs", "pph_spmv", "pph_spmv_bench",
-    "pph_get_timers", "pph_set_option",
+    "pph_get_timers", "pph_set_option", "pph_comm_set_callbacks",
 ]
+
+HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
 
 
 class SolverCfg(C.Structure):
@@ -57,7 +60,35 @@ class SolveInfo(C.Structure):
     ]
 
 
+def _preload_hip_runtime() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm bundles its own libamdhip64.so / libhsa-runtime64.so
+    (same SONAMEs as /opt/rocm's, loaded by path): if this library binds the system copy first and torch
+    is imported later, two runtimes coexist and the second one finds no GPU.  So when torch is installed
+    and not yet imported, its copy is loaded first (RTLD_GLOBAL) and libperphil_hip.so resolves its
+    libamdhip64.so.7 dependency to it.  PERPHIL_HIP_RUNTIME=system skips this."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules or os.environ.get("PERPHIL_HIP_RUNTIME", "") == "system":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if not spec or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+            except OSError:
+                return
+
+
 def _load() -> C.CDLL:
+    _preload_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -87,6 +118,7 @@ def _load() -> C.CDLL:
         "pph_spmv_bench": ([p, C.c_int, C.c_int, f64p], C.c_int),
         "pph_get_timers": ([p, C.c_void_p, C.c_int], C.c_int),
         "pph_set_option": ([p, C.c_char_p, C.c_double], C.c_int),
+        "pph_comm_set_callbacks": ([p, C.c_int, C.c_int, HALO_FN, ALLREDUCE_FN, C.c_void_p], C.c_int),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = ABI mismatch: fail loudly
@@ -233,8 +265,9 @@ class Context:
         return ms.value
 
     def timers(self) -> dict:
-        t = np.zeros(10, dtype=np.float64)
-        self._check(lib.pph_get_timers(self._h, _ptr(t), 10))
+        t = np.zeros(11, dtype=np.float64)
+        self._check(lib.pph_get_timers(self._h, _ptr(t), 11))
         return {"mesh_ms": t[0], "assemble_ms": t[1], "bc_blocks_ms": t[2], "solve_ms": t[3],
                 "spmv_ms": t[4], "spmv_launches": int(t[5]), "spmv_bytes": t[6],
-                "spmv_dot_ms": t[7], "spmv_dot_launches": int(t[8]), "spmv_dot_bytes": t[9]}
+                "spmv_dot_ms": t[7], "spmv_dot_launches": int(t[8]), "spmv_dot_bytes": t[9],
+                "halo_exchanges": int(t[10])}

@@ -155,6 +155,8 @@ int pph_mesh_build(pph_ctx* ctx, int dim, int cell_kind, int nx, int ny, int nz,
   m.dim = dim; m.kind = cell_kind; m.nx = nx; m.ny = ny; m.nz = nz; m.z0 = z_cell_begin; m.nzl = z_cell_count;
   ctx->ghost_lo = ghost_lo ? 1 : 0;
   ctx->ghost_hi = ghost_hi ? 1 : 0;
+  m.glo = ctx->ghost_lo;
+  m.ghi = ctx->ghost_hi;
   PPH_TRY(pph_launch_mesh(ctx, m));
   ctx->n = m.n;
   ctx->nnzb = m.nnzb;
@@ -405,13 +407,27 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
   return PPH_ERR_INVALID;
 }
 
+int pph_comm_set_callbacks(pph_ctx* ctx, int rank, int world, pph_halo_fn halo, pph_allreduce_fn allreduce,
+                           void* user) {
+  if (!ctx) return PPH_ERR_INVALID;
+  PPH_REQUIRE(ctx, world >= 1 && rank >= 0 && rank < world, "rank %d outside world %d", rank, world);
+  PPH_REQUIRE(ctx, world == 1 || (halo && allreduce), "multi-rank contexts need both callbacks");
+  ctx->rank = rank;
+  ctx->world = world;
+  ctx->halo_cb = halo;
+  ctx->allreduce_cb = allreduce;
+  ctx->comm_user = user;
+  mg_release(ctx);
+  return PPH_OK;
+}
+
 int pph_get_timers(pph_ctx* ctx, double* out, int n) {
   if (!ctx || !out) return PPH_ERR_INVALID;
   la_harvest_spmv_times(ctx);
-  const double v[10] = {ctx->t_mesh, ctx->t_asm, ctx->t_bc, ctx->t_solve,
+  const double v[11] = {ctx->t_mesh, ctx->t_asm, ctx->t_bc, ctx->t_solve,
                         ctx->t_spmv[0], (double)ctx->n_spmv[0], ctx->spmv_bytes[0],
-                        ctx->t_spmv[1], (double)ctx->n_spmv[1], ctx->spmv_bytes[1]};
-  for (int i = 0; i < n && i < 10; ++i) out[i] = v[i];
+                        ctx->t_spmv[1], (double)ctx->n_spmv[1], ctx->spmv_bytes[1], (double)ctx->n_halo};
+  for (int i = 0; i < n && i < 11; ++i) out[i] = v[i];
   return PPH_OK;
 }
 

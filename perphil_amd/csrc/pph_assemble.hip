@@ -366,8 +366,9 @@ __global__ __launch_bounds__(256) void k_blocks(const int64_t* __restrict__ rowp
       const double kk = K[k], mm = M[k];
       const bool diag = (j == (int32_t)row);
       const bool c1 = (m1[j] & 1) != 0, c2 = (m2[j] & 1) != 0;
-      A11[k] = (r1 != 0) ? (diag ? 1.0 : 0.0) : (c1 ? 0.0 : a * kk + b * mm);
-      A22[k] = (r2 != 0) ? (diag ? 1.0 : 0.0) : (c2 ? 0.0 : c * kk + b * mm);
+      // ghost rows (bit 1) belong to the neighbouring slab: empty here; Dirichlet rows: identity
+      A11[k] = (r1 & 2) ? 0.0 : (r1 & 1) ? (diag ? 1.0 : 0.0) : (c1 ? 0.0 : a * kk + b * mm);
+      A22[k] = (r2 & 2) ? 0.0 : (r2 & 1) ? (diag ? 1.0 : 0.0) : (c2 ? 0.0 : c * kk + b * mm);
       A12[k] = (r1 != 0 || c2) ? 0.0 : -b * mm;
       A21[k] = (r2 != 0 || c1) ? 0.0 : -b * mm;
     }
@@ -452,7 +453,7 @@ __global__ __launch_bounds__(256) void k_scalar_block(const int64_t* __restrict_
     for (int64_t k = rowptr[row] + sub; k < rowptr[row + 1]; k += BC_LANES) {
       const int32_t j = col[k];
       const bool diag = (j == (int32_t)row);
-      out[k] = (r != 0) ? (diag ? 1.0 : 0.0) : (((mask[j] & 1) != 0) ? 0.0 : coefK * K[k] + coefM * M[k]);
+      out[k] = (r & 2) ? 0.0 : (r & 1) ? (diag ? 1.0 : 0.0) : (((mask[j] & 1) != 0) ? 0.0 : coefK * K[k] + coefM * M[k]);
     }
   }
 }

@@ -49,12 +49,14 @@ struct DevBuf {
   void release();
 };
 
+struct MeshData;
 struct Csr {  // device CSR view (no ownership)
   const int64_t* rowptr = nullptr;
   const int32_t* col = nullptr;
   const double* val = nullptr;
   int64_t nrows = 0;
   int64_t nnz = 0;
+  const MeshData* geom = nullptr;  // slab geometry of the rows (halo exchange of x before the product); may be null
   int lanes = 8;    // lanes per row used by the CSR-vector SpMV kernel
   int max_row = 0;  // longest row (0: unknown) - selects the CSR-stream kernel geometry
 };
@@ -64,6 +66,7 @@ struct MeshData {
   int dim = 0, kind = -1, m = 0;        // m = nodes per cell
   int nx = 0, ny = 0, nz = 0;           // global cells of this level
   int z0 = 0, nzl = 0;                  // local slab: first cell layer, layer count
+  int glo = 0, ghi = 0;                 // lowest / highest local node plane is a ghost plane (owned by a neighbour)
   int px = 0, py = 0, pzl = 0;          // local node dims
   int64_t n = 0, ncell = 0, nnzb = 0;   // nodes, cells, nnz of one scalar block
   int max_row = 0;                      // stencil size = longest row of the scalar pattern
@@ -72,6 +75,9 @@ struct MeshData {
   DevBuf<int64_t> rowptr;               // scalar CSR pattern
   DevBuf<int32_t> col;
   DevBuf<double> K, M;                  // scalar stiffness / mass values
+  int64_t plane() const { return (int64_t)px * py; }
+  int64_t own_begin() const { return glo ? plane() : 0; }           // owned entries = [own_begin, own_end)
+  int64_t own_end() const { return n - (ghi ? plane() : 0); }
   void release_geometry() { cx.release(); cy.release(); cz.release(); cells.release(); K.release(); M.release(); }
   void release_all() { release_geometry(); rowptr.release(); col.release(); }
 };
@@ -89,6 +95,10 @@ struct MgLevel {
   DevBuf<uint8_t> mask[2];       // per field: non-zero where the dof is constrained
   const uint8_t* maskp[2] = {nullptr, nullptr};
   DevBuf<double> x, b, r, d, t, w;  // work vectors of the V-cycle (x, b unused on level 0)
+  const MeshData* geom = nullptr;  // slab geometry of this level (level 0: the context's mesh)
+  bool replicated = false;       // level holds the whole (global) coarse mesh on every rank
+  int gz0 = 0;                   // global index of local node plane 0
+  int own_lo = 0, own_hi = 0;    // owned global node planes [own_lo, own_hi)
   double lam[2] = {0, 0};        // upper bound of the spectrum of D^-1 A
 };
 
@@ -111,6 +121,16 @@ struct pph_ctx {
   DevBuf<int32_t> mcol;
   DevBuf<double> mval;
   double a = 0, b = 0, c = 0;           // k1/mu, beta/mu, k2/mu
+
+  // multi-GPU: cell-slab decomposition along z; communication goes through two callbacks so that the
+  // same solver code runs over torch.distributed (gloo in tests, nccl = RCCL on the 8-GPU node)
+  int rank = 0, world = 1;
+  pph_halo_fn halo_cb = nullptr;
+  pph_allreduce_fn allreduce_cb = nullptr;
+  void* comm_user = nullptr;
+  std::vector<double> h_stage;          // host staging for vector all-reduces
+  bool comm_suspended = false;          // true while working on replicated (non-distributed) coarse levels
+  int64_t n_halo = 0;                   // halo exchanges of the last solve
 
   // solver workspace
   DevBuf<double> scal;                  // device scalars / reduction partials
@@ -175,10 +195,14 @@ void la_dot2(pph_ctx* ctx, const double* x, const double* y, const double* z, in
 // fused CG update with Jacobi-type PC: x += alpha p; r -= alpha q; z = dinv.*r (dinv may be null: z=r);
 // scal[slot] = r.z, scal[slot+1] = z.z
 void la_cg_update(pph_ctx* ctx, double* x, double* r, double* z, const double* p, const double* q,
-                  const double* dinv, double alpha, int64_t n, int slot);
+                  const double* dinv, double alpha, int64_t n, int slot, int64_t own_begin = 0, int64_t own_end = -1);
 void la_extract_diag_inv(pph_ctx* ctx, const Csr& A, double* dinv);
 // fetch `count` reduction results starting at slot into ctx->h_scal (synchronises the stream)
 int la_fetch(pph_ctx* ctx, int slot, int count);
+// ghost planes of v <- owner's values (no-op without neighbours / communicator)
+int la_halo(pph_ctx* ctx, const MeshData& g, double* v);
+// element-wise sum over all ranks of a device vector (small coarse-level vectors)
+int la_allreduce_vec(pph_ctx* ctx, double* v, int64_t n);
 // adds the elapsed times of all event pairs recorded since the last call to ctx->t_spmv (synchronises)
 void la_harvest_spmv_times(pph_ctx* ctx);
 void la_reset_spmv_stats(pph_ctx* ctx);

@@ -404,6 +404,7 @@ static int stream_T(int max_row) {
 template <bool DOT>
 static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const double* bvec, double* y, double* part) {
   const int variant = DOT ? 1 : 0;
+  if (A.geom) (void)la_halo(ctx, *A.geom, const_cast<double*>(x));  // ghost planes of x <- owners (slabs only)
   pph_ctx::EvPair* ev = nullptr;
   if (ctx->time_spmv) {
     if (ctx->ev_used == ctx->ev_pool.size()) {
@@ -699,7 +700,8 @@ void la_maxpy(pph_ctx* ctx, double* x, const double* V, int64_t ld, int k, const
 __global__ __launch_bounds__(256) void k_cg_update(double* __restrict__ x, double* __restrict__ r,
                                                    double* __restrict__ z, const double* __restrict__ p,
                                                    const double* __restrict__ q, const double* __restrict__ dinv,
-                                                   double alpha, int64_t n, double* __restrict__ part) {
+                                                   double alpha, int64_t n, int64_t ob, int64_t oe,
+                                                   double* __restrict__ part) {
   __shared__ double lds[4];
   double a = 0.0, b = 0.0;
   EW_LOOP(i, n) {
@@ -708,8 +710,10 @@ __global__ __launch_bounds__(256) void k_cg_update(double* __restrict__ x, doubl
     r[i] = ri;
     const double zi = dinv ? dinv[i] * ri : ri;
     z[i] = zi;
-    a += ri * zi;
-    b += zi * zi;
+    if (i >= ob && i < oe) {  // reductions over owned entries only (ghost planes belong to a neighbour)
+      a += ri * zi;
+      b += zi * zi;
+    }
   }
   a = block_sum(a, lds);
   b = block_sum(b, lds);
@@ -720,11 +724,12 @@ __global__ __launch_bounds__(256) void k_cg_update(double* __restrict__ x, doubl
 }
 
 void la_cg_update(pph_ctx* ctx, double* x, double* r, double* z, const double* p, const double* q,
-                  const double* dinv, double alpha, int64_t n, int slot) {
+                  const double* dinv, double alpha, int64_t n, int slot, int64_t ob, int64_t oe) {
+  if (oe < 0) { ob = 0; oe = n; }
   double* part = partials(ctx);
   int grid = ew_grid(n);
   if (grid > RED_BLOCKS) grid = RED_BLOCKS;
-  hipLaunchKernelGGL(k_cg_update, dim3(grid), dim3(256), 0, ctx->stream, x, r, z, p, q, dinv, alpha, n, part);
+  hipLaunchKernelGGL(k_cg_update, dim3(grid), dim3(256), 0, ctx->stream, x, r, z, p, q, dinv, alpha, n, ob, oe, part);
   hipLaunchKernelGGL(k_reduce_final, dim3(2), dim3(256), 0, ctx->stream, part, grid, ctx->scal.p + slot);
 }
 
@@ -749,6 +754,40 @@ void la_extract_diag_inv(pph_ctx* ctx, const Csr& A, double* dinv) {
 int la_fetch(pph_ctx* ctx, int slot, int count) {
   PPH_HIP(ctx, hipMemcpyAsync(ctx->h_scal + slot, ctx->scal.p + slot, sizeof(double) * (size_t)count,
                               hipMemcpyDeviceToHost, ctx->stream));
+  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->allreduce_cb && ctx->world > 1 && !ctx->comm_suspended) {
+    if (ctx->allreduce_cb(ctx->comm_user, ctx->h_scal + slot, (int64_t)count) != 0) {
+      pph_set_error(ctx, "all-reduce callback failed");
+      return PPH_ERR_COMM;
+    }
+  }
+  return PPH_OK;
+}
+
+int la_halo(pph_ctx* ctx, const MeshData& g, double* v) {
+  if (!ctx->halo_cb || ctx->world <= 1 || (!g.glo && !g.ghi)) return PPH_OK;
+  const int64_t pl = g.plane();
+  const int64_t send_lo = g.glo ? pl : -1, recv_lo = g.glo ? 0 : -1;
+  const int64_t send_hi = g.ghi ? g.n - 2 * pl : -1, recv_hi = g.ghi ? g.n - pl : -1;
+  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->halo_cb(ctx->comm_user, v, pl, send_lo, recv_lo, send_hi, recv_hi) != 0) {
+    pph_set_error(ctx, "halo-exchange callback failed");
+    return PPH_ERR_COMM;
+  }
+  ctx->n_halo++;
+  return PPH_OK;
+}
+
+int la_allreduce_vec(pph_ctx* ctx, double* v, int64_t n) {
+  if (!ctx->allreduce_cb || ctx->world <= 1) return PPH_OK;
+  ctx->h_stage.resize((size_t)n);
+  PPH_HIP(ctx, hipMemcpyAsync(ctx->h_stage.data(), v, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->allreduce_cb(ctx->comm_user, ctx->h_stage.data(), n) != 0) {
+    pph_set_error(ctx, "all-reduce callback failed");
+    return PPH_ERR_COMM;
+  }
+  PPH_HIP(ctx, hipMemcpyAsync(v, ctx->h_stage.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return PPH_OK;
 }

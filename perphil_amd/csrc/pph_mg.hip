@@ -50,33 +50,55 @@ static TStencil make_transfer_stencil(int kind) {
 #define NODE_LOOP(id, n) \
   for (int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; id < (n); id += (int64_t)gridDim.x * blockDim.x)
 
-__global__ void k_inject_mask(uint8_t* __restrict__ mc, const uint8_t* __restrict__ mf, int pxc, int pyc, int pzc,
-                              int pxf, int pyf) {
-  const int64_t nc = (int64_t)pxc * pyc * pzc;
+// Level geometry for the transfers: local node dims and the GLOBAL index of local node plane 0, so that
+// slabs (local boxes with ghost planes) and replicated coarse levels use the same kernels:
+// global fine plane = gzf + kf, global coarse plane = gzc + kc, and fine = 2 * coarse + d.
+struct TGeom {
+  int pxc, pyc, pzc, gzc;
+  int pxf, pyf, pzf, gzf;
+  int own_lo_f, own_hi_f;  // owned global fine planes [lo, hi): a coarse plane K is assigned to this rank iff 2K is owned
+};
+
+// coarse mask <- fine mask at the coinciding node (0 where the fine node is not in the local box or the
+// coarse plane is not assigned to this rank; ghost planes are completed by a halo exchange afterwards)
+__global__ void k_inject_mask(double* __restrict__ mc, const uint8_t* __restrict__ mf, TGeom g) {
+  const int64_t nc = (int64_t)g.pxc * g.pyc * g.pzc;
   NODE_LOOP(id, nc) {
-    const int I = (int)(id % pxc);
-    const int64_t t = id / pxc;
-    const int J = (int)(t % pyc), K = (int)(t / pyc);
-    mc[id] = mf[2 * I + (int64_t)pxf * (2 * J + (int64_t)pyf * (2 * K))];
+    const int I = (int)(id % g.pxc);
+    const int64_t t = id / g.pxc;
+    const int J = (int)(t % g.pyc), K = (int)(t / g.pyc) + g.gzc;
+    const int kf = 2 * K - g.gzf;
+    double v = 0.0;
+    if (2 * K >= g.own_lo_f && 2 * K < g.own_hi_f && kf >= 0 && kf < g.pzf)
+      v = (double)(mf[2 * I + (int64_t)g.pxf * (2 * J + (int64_t)g.pyf * kf)] & 1);
+    mc[id] = v;
   }
 }
 
-// b_c[C] = sum_d w_d r_f[2C + d]   (0 on constrained coarse dofs)
+__global__ void k_mask_from_double(uint8_t* __restrict__ m, const double* __restrict__ v, int64_t n, int64_t plane,
+                                   int glo, int ghi) {
+  NODE_LOOP(id, n) {
+    uint8_t b = (v[id] != 0.0) ? 1 : 0;
+    if ((glo && id < plane) || (ghi && id >= n - plane)) b |= 2;
+    m[id] = b;
+  }
+}
+
+// b_c[C] = sum_d w_d r_f[2C + d]   (0 on constrained coarse dofs and on coarse planes of other ranks)
 __global__ void k_restrict(double* __restrict__ bc, const double* __restrict__ rf, TStencil st,
-                           const uint8_t* __restrict__ mc, const uint8_t* __restrict__ mf, int pxc, int pyc, int pzc,
-                           int pxf, int pyf, int pzf) {
-  const int64_t nc = (int64_t)pxc * pyc * pzc;
+                           const uint8_t* __restrict__ mc, const uint8_t* __restrict__ mf, TGeom g) {
+  const int64_t nc = (int64_t)g.pxc * g.pyc * g.pzc;
   NODE_LOOP(id, nc) {
-    const int I = (int)(id % pxc);
-    const int64_t t = id / pxc;
-    const int J = (int)(t % pyc), K = (int)(t / pyc);
+    const int I = (int)(id % g.pxc);
+    const int64_t t = id / g.pxc;
+    const int J = (int)(t % g.pyc), K = (int)(t / g.pyc) + g.gzc;
     double s = 0.0;
-    if (mc[id] == 0) {
+    if (mc[id] == 0 && 2 * K >= g.own_lo_f && 2 * K < g.own_hi_f) {
       for (int q = 0; q < st.count; ++q) {
-        const int i = 2 * I + st.d[q][0], j = 2 * J + st.d[q][1], k = 2 * K + st.d[q][2];
-        if (i >= 0 && i < pxf && j >= 0 && j < pyf && k >= 0 && k < pzf) {
-          const int64_t f = i + (int64_t)pxf * (j + (int64_t)pyf * k);
-          if (mf[f] == 0) s += st.w[q] * rf[f];
+        const int i = 2 * I + st.d[q][0], j = 2 * J + st.d[q][1], k = 2 * K + st.d[q][2] - g.gzf;
+        if (i >= 0 && i < g.pxf && j >= 0 && j < g.pyf && k >= 0 && k < g.pzf) {
+          const int64_t f = i + (int64_t)g.pxf * (j + (int64_t)g.pyf * k);
+          if ((mf[f] & 1) == 0) s += st.w[q] * rf[f];  // ghost fine entries hold the owner's residual
         }
       }
     }
@@ -85,39 +107,33 @@ __global__ void k_restrict(double* __restrict__ bc, const double* __restrict__ r
 }
 
 // x_f[f] += (P x_c)[f]   (constrained fine dofs untouched).  Closed form of the transpose of k_restrict:
-// a fine node f = 2c + o (o = parity vector) interpolates
+// a fine node f = 2c + o (o = parity vector of the GLOBAL index) interpolates
 //   Q1 (TK 0)         : the 2^|o| coarse nodes c + s, s <= o component-wise, weight 2^-|o|
 //   Kuhn P1 (TK 1)    : 1/2 (x_c[c] + x_c[c + o])                         (o != 0)
 //   left-diag P1 (TK 2): o = (1,1): 1/2 (x_c[c + x] + x_c[c + y]), else as Kuhn
 template <int TK>
 __global__ __launch_bounds__(256) void k_prolong_add(double* __restrict__ xf, const double* __restrict__ xc,
-                                                     const uint8_t* __restrict__ mf, int pxc, int pyc, int pxf,
-                                                     int pyf, int pzf) {
-  const int64_t nf = (int64_t)pxf * pyf * pzf;
+                                                     const uint8_t* __restrict__ mf, TGeom g) {
+  const int64_t nf = (int64_t)g.pxf * g.pyf * g.pzf;
   NODE_LOOP(id, nf) {
     if (mf[id] != 0) continue;
-    const int i = (int)(id % pxf);
-    const int64_t t = id / pxf;
-    const int j = (int)(t % pyf), k = (int)(t / pyf);
-    const int ox = i & 1, oy = j & 1, oz = k & 1;
-    const int64_t sx = 1, sy = pxc, sz = (int64_t)pxc * pyc;
-    const int64_t c = (i >> 1) + sy * (j >> 1) + sz * (k >> 1);
+    const int i = (int)(id % g.pxf);
+    const int64_t t = id / g.pxf;
+    const int j = (int)(t % g.pyf), kg = (int)(t / g.pyf) + g.gzf;
+    const int ox = i & 1, oy = j & 1, oz = kg & 1;
+    const int64_t sx = 1, sy = g.pxc, sz = (int64_t)g.pxc * g.pyc;
+    const int64_t c = (i >> 1) + sy * (j >> 1) + sz * ((kg >> 1) - g.gzc);
     double s;
     if (TK == 0) {
-      // tensor product of 1D interpolations
       double a0 = xc[c], a1 = ox ? xc[c + sx] : a0;
-      double v00 = 0.5 * (a0 + a1);
-      if (!(oy | oz)) {
-        s = v00;
-      } else {
-        double v10 = v00, v01 = v00, v11 = v00;
-        if (oy) { a0 = xc[c + sy]; a1 = ox ? xc[c + sy + sx] : a0; v10 = 0.5 * (a0 + a1); }
-        if (oz) { a0 = xc[c + sz]; a1 = ox ? xc[c + sz + sx] : a0; v01 = 0.5 * (a0 + a1); }
-        if (oy && oz) { a0 = xc[c + sy + sz]; a1 = ox ? xc[c + sy + sz + sx] : a0; v11 = 0.5 * (a0 + a1); }
-        else v11 = oy ? v10 : v01;
-        if (oy && oz) s = 0.25 * (v00 + v10 + v01 + v11);
-        else s = 0.5 * (v00 + (oy ? v10 : v01));
-      }
+      const double v00 = 0.5 * (a0 + a1);
+      double v10 = v00, v01 = v00, v11 = v00;
+      if (oy) { a0 = xc[c + sy]; a1 = ox ? xc[c + sy + sx] : a0; v10 = 0.5 * (a0 + a1); }
+      if (oz) { a0 = xc[c + sz]; a1 = ox ? xc[c + sz + sx] : a0; v01 = 0.5 * (a0 + a1); }
+      if (oy && oz) { a0 = xc[c + sy + sz]; a1 = ox ? xc[c + sy + sz + sx] : a0; v11 = 0.5 * (a0 + a1); }
+      if (oy && oz) s = 0.25 * (v00 + v10 + v01 + v11);
+      else if (oy | oz) s = 0.5 * (v00 + (oy ? v10 : v01));
+      else s = v00;
     } else {
       const int64_t o = ox * sx + oy * sy + oz * sz;
       if (TK == 2 && ox && oy) s = 0.5 * (xc[c + sx] + xc[c + sy]);
@@ -185,8 +201,17 @@ static Csr level_csr(const pph_ctx* ctx, const MgLevel& L, int which) {
   Csr A;
   A.rowptr = L.rowptr; A.col = L.col; A.val = L.val[which]; A.nrows = L.n; A.nnz = L.nnz;
   A.max_row = ctx->mesh.max_row;
+  A.geom = (ctx->world > 1 && !L.replicated) ? L.geom : nullptr;
   A.lanes = pph_pick_lanes(ctx, A.nnz, A.nrows);
   return A;
+}
+
+static TGeom tgeom(const MgLevel& F, const MgLevel& C) {
+  TGeom g;
+  g.pxc = C.px; g.pyc = C.py; g.pzc = C.pz; g.gzc = C.gz0;
+  g.pxf = F.px; g.pyf = F.py; g.pzf = F.pz; g.gzf = F.gz0;
+  g.own_lo_f = F.own_lo; g.own_hi_f = F.own_hi;
+  return g;
 }
 
 void mg_release(pph_ctx* ctx) {
@@ -200,43 +225,99 @@ void mg_release(pph_ctx* ctx) {
   ctx->mg_ok = false;
 }
 
+// minimum of one integer per rank (collective); identity on a single rank
+static int comm_min_int(pph_ctx* ctx, int v, int* out) {
+  *out = v;
+  if (ctx->world <= 1 || !ctx->allreduce_cb) return PPH_OK;
+  std::vector<double> buf((size_t)ctx->world, 0.0);
+  buf[(size_t)ctx->rank] = (double)v;
+  if (ctx->allreduce_cb(ctx->comm_user, buf.data(), (int64_t)ctx->world) != 0) {
+    pph_set_error(ctx, "all-reduce callback failed");
+    return PPH_ERR_COMM;
+  }
+  double m = buf[0];
+  for (double b : buf) m = b < m ? b : m;
+  *out = (int)m;
+  return PPH_OK;
+}
+
+static int comm_max_double(pph_ctx* ctx, double v, double* out) {
+  *out = v;
+  if (ctx->world <= 1 || !ctx->allreduce_cb) return PPH_OK;
+  std::vector<double> buf((size_t)ctx->world, 0.0);
+  buf[(size_t)ctx->rank] = v;
+  if (ctx->allreduce_cb(ctx->comm_user, buf.data(), (int64_t)ctx->world) != 0) {
+    pph_set_error(ctx, "all-reduce callback failed");
+    return PPH_ERR_COMM;
+  }
+  double m = buf[0];
+  for (double b : buf) m = b > m ? b : m;
+  *out = m;
+  return PPH_OK;
+}
+
+// Hierarchy.  Single GPU: levels nx/2^l while every direction stays even with >= 2 cells.  Slabs: the
+// same global hierarchy; level l is DISTRIBUTED (each rank a sub-slab with ghost planes) while the owned
+// cell range of every rank is divisible by 2^l and keeps >= 2 layers, and REPLICATED (whole coarse mesh on
+// every rank, right-hand side summed by one all-reduce) below that, so the cycle equals the 1-GPU one.
 int mg_setup(pph_ctx* ctx) {
   if (ctx->mg_ok) return PPH_OK;
   mg_release(ctx);
   const MeshData& fm = ctx->mesh;
-  PPH_REQUIRE(ctx, ctx->ghost_lo == 0 && ctx->ghost_hi == 0, "multigrid on slab-decomposed meshes is not available");
-  // count levels: halve while every direction stays even and keeps >= 2 cells
+  const bool dist = ctx->world > 1;
+  PPH_REQUIRE(ctx, !dist || fm.dim == 3, "slab decomposition needs a 3D mesh");
   int nlev = 1;
   {
-    int nx = fm.nx, ny = fm.ny, nz = fm.nzl;
+    int nx = fm.nx, ny = fm.ny, nz = (fm.dim == 3) ? fm.nz : 0;
     while (nx % 2 == 0 && ny % 2 == 0 && (fm.dim == 2 || nz % 2 == 0) && nx / 2 >= 2 && ny / 2 >= 2 &&
            (fm.dim == 2 || nz / 2 >= 2)) {
       nx /= 2; ny /= 2; nz /= 2; nlev++;
     }
   }
+  // owned cell layers [c0, c1) of this rank (the local box has one extra layer below when glo)
+  const int c0 = fm.z0 + fm.glo, c1 = fm.z0 + fm.nzl;
+  int ndist = nlev;  // levels [0, ndist) are distributed
+  if (dist) {
+    int l = 0;
+    while (l + 1 < nlev && (c0 % (2 << l)) == 0 && (c1 % (2 << l)) == 0 && ((c1 - c0) >> (l + 1)) >= 2) ++l;
+    PPH_TRY(comm_min_int(ctx, l + 1, &ndist));
+  }
   ctx->mg.resize(nlev);
   DevBuf<unsigned long long> lamdev;
+  DevBuf<double> mtmp;
   PPH_TRY(lamdev.alloc(ctx, 2));
   const double coefK[2] = {ctx->a, ctx->c};
   for (int l = 0; l < nlev; ++l) {
     MgLevel& L = ctx->mg[l];
+    L.replicated = dist && l >= ndist;
     if (l == 0) {
       L.rowptr = fm.rowptr.p; L.col = fm.col.p; L.val[0] = ctx->A11.p; L.val[1] = ctx->A22.p;
       L.n = fm.n; L.nnz = fm.nnzb; L.px = fm.px; L.py = fm.py; L.pz = fm.pzl;
       L.maskp[0] = ctx->bcmask[0].p; L.maskp[1] = ctx->bcmask[1].p;
+      L.geom = &ctx->mesh;
     } else {
       const MgLevel& F = ctx->mg[l - 1];
       MeshData& m = L.mesh;
       m.dim = fm.dim; m.kind = fm.kind;
       m.nx = fm.nx >> l; m.ny = fm.ny >> l; m.nz = (fm.dim == 3) ? (fm.nz >> l) : 0;
-      m.z0 = 0; m.nzl = (fm.dim == 3) ? (fm.nzl >> l) : 0;
+      if (fm.dim == 2) { m.z0 = 0; m.nzl = 0; m.glo = m.ghi = 0; }
+      else if (L.replicated || !dist) { m.z0 = 0; m.nzl = m.nz; m.glo = m.ghi = 0; }
+      else { m.glo = fm.glo; m.ghi = fm.ghi; m.z0 = (c0 >> l) - m.glo; m.nzl = (c1 >> l) - m.z0; }
       PPH_TRY(pph_launch_mesh(ctx, m));
       PPH_TRY(pph_launch_assemble_KM(ctx, m));
       L.rowptr = m.rowptr.p; L.col = m.col.p; L.n = m.n; L.nnz = m.nnzb; L.px = m.px; L.py = m.py; L.pz = m.pzl;
+      L.geom = &L.mesh;
+      L.gz0 = m.z0;
+      L.own_lo = m.z0 + m.glo; L.own_hi = m.z0 + m.pzl - m.ghi;
+      const TGeom tg = tgeom(F, L);
+      PPH_TRY(mtmp.alloc(ctx, (size_t)L.n));
       for (int f = 0; f < 2; ++f) {
         PPH_TRY(L.mask[f].alloc(ctx, (size_t)L.n));
-        hipLaunchKernelGGL(k_inject_mask, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, L.mask[f].p, F.maskp[f], L.px,
-                           L.py, L.pz, F.px, F.py);
+        hipLaunchKernelGGL(k_inject_mask, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, mtmp.p, F.maskp[f], tg);
+        if (L.replicated && !F.replicated) PPH_TRY(la_allreduce_vec(ctx, mtmp.p, L.n));
+        else if (dist && !L.replicated) PPH_TRY(la_halo(ctx, m, mtmp.p));
+        hipLaunchKernelGGL(k_mask_from_double, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, L.mask[f].p, mtmp.p, L.n,
+                           m.plane(), m.glo, m.ghi);
         L.maskp[f] = L.mask[f].p;
         PPH_TRY(L.own_val[f].alloc(ctx, (size_t)L.nnz));
         pph_launch_scalar_block(ctx, m, L.maskp[f], coefK[f], ctx->b, L.own_val[f].p);
@@ -244,6 +325,13 @@ int mg_setup(pph_ctx* ctx) {
       }
       PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
       m.release_geometry();
+    }
+    if (l == 0) {
+      L.gz0 = fm.z0;
+      L.own_lo = fm.z0 + fm.glo; L.own_hi = fm.z0 + fm.pzl - fm.ghi;
+      if (fm.dim == 2) { L.gz0 = 0; L.own_lo = 0; L.own_hi = 1; }
+    } else if (fm.dim == 2) {
+      L.gz0 = 0; L.own_lo = 0; L.own_hi = 1;
     }
     for (int f = 0; f < 2; ++f) {
       PPH_TRY(L.dinv[f].alloc(ctx, (size_t)L.n));
@@ -259,6 +347,7 @@ int mg_setup(pph_ctx* ctx) {
     for (int f = 0; f < 2; ++f) {
       double v;
       memcpy(&v, &bits[f], sizeof(double));
+      if (dist && !L.replicated) PPH_TRY(comm_max_double(ctx, v, &v));
       L.lam[f] = v;
       PPH_REQUIRE(ctx, v > 0.0 && v == v, "multigrid level %d: bad spectral bound %g", l, v);
     }
@@ -269,6 +358,7 @@ int mg_setup(pph_ctx* ctx) {
     if (l == nlev - 1) PPH_TRY(L.w.alloc(ctx, (size_t)L.n));
   }
   lamdev.release();
+  mtmp.release();
   PPH_HIP(ctx, hipGetLastError());
   ctx->mg_ok = true;
   return PPH_OK;
@@ -303,6 +393,7 @@ void mg_vcycle(pph_ctx* ctx, int which, const double* rin, double* zout, int nsm
   std::vector<MgLevel>& mg = ctx->mg;
   const int nlev = (int)mg.size();
   const TStencil st = make_transfer_stencil(ctx->mesh.kind);
+  const bool dist = ctx->world > 1;
   if (nlev == 1) {
     // mesh cannot be coarsened: polynomial (Chebyshev) preconditioner only
     chebyshev(ctx, mg[0], which, rin, zout, nsmooth > 2 ? nsmooth : 2, true);
@@ -314,15 +405,19 @@ void mg_vcycle(pph_ctx* ctx, int which, const double* rin, double* zout, int nsm
     MgLevel& C = mg[l + 1];
     const double* b = (l == 0) ? rin : L.b.p;
     double* x = (l == 0) ? zout : L.x.p;
+    ctx->comm_suspended = L.replicated;
     chebyshev(ctx, L, which, b, x, nsmooth, true);
     la_spmv_resid(ctx, level_csr(ctx, L, which), x, b, L.r.p);
+    if (dist && !L.replicated) (void)la_halo(ctx, *L.geom, L.r.p);  // restriction reads one fine plane beyond the owned ones
     hipLaunchKernelGGL(k_restrict, dim3(mg_grid(C.n)), dim3(256), 0, ctx->stream, C.b.p, L.r.p, st, C.maskp[which],
-                       L.maskp[which], C.px, C.py, C.pz, L.px, L.py, L.pz);
+                       L.maskp[which], tgeom(L, C));
+    if (dist && C.replicated && !L.replicated) (void)la_allreduce_vec(ctx, C.b.p, C.n);
   }
   // coarsest level: Jacobi-CG to 1e-12 (a handful of unknowns)
   {
     MgLevel& C = mg[nlev - 1];
     int its = 0;
+    ctx->comm_suspended = C.replicated;
     pph_cg_jacobi(ctx, level_csr(ctx, C, which), C.b.p, C.x.p, C.dinv[which].p, 1e-12, 0.0, 500, C.r.p, C.d.p, C.t.p,
                   C.w.p, &its);
   }
@@ -332,16 +427,17 @@ void mg_vcycle(pph_ctx* ctx, int which, const double* rin, double* zout, int nsm
     MgLevel& C = mg[l + 1];
     const double* b = (l == 0) ? rin : L.b.p;
     double* x = (l == 0) ? zout : L.x.p;
+    ctx->comm_suspended = L.replicated;
+    if (dist && !C.replicated) (void)la_halo(ctx, *C.geom, C.x.p);  // interpolation reads the coarse ghost plane
+    const TGeom tg = tgeom(L, C);
     const int kind = ctx->mesh.kind;
     if (kind == PPH_CELL_QUAD || kind == PPH_CELL_HEX)
-      hipLaunchKernelGGL(k_prolong_add<0>, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, x, C.x.p, L.maskp[which], C.px,
-                         C.py, L.px, L.py, L.pz);
+      hipLaunchKernelGGL(k_prolong_add<0>, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, x, C.x.p, L.maskp[which], tg);
     else if (kind == PPH_CELL_TET)
-      hipLaunchKernelGGL(k_prolong_add<1>, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, x, C.x.p, L.maskp[which], C.px,
-                         C.py, L.px, L.py, L.pz);
+      hipLaunchKernelGGL(k_prolong_add<1>, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, x, C.x.p, L.maskp[which], tg);
     else
-      hipLaunchKernelGGL(k_prolong_add<2>, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, x, C.x.p, L.maskp[which], C.px,
-                         C.py, L.px, L.py, L.pz);
+      hipLaunchKernelGGL(k_prolong_add<2>, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, x, C.x.p, L.maskp[which], tg);
     chebyshev(ctx, L, which, b, x, nsmooth, false);
   }
+  ctx->comm_suspended = false;
 }

@@ -49,6 +49,7 @@ static Csr block_csr(pph_ctx* ctx, const double* val) {
   Csr A;
   A.rowptr = ctx->mesh.rowptr.p; A.col = ctx->mesh.col.p; A.val = val; A.nrows = ctx->n; A.nnz = ctx->nnzb;
   A.max_row = ctx->mesh.max_row;
+  A.geom = (ctx->world > 1) ? &ctx->mesh : nullptr;
   A.lanes = pph_pick_lanes(ctx, A.nnz, A.nrows);
   return A;
 }
@@ -70,6 +71,10 @@ static int cg_solve(pph_ctx* ctx, const Csr& A, const double* b, double* x, cons
                     double rtol, double atol, int max_it, bool warm, double* r, double* z, double* p, double* q,
                     int slot, KspOut* out, double* hist, int hist_cap, double bnorm_hint = -1.0) {
   const int64_t n = A.nrows;
+  // reductions run over the owned entries of a slab (whole vector on a single GPU)
+  const int64_t ob = A.geom ? A.geom->own_begin() : 0;
+  const int64_t oe = A.geom ? A.geom->own_end() : n;
+  const int64_t on = oe - ob;
   const bool fused = (dinv != nullptr) || !pc;
   auto apply_pc = [&](const double* in, double* o) {
     if (dinv) la_pointwise_mult(ctx, o, dinv, in, n);
@@ -85,7 +90,7 @@ static int cg_solve(pph_ctx* ctx, const Csr& A, const double* b, double* x, cons
       bnorm = bnorm_hint;
     } else {
       apply_pc(b, z);
-      la_dot(ctx, z, z, n, slot);
+      la_dot(ctx, z + ob, z + ob, on, slot);
       PPH_TRY(la_fetch(ctx, slot, 1));
       bnorm = std::sqrt(ctx->h_scal[slot]);
     }
@@ -96,7 +101,7 @@ static int cg_solve(pph_ctx* ctx, const Csr& A, const double* b, double* x, cons
     bnorm = -1.0;
   }
   apply_pc(r, z);
-  la_dot2(ctx, r, z, z, n, slot);
+  la_dot2(ctx, r + ob, z + ob, z + ob, on, slot);
   PPH_TRY(la_fetch(ctx, slot, 2));
   double rz = ctx->h_scal[slot];
   double res = std::sqrt(ctx->h_scal[slot + 1]);
@@ -116,12 +121,12 @@ static int cg_solve(pph_ctx* ctx, const Csr& A, const double* b, double* x, cons
     const double alpha = rz / pq;
     double rz_new;
     if (fused) {
-      la_cg_update(ctx, x, r, z, p, q, dinv, alpha, n, slot);
+      la_cg_update(ctx, x, r, z, p, q, dinv, alpha, n, slot, ob, oe);
     } else {
       la_axpy(ctx, x, alpha, p, n);
       la_axpy(ctx, r, -alpha, q, n);
       pc(r, z);
-      la_dot2(ctx, r, z, z, n, slot);
+      la_dot2(ctx, r + ob, z + ob, z + ob, on, slot);
     }
     PPH_TRY(la_fetch(ctx, slot, 2));
     rz_new = ctx->h_scal[slot];
@@ -345,6 +350,7 @@ static int validate_cfg(pph_ctx* ctx, const pph_solver_cfg* cfg) {
   PPH_REQUIRE(ctx, cfg->inner_ksp_type == PPH_KSP_PREONLY || cfg->inner_ksp_type == PPH_KSP_CG,
               "inner ksp_type %d not supported (preonly, cg)", cfg->inner_ksp_type);
   if (!cfg->picard) {
+    PPH_REQUIRE(ctx, ctx->world == 1, "slab-decomposed (multi-GPU) solves support the Picard / block-solve path only");
     PPH_REQUIRE(ctx, cfg->pc_type != PPH_PC_MG, "pc_type mg applies to the scalar blocks: use it as inner_pc_type");
     PPH_REQUIRE(ctx, ctx->mono_ok, "monolithic Krylov solve needs pph_assemble_dpp(..., monolithic=1)");
   }
@@ -358,6 +364,7 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
   PPH_HIP(ctx, hipSetDevice(ctx->device));
   const int64_t n = ctx->n, N = 2 * n;
   la_reset_spmv_stats(ctx);
+  ctx->n_halo = 0;
   PPH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
 
   pph_solve_info inf;
@@ -398,6 +405,7 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
     PPH_TRY(work(ctx, W_R1, (size_t)n, &r1));
     la_set(ctx, t12, 0.0, n);
     const bool recur = (cfg->inner_ksp_type == PPH_KSP_CG);
+    const int64_t pob = ctx->mesh.own_begin(), pon = ctx->mesh.own_end() - ctx->mesh.own_begin();
     while (res > tol && its < cfg->picard_max_it) {
       la_sub(ctx, pb, b1, t12, n);
       PPH_TRY(bs.solve(0, pb, du1, its > 0));
@@ -411,17 +419,17 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
       la_spmv(ctx, A12, du2, t12);
       if (recur) {
         la_axpy(ctx, r1, -1.0, t12, n);
-        la_dot(ctx, r1, r1, n, S_A);
-        la_dot(ctx, bs.last_resid, bs.last_resid, n, S_A + 1);
+        la_dot(ctx, r1 + pob, r1 + pob, pon, S_A);
+        la_dot(ctx, bs.last_resid + pob, bs.last_resid + pob, pon, S_A + 1);
       } else {
         // inner "solves" without a residual recurrence (preonly): evaluate the monolithic residual
         la_spmv_resid(ctx, bs.A[0], du1, b1, r1);
         la_axpy(ctx, r1, -1.0, t12, n);
-        la_dot(ctx, r1, r1, n, S_A);
+        la_dot(ctx, r1 + pob, r1 + pob, pon, S_A);
         la_spmv_resid(ctx, A21, du1, b2, r1);
         la_spmv(ctx, bs.A[1], du2, t);
         la_axpy(ctx, r1, -1.0, t, n);
-        la_dot(ctx, r1, r1, n, S_A + 1);
+        la_dot(ctx, r1 + pob, r1 + pob, pon, S_A + 1);
       }
       PPH_TRY(la_fetch(ctx, S_A, 2));
       res = std::sqrt(ctx->h_scal[S_A] + ctx->h_scal[S_A + 1]);
@@ -431,11 +439,11 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
         // confirm with the true residual once; keep sweeping if the recurrence was optimistic
         la_spmv_resid(ctx, bs.A[0], du1, b1, r1);
         la_axpy(ctx, r1, -1.0, t12, n);
-        la_dot(ctx, r1, r1, n, S_A);
+        la_dot(ctx, r1 + pob, r1 + pob, pon, S_A);
         la_spmv_resid(ctx, A21, du1, b2, r1);
         la_spmv(ctx, bs.A[1], du2, t);
         la_axpy(ctx, r1, -1.0, t, n);
-        la_dot(ctx, r1, r1, n, S_A + 1);
+        la_dot(ctx, r1 + pob, r1 + pob, pon, S_A + 1);
         PPH_TRY(la_fetch(ctx, S_A, 2));
         res = std::sqrt(ctx->h_scal[S_A] + ctx->h_scal[S_A + 1]);
         if (hist && its < hist_cap) hist[its] = res;

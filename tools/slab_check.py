@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Multi-rank parity check of the slab-decomposed HIP path (launched by torch.distributed.run):
+every rank solves its slab; rank 0 also solves the whole cube on one context and compares solution,
+Picard sweeps and inner CG iteration totals.  Exit code 0 = parity."""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cells", type=int, default=16)
+ap.add_argument("--backend", default="gloo")
+ap.add_argument("--kind", default="hex")
+ap.add_argument("--inner-pc", default="mg")
+args = ap.parse_args()
+
+from perphil_amd import _ffi  # noqa: E402  (before torch: the library binds the system HIP runtime first)
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+import bench  # noqa: E402
+from perphil_amd.distributed import SlabSolver  # noqa: E402
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+ndev = torch.cuda.device_count()
+device = local_rank % max(ndev, 1)
+torch.cuda.set_device(device)
+dist.init_process_group(backend=args.backend)
+kind = _ffi.CELL_HEX if args.kind == "hex" else _ffi.CELL_TET
+pc = _ffi.PC_MG if args.inner_pc == "mg" else _ffi.PC_JACOBI
+k1, k2, beta, mu = 1.0, 1e-2, 1.0, 1.0
+solver = SlabSolver(args.cells, world, rank, device, k1, k2, beta, mu, kind=kind, inner_pc=pc)
+info = solver.step()
+full = solver.gather_solution()
+ok = True
+if rank == 0:
+    ctx = _ffi.Context(device)
+    ctx.mesh_build(3, kind, args.cells, args.cells, args.cells)
+    b, g1, g2 = bench.mms_boundary(args.cells, k1, k2, beta, mu) if kind == _ffi.CELL_HEX else (None, None, None)
+    if b is None:
+        from perphil_amd import fd, DPPParameters, exact_expressions_3d
+        mesh = fd.UnitCubeMesh(args.cells, args.cells, args.cells)
+        b = mesh.boundary_nodes()
+        _, p1, _, p2 = exact_expressions_3d(mesh, DPPParameters(k1=k1, k2=k2, beta=beta, mu=mu))
+        X = mesh.node_coordinates(b)
+        g1, g2 = p1(X), p2(X)
+    ctx.set_dirichlet(0, b, g1)
+    ctx.set_dirichlet(1, b, g2)
+    ctx.assemble(k1, k2, beta, mu, monolithic=False)
+    x1, info1, _ = ctx.solve(solver.cfg)
+    err = np.abs(full - x1).max() / np.abs(x1).max()
+    print(f"world={world} n={args.cells} kind={args.kind} pc={args.inner_pc}: sweeps {info.iterations} vs {info1.iterations}, "
+          f"inner its {info.inner_iterations} vs {info1.inner_iterations}, residual {info.resnorm:.3e} vs {info1.resnorm:.3e}, "
+          f"max rel diff {err:.3e}, halo calls {solver.comm.halo_calls}, allreduce calls {solver.comm.allreduce_calls}", flush=True)
+    ok = (err < 1e-9 and info.iterations == info1.iterations and abs(info.inner_iterations - info1.inner_iterations) <= 1
+          and info.converged == 1)
+flag = torch.tensor([1.0 if ok else 0.0])
+if args.backend == "nccl":
+    flag = flag.cuda()
+dist.broadcast(flag, 0)
+dist.barrier()
+dist.destroy_process_group()
+sys.exit(0 if flag.item() == 1.0 else 1)

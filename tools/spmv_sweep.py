@@ -12,11 +12,11 @@ from perphil_amd import _ffi  # noqa: E402
 import bench  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--n", type=int, nargs="+", default=[128, 256])
+ap.add_argument("--cells", type=int, nargs="+", default=[128, 256])
 ap.add_argument("--reps", type=int, default=30)
 ap.add_argument("--mono", action="store_true")
 args = ap.parse_args()
-for N in args.n:
+for N in args.cells:
     ctx = _ffi.Context(0)
     ctx.mesh_build(3, _ffi.CELL_HEX, N, N, N)
     b, g1, g2 = bench.mms_boundary(N, 1.0, 1e-2, 1.0, 1.0)
