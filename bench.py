@@ -114,23 +114,31 @@ def main():
     from perphil_amd import _ffi
 
     dist = None
+    device = local_rank
     if world > 1:
         import torch.distributed as dist  # noqa: F811
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # "nccl" is RCCL on ROCm.  PERPHIL_DIST_BACKEND=gloo rehearses the multi-rank path on a box with
+        # fewer GPUs than ranks (ranks then share devices; communication is staged through the host).
+        backend = os.environ.get("PERPHIL_DIST_BACKEND", "nccl")
+        device = local_rank % max(torch.cuda.device_count(), 1)
+        torch.cuda.set_device(device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group(backend=backend)
     N = args.cells
     k1, k2, beta, mu = 1.0, 1e-2, 1.0, 1.0
 
     if world > 1:
         from perphil_amd.distributed import SlabSolver
 
-        solver = SlabSolver(N, world, rank, local_rank, k1, k2, beta, mu, inner_rtol=args.inner_rtol, smooth=args.smooth)
+        solver = SlabSolver(N, world, rank, device, k1, k2, beta, mu, inner_rtol=args.inner_rtol, smooth=args.smooth)
         dofs_global = solver.global_dofs
         step = solver.step
         ctx = solver.ctx
     else:
-        ctx = _ffi.Context(local_rank)
+        ctx = _ffi.Context(device)
         ctx.mesh_build(3, _ffi.CELL_HEX, N, N, N)
         b, g1, g2 = mms_boundary(N, k1, k2, beta, mu)
         ctx.set_dirichlet(0, b, g1)
@@ -161,7 +169,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     tm = ctx.timers()
@@ -213,6 +221,7 @@ def main():
             "picard_ms_per_sweep": round(tm["solve_ms"] / max(int(info.iterations), 1), 3),
             "assemble_ms": round(tm["assemble_ms"] + tm["bc_blocks_ms"], 3), "solve_ms": round(tm["solve_ms"], 3),
             "final_residual": float(info.resnorm), "rhs_norm": float(info.rhs_norm),
+            "halo_exchanges_per_step": int(tm.get("halo_exchanges", 0)),
         },
         "roofline": roofline,
     }

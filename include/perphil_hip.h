@@ -168,6 +168,14 @@ typedef int (*pph_halo_fn)(void* user, double* vec, int64_t plane_elems, int64_t
 typedef int (*pph_allreduce_fn)(void* user, double* vals, int64_t count);
 int pph_comm_set_callbacks(pph_ctx* ctx, int rank, int world, pph_halo_fn halo, pph_allreduce_fn allreduce,
                            void* user);
+/* RCCL transport (default on the multi-GPU node): the library issues grouped ncclSend/ncclRecv of the
+ * neighbour planes and ncclAllReduce of the reduction scalars on its own stream.  librccl is resolved with
+ * dlopen (`libpath` may be NULL/empty: default search, then /opt/rocm/lib).  Rank 0 draws the 128-byte
+ * unique id, the launcher broadcasts it, every rank calls pph_comm_init_rccl; pph_comm_selftest verifies
+ * a send/recv to self and an all-reduce on the context stream. */
+int pph_rccl_unique_id(const char* libpath, uint8_t* id128);
+int pph_comm_init_rccl(pph_ctx* ctx, int rank, int world, const uint8_t* id128, const char* libpath);
+int pph_comm_selftest(pph_ctx* ctx);
 
 /* ---- stats ---------------------------------------------------------------------------------
  * replaces: PETSc -log_view event times scraped by reference src/perphil/experiments/petsc_profiling.py:302-447.

@@ -33,6 +33,7 @@ EXPORTS = [
     "pph_solve", "pph_solve_device", "pph_get_solution",
     "pph_csr_sizes", "pph_get_csr", "pph_get_rhs", "pph_spmv", "pph_spmv_bench",
     "pph_get_timers", "pph_set_option", "pph_comm_set_callbacks",
+    "pph_rccl_unique_id", "pph_comm_init_rccl", "pph_comm_selftest",
 ]
 
 HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64)
@@ -119,6 +120,9 @@ def _load() -> C.CDLL:
         "pph_get_timers": ([p, C.c_void_p, C.c_int], C.c_int),
         "pph_set_option": ([p, C.c_char_p, C.c_double], C.c_int),
         "pph_comm_set_callbacks": ([p, C.c_int, C.c_int, HALO_FN, ALLREDUCE_FN, C.c_void_p], C.c_int),
+        "pph_rccl_unique_id": ([C.c_char_p, C.c_void_p], C.c_int),
+        "pph_comm_init_rccl": ([p, C.c_int, C.c_int, C.c_void_p, C.c_char_p], C.c_int),
+        "pph_comm_selftest": ([p], C.c_int),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = ABI mismatch: fail loudly

@@ -106,6 +106,7 @@ int pph_ctx_destroy(pph_ctx* ctx) {
   release_system(ctx);
   ctx->mesh.release_all();
   for (int f = 0; f < 2; ++f) { ctx->bcmask[f].release(); ctx->g[f].release(); }
+  comm_release(ctx);
   for (auto& w : ctx->work) w.release();
   for (auto& p : ctx->ev_pool) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
   ctx->scal.release();
@@ -412,6 +413,7 @@ int pph_comm_set_callbacks(pph_ctx* ctx, int rank, int world, pph_halo_fn halo, 
   if (!ctx) return PPH_ERR_INVALID;
   PPH_REQUIRE(ctx, world >= 1 && rank >= 0 && rank < world, "rank %d outside world %d", rank, world);
   PPH_REQUIRE(ctx, world == 1 || (halo && allreduce), "multi-rank contexts need both callbacks");
+  comm_release(ctx);
   ctx->rank = rank;
   ctx->world = world;
   ctx->halo_cb = halo;

@@ -9,6 +9,8 @@
 
 #define PPH_WAVE 64
 
+struct PphNcclId { char internal[128]; };  // layout of ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128)
+
 // ---------------------------------------------------------------------------------------------
 // error plumbing: HIP failures become a negative status + message, never an abort
 // ---------------------------------------------------------------------------------------------
@@ -128,6 +130,7 @@ struct pph_ctx {
   pph_halo_fn halo_cb = nullptr;
   pph_allreduce_fn allreduce_cb = nullptr;
   void* comm_user = nullptr;
+  void* nccl_comm = nullptr;            // RCCL communicator (pph_comm_init_rccl); takes precedence over the callbacks
   std::vector<double> h_stage;          // host staging for vector all-reduces
   bool comm_suspended = false;          // true while working on replicated (non-distributed) coarse levels
   int64_t n_halo = 0;                   // halo exchanges of the last solve
@@ -203,6 +206,9 @@ int la_fetch(pph_ctx* ctx, int slot, int count);
 int la_halo(pph_ctx* ctx, const MeshData& g, double* v);
 // element-wise sum over all ranks of a device vector (small coarse-level vectors)
 int la_allreduce_vec(pph_ctx* ctx, double* v, int64_t n);
+int comm_allreduce_device(pph_ctx* ctx, double* dev, int64_t count);
+int comm_allreduce_host(pph_ctx* ctx, double* vals, int64_t count);
+void comm_release(pph_ctx* ctx);
 // adds the elapsed times of all event pairs recorded since the last call to ctx->t_spmv (synchronises)
 void la_harvest_spmv_times(pph_ctx* ctx);
 void la_reset_spmv_stats(pph_ctx* ctx);

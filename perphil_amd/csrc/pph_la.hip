@@ -752,42 +752,12 @@ void la_extract_diag_inv(pph_ctx* ctx, const Csr& A, double* dinv) {
 }
 
 int la_fetch(pph_ctx* ctx, int slot, int count) {
+  const bool reduce = ctx->world > 1 && !ctx->comm_suspended;
+  // RCCL: sum the partial results on the device, on the stream, before they travel to the host
+  if (reduce && ctx->nccl_comm) PPH_TRY(comm_allreduce_device(ctx, ctx->scal.p + slot, count));
   PPH_HIP(ctx, hipMemcpyAsync(ctx->h_scal + slot, ctx->scal.p + slot, sizeof(double) * (size_t)count,
                               hipMemcpyDeviceToHost, ctx->stream));
   PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (ctx->allreduce_cb && ctx->world > 1 && !ctx->comm_suspended) {
-    if (ctx->allreduce_cb(ctx->comm_user, ctx->h_scal + slot, (int64_t)count) != 0) {
-      pph_set_error(ctx, "all-reduce callback failed");
-      return PPH_ERR_COMM;
-    }
-  }
-  return PPH_OK;
-}
-
-int la_halo(pph_ctx* ctx, const MeshData& g, double* v) {
-  if (!ctx->halo_cb || ctx->world <= 1 || (!g.glo && !g.ghi)) return PPH_OK;
-  const int64_t pl = g.plane();
-  const int64_t send_lo = g.glo ? pl : -1, recv_lo = g.glo ? 0 : -1;
-  const int64_t send_hi = g.ghi ? g.n - 2 * pl : -1, recv_hi = g.ghi ? g.n - pl : -1;
-  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (ctx->halo_cb(ctx->comm_user, v, pl, send_lo, recv_lo, send_hi, recv_hi) != 0) {
-    pph_set_error(ctx, "halo-exchange callback failed");
-    return PPH_ERR_COMM;
-  }
-  ctx->n_halo++;
-  return PPH_OK;
-}
-
-int la_allreduce_vec(pph_ctx* ctx, double* v, int64_t n) {
-  if (!ctx->allreduce_cb || ctx->world <= 1) return PPH_OK;
-  ctx->h_stage.resize((size_t)n);
-  PPH_HIP(ctx, hipMemcpyAsync(ctx->h_stage.data(), v, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (ctx->allreduce_cb(ctx->comm_user, ctx->h_stage.data(), n) != 0) {
-    pph_set_error(ctx, "all-reduce callback failed");
-    return PPH_ERR_COMM;
-  }
-  PPH_HIP(ctx, hipMemcpyAsync(v, ctx->h_stage.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
-  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (reduce && !ctx->nccl_comm) PPH_TRY(comm_allreduce_host(ctx, ctx->h_scal + slot, (int64_t)count));
   return PPH_OK;
 }

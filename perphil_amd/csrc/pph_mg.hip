@@ -228,13 +228,10 @@ void mg_release(pph_ctx* ctx) {
 // minimum of one integer per rank (collective); identity on a single rank
 static int comm_min_int(pph_ctx* ctx, int v, int* out) {
   *out = v;
-  if (ctx->world <= 1 || !ctx->allreduce_cb) return PPH_OK;
+  if (ctx->world <= 1) return PPH_OK;
   std::vector<double> buf((size_t)ctx->world, 0.0);
   buf[(size_t)ctx->rank] = (double)v;
-  if (ctx->allreduce_cb(ctx->comm_user, buf.data(), (int64_t)ctx->world) != 0) {
-    pph_set_error(ctx, "all-reduce callback failed");
-    return PPH_ERR_COMM;
-  }
+  PPH_TRY(comm_allreduce_host(ctx, buf.data(), (int64_t)ctx->world));
   double m = buf[0];
   for (double b : buf) m = b < m ? b : m;
   *out = (int)m;
@@ -243,13 +240,10 @@ static int comm_min_int(pph_ctx* ctx, int v, int* out) {
 
 static int comm_max_double(pph_ctx* ctx, double v, double* out) {
   *out = v;
-  if (ctx->world <= 1 || !ctx->allreduce_cb) return PPH_OK;
+  if (ctx->world <= 1) return PPH_OK;
   std::vector<double> buf((size_t)ctx->world, 0.0);
   buf[(size_t)ctx->rank] = v;
-  if (ctx->allreduce_cb(ctx->comm_user, buf.data(), (int64_t)ctx->world) != 0) {
-    pph_set_error(ctx, "all-reduce callback failed");
-    return PPH_ERR_COMM;
-  }
+  PPH_TRY(comm_allreduce_host(ctx, buf.data(), (int64_t)ctx->world));
   double m = buf[0];
   for (double b : buf) m = b > m ? b : m;
   *out = m;

@@ -22,6 +22,41 @@ _HALO_FN = _ffi.HALO_FN
 _ALLREDUCE_FN = _ffi.ALLREDUCE_FN
 
 
+def _loaded_rccl_path() -> bytes:
+    """Path of the librccl the process already has (torch's bundled copy), else empty (library default)."""
+    try:
+        with open("/proc/self/maps") as f:
+            for line in f:
+                if "librccl" in line:
+                    return line.split()[-1].encode()
+    except OSError:
+        pass
+    return b""
+
+
+def init_rccl(ctx: _ffi.Context, group=None) -> None:
+    """Create the context's RCCL communicator: rank 0 draws the unique id, torch.distributed broadcasts
+    it (any backend), every rank joins; then the library's self-test runs on the context stream."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    path = _loaded_rccl_path()
+    ident = np.zeros(128, dtype=np.uint8)
+    if rank == 0:
+        ctx._check(_ffi.lib.pph_rccl_unique_id(path, ident.ctypes.data_as(C.c_void_p)))
+    t = torch.from_numpy(ident)
+    if dist.get_backend(group) == "nccl":
+        d = t.cuda()
+        dist.broadcast(d, 0, group=group)
+        ident = d.cpu().numpy()
+    else:
+        dist.broadcast(t, 0, group=group)
+    ident = np.ascontiguousarray(ident)
+    ctx._check(_ffi.lib.pph_comm_init_rccl(ctx._h, rank, world, ident.ctypes.data_as(C.c_void_p), path))
+    ctx._check(_ffi.lib.pph_comm_selftest(ctx._h))
+
+
 class _DevView:
     """Zero-copy view of `count` doubles at a raw device address (CUDA array interface v3)."""
 
@@ -103,7 +138,7 @@ class SlabSolver:
 
     def __init__(self, n_cells: int, world: int, rank: int, device: int, k1: float, k2: float, beta: float, mu: float,
                  inner_rtol: float = 1e-10, smooth: int = 2, kind: int = _ffi.CELL_HEX, group=None,
-                 inner_pc: int = _ffi.PC_MG):
+                 inner_pc: int = _ffi.PC_MG, transport: str = "auto"):
         from .manufactured_solutions import exact_expressions_3d
         from .parameters import DPPParameters
         from . import fd
@@ -115,7 +150,21 @@ class SlabSolver:
         self.ctx = _ffi.Context(device)
         s = self.slab
         self.ctx.mesh_build(3, kind, s.nx, s.ny, s.nz, s.z_begin, s.z_count, s.ghost_lo, s.ghost_hi)
-        self.comm.attach(self.ctx)
+        # transport: "rccl" = ncclSend/Recv/AllReduce issued by the library on its own stream (default with
+        # the nccl backend), "torch" = callbacks into torch.distributed (needed for gloo rehearsals)
+        if transport == "auto":
+            transport = "rccl" if self.comm.backend == "nccl" else "torch"
+        self.transport = transport
+        if transport == "rccl":
+            try:
+                init_rccl(self.ctx, group)
+            except Exception as e:
+                if world > 1:
+                    print(f"[perphil_amd.distributed] RCCL transport unavailable on rank {rank} ({e!r}); "
+                          "falling back to torch.distributed callbacks", flush=True)
+                self.transport = "torch"
+        if self.transport == "torch":
+            self.comm.attach(self.ctx)
         mesh = fd.UnitCubeMesh(n_cells, n_cells, n_cells, hexahedral=(kind == _ffi.CELL_HEX))
         loc, glob = s.boundary_local()
         X = mesh.node_coordinates(glob)

@@ -1,0 +1,46 @@
+"""Slab-decomposed (multi-rank) HIP path against the single-context run, on ONE GPU: the ranks share
+the device and communicate through gloo (tools/slab_check.py).  Same solver code as the 8-GPU RCCL run;
+only the transport differs."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,cells,kind,pc", [(2, 16, "hex", "mg"), (4, 16, "hex", "mg"), (2, 16, "tet", "mg"),
+                                                  (2, 8, "hex", "jacobi")])
+def test_slab_runs_match_single_context(world, cells, kind, pc):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tools", "slab_check.py"), "--cells", str(cells), "--backend", "gloo", "--kind", kind,
+           "--inner-pc", pc]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    line = [l for l in r.stdout.splitlines() if l.startswith("world=")]
+    assert r.returncode == 0, (line, r.stdout[-2000:], r.stderr[-2000:])
+    assert line and "max rel diff" in line[0]
+
+
+def test_rccl_plumbing_single_rank():
+    """A 1-rank RCCL communicator exercises dlopen, ncclCommInitRank, grouped ncclSend/ncclRecv and
+    ncclAllReduce on the context stream (the 8-GPU run uses the same calls with more ranks)."""
+    code = (
+        "import os, sys; sys.path.insert(0, %r)\n"
+        "import torch, torch.distributed as dist\n"
+        "from perphil_amd import _ffi\n"
+        "from perphil_amd.distributed import init_rccl\n"
+        "dist.init_process_group('gloo', init_method='tcp://127.0.0.1:%d', rank=0, world_size=1)\n"
+        "ctx = _ffi.Context(0); init_rccl(ctx); print('rccl selftest ok'); dist.destroy_process_group()\n"
+    ) % (ROOT, _free_port())
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0 and "rccl selftest ok" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
