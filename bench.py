@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def picard_cfg(_ffi, inner_rtol=1e-10, smooth=2):
+def picard_cfg(_ffi, inner_rtol=1e-10, smooth=2, reduction=0.0):
     cfg = _ffi.SolverCfg()
     cfg.ksp_type, cfg.pc_type, cfg.restart, cfg.max_it = _ffi.KSP_GMRES, _ffi.PC_FIELDSPLIT, 30, 50000
     cfg.rtol, cfg.atol = 1e-8, 1e-12
@@ -39,6 +39,7 @@ def picard_cfg(_ffi, inner_rtol=1e-10, smooth=2):
     cfg.inner_rtol, cfg.inner_atol = inner_rtol, 1e-300
     cfg.picard, cfg.picard_rtol, cfg.picard_atol, cfg.picard_max_it = 1, 1e-8, 1e-12, 100
     cfg.mg_smooth = smooth
+    cfg.inner_reduction = reduction
     return cfg
 
 
@@ -101,7 +102,9 @@ def main():
     ap.add_argument("--cpu-sample-n", type=int, default=48)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inner-rtol", type=float, default=1e-10)
-    ap.add_argument("--smooth", type=int, default=2)
+    ap.add_argument("--smooth", type=int, default=1)
+    ap.add_argument("--inner-reduction", type=float, default=1e-2)
+    ap.add_argument("--asm-kernel", type=int, default=1)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -143,7 +146,8 @@ def main():
         b, g1, g2 = mms_boundary(N, k1, k2, beta, mu)
         ctx.set_dirichlet(0, b, g1)
         ctx.set_dirichlet(1, b, g2)
-        cfg = picard_cfg(_ffi, args.inner_rtol, args.smooth)
+        cfg = picard_cfg(_ffi, args.inner_rtol, args.smooth, args.inner_reduction)
+        ctx.set_option("asm_kernel", args.asm_kernel)
         dofs_global = 2 * ctx.n
         last = {}
 

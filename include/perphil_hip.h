@@ -78,6 +78,10 @@ typedef struct {
   double picard_atol;    /* snes_atol */
   int32_t picard_max_it; /* snes_max_it */
   int32_t mg_smooth;     /* smoothing steps per level side for PPH_PC_MG (default 2)     */
+  double inner_reduction; /* > 0: block solves stop once their preconditioned residual has dropped by this
+                          * factor from its value at the start of the solve (inexact Picard sweeps; warm
+                          * starts make the sequence converge to the exact fixed point), or at inner_rtol,
+                          * whichever comes first.  0: inner_rtol only.                       */
 } pph_solver_cfg;
 
 typedef struct {

@@ -50,6 +50,7 @@ class SolverCfg(C.Structure):
         ("inner_rtol", C.c_double), ("inner_atol", C.c_double),
         ("picard_rtol", C.c_double), ("picard_atol", C.c_double),
         ("picard_max_it", C.c_int32), ("mg_smooth", C.c_int32),
+        ("inner_reduction", C.c_double),
     ]
 
 

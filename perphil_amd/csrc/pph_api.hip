@@ -21,8 +21,9 @@ void pph_set_error(pph_ctx* ctx, const char* fmt, ...) {
 
 template <typename T>
 int DevBuf<T>::alloc(pph_ctx* ctx, size_t count) {
-  release();
   if (count == 0) count = 1;
+  if (p && n == count) return PPH_OK;  // same size: keep the allocation (hipMalloc/hipFree of multi-GB buffers is slow)
+  release();
   void* q = nullptr;
   // 64 bytes of slack: the aligned-wide SpMV reads whole 16-byte groups around a row's range
   hipError_t e = hipMalloc(&q, count * sizeof(T) + 64);
@@ -90,20 +91,27 @@ int pph_ctx_create(int device, pph_ctx** out) {
   return PPH_OK;
 }
 
+// the assembled system is stale (parameters / boundary data changed): buffers are kept for re-use
 static void release_system(pph_ctx* ctx) {
+  ctx->asm_ok = false;
+  ctx->mono_ok = false;
+  ctx->mg_ok = false;
+}
+
+// the mesh goes away: free everything that was sized by it
+static void free_system(pph_ctx* ctx) {
   ctx->A11.release(); ctx->A22.release(); ctx->A12.release(); ctx->A21.release();
   ctx->rhs.release(); ctx->u0.release(); ctx->sol.release();
   ctx->mrowptr.release(); ctx->mcol.release(); ctx->mval.release();
   mg_release(ctx);
-  ctx->asm_ok = false;
-  ctx->mono_ok = false;
+  release_system(ctx);
 }
 
 int pph_ctx_destroy(pph_ctx* ctx) {
   if (!ctx) return PPH_OK;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  release_system(ctx);
+  free_system(ctx);
   ctx->mesh.release_all();
   for (int f = 0; f < 2; ++f) { ctx->bcmask[f].release(); ctx->g[f].release(); }
   comm_release(ctx);
@@ -148,8 +156,9 @@ int pph_mesh_build(pph_ctx* ctx, int dim, int cell_kind, int nx, int ny, int nz,
     PPH_REQUIRE(ctx, !(ghost_lo && z_cell_begin == 0) && !(ghost_hi && z_cell_begin + z_cell_count == nz),
                 "a ghost plane cannot lie on the domain boundary");
   }
-  release_system(ctx);
+  free_system(ctx);
   ctx->mesh.release_all();
+  ctx->mesh.km_valid = false;
   ctx->mesh_ok = false;
   PPH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   MeshData& m = ctx->mesh;
@@ -255,9 +264,10 @@ int pph_assemble_dpp(pph_ctx* ctx, double k1, double k2, double beta, double mu,
   ctx->a = k1 / mu; ctx->b = beta / mu; ctx->c = k2 / mu;
   float ms = 0.f;
   // K and M depend only on the mesh: integrate once per mesh
-  if (!ctx->mesh.K.p) {
+  if (!ctx->mesh.km_valid) {
     PPH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     PPH_TRY(pph_launch_assemble_KM(ctx, ctx->mesh));
+    ctx->mesh.km_valid = true;
     PPH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     PPH_HIP(ctx, hipEventSynchronize(ctx->ev1));
     PPH_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
@@ -288,8 +298,8 @@ static int select_csr(pph_ctx* ctx, int which, Csr* A) {
       A->lanes = pph_pick_lanes(ctx, A->nnz, A->nrows);
       A->max_row = 2 * m.max_row;
       return PPH_OK;
-    case 1: PPH_REQUIRE(ctx, m.K.p, "K not assembled"); A->val = m.K.p; return PPH_OK;
-    case 2: PPH_REQUIRE(ctx, m.M.p, "M not assembled"); A->val = m.M.p; return PPH_OK;
+    case 1: PPH_REQUIRE(ctx, m.K.p && m.km_valid, "K not assembled"); A->val = m.K.p; return PPH_OK;
+    case 2: PPH_REQUIRE(ctx, m.M.p && m.km_valid, "M not assembled"); A->val = m.M.p; return PPH_OK;
     case 3: PPH_REQUIRE(ctx, ctx->asm_ok, "blocks not assembled"); A->val = ctx->A11.p; return PPH_OK;
     case 4: PPH_REQUIRE(ctx, ctx->asm_ok, "blocks not assembled"); A->val = ctx->A22.p; return PPH_OK;
     case 5: PPH_REQUIRE(ctx, ctx->asm_ok, "blocks not assembled"); A->val = ctx->A12.p; return PPH_OK;
@@ -396,12 +406,23 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
     ctx->spmv_kernel = v;
     return PPH_OK;
   }
+  if (!strcmp(name, "asm_kernel")) {
+    const int v = (int)value;
+    PPH_REQUIRE(ctx, v == 0 || v == 1, "asm_kernel: 0 cell-centred scatter-add (atomics), 1 node-centred gather");
+    ctx->asm_kernel = v;
+    ctx->mesh.km_valid = false;
+    for (auto& L : ctx->mg) L.mesh.km_valid = false;
+    ctx->mg_ok = false;
+    return PPH_OK;
+  }
   if (!strcmp(name, "spmv_blocks")) { la_set_spmv_blocks((int)value); return PPH_OK; }
   if (!strcmp(name, "time_spmv")) { ctx->time_spmv = value != 0.0; return PPH_OK; }
   if (!strcmp(name, "invalidate_KM")) {
-    // forget the integrated K and M so that the next pph_assemble_dpp integrates again (benchmarks)
-    ctx->mesh.K.release();
-    ctx->mesh.M.release();
+    // forget the integrated K and M (all multigrid levels) so that the next assemble + solve integrates
+    // again (benchmarks); the buffers are kept
+    ctx->mesh.km_valid = false;
+    for (auto& L : ctx->mg) L.mesh.km_valid = false;
+    ctx->mg_ok = false;
     return PPH_OK;
   }
   pph_set_error(ctx, "unknown option '%s'", name);
@@ -420,6 +441,7 @@ int pph_comm_set_callbacks(pph_ctx* ctx, int rank, int world, pph_halo_fn halo, 
   ctx->allreduce_cb = allreduce;
   ctx->comm_user = user;
   mg_release(ctx);
+  ctx->mg_ok = false;
   return PPH_OK;
 }
 

@@ -282,14 +282,191 @@ __global__ __launch_bounds__(256) void k_asm_simplex(const int32_t* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Node-centred (gather) assembly for multilinear cells: deterministic, no atomics, every CSR entry is
+// written exactly once.  One lane per (node, incident cell): the 2^d lanes of a node integrate the row of
+// K_e / M_e that belongs to the node in each of its (up to) 2^d incident cells — the same quadrature as
+// the scatter kernel — and park the rows in LDS; then the lanes of the node walk its CSR row and sum, in a
+// fixed order, the parked entries whose column matches.  Incident cells are enumerated from the box
+// structure, the local row index and the column matching come from the cell->dof map.
+// ------------------------------------------------------------------------------------------------
+template <int DIM>
+__global__ __launch_bounds__(256) void k_asm_gather(const int32_t* __restrict__ cells, const double* __restrict__ cx,
+                                                    const double* __restrict__ cy, const double* __restrict__ cz,
+                                                    const int64_t* __restrict__ rowptr,
+                                                    const int32_t* __restrict__ col, double* __restrict__ K,
+                                                    double* __restrict__ M, int nx, int ny, int nzl, int px, int py,
+                                                    int64_t n) {
+  constexpr int NB = 1 << DIM;   // nodes per cell == incident cells per node == Gauss points
+  constexpr int NPB = 256 / NB;  // nodes per workgroup batch
+  __shared__ double sN[NB][NB];
+  __shared__ double sdN[NB][NB][DIM];
+  __shared__ double sK[NPB][NB][NB];    // [node][incident cell][local column]
+  __shared__ double sM[NPB][NB][NB];
+  __shared__ int32_t sC[NPB][NB][NB];   // node ids of the incident cells (-1: cell absent)
+  const int tid = threadIdx.x;
+  if (tid < NB * NB) {
+    const int q = tid / NB, b = tid % NB;
+    const double gp = 0.57735026918962576451;
+    double xi[DIM], sg[DIM];
+#pragma unroll
+    for (int e = 0; e < DIM; ++e) {
+      xi[e] = ((q >> e) & 1) ? gp : -gp;
+      sg[e] = ((b >> e) & 1) ? 1.0 : -1.0;
+    }
+    double nv = 1.0;
+#pragma unroll
+    for (int e = 0; e < DIM; ++e) nv *= 0.5 * (1.0 + sg[e] * xi[e]);
+    sN[q][b] = nv;
+#pragma unroll
+    for (int e = 0; e < DIM; ++e) {
+      double d = 1.0;
+#pragma unroll
+      for (int f = 0; f < DIM; ++f) d *= (f == e) ? 0.5 * sg[f] : 0.5 * (1.0 + sg[f] * xi[f]);
+      sdN[q][b][e] = d;
+    }
+  }
+  const int ln = tid / NB;  // node inside the batch
+  const int c = tid % NB;   // incident-cell slot: the node is local vertex c of that cell
+  const int64_t nbatch = (n + NPB - 1) / NPB;
+  for (int64_t batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+    __syncthreads();
+    const int64_t node = batch * NPB + ln;
+    bool valid = node < n;
+    int64_t cell = -1;
+    if (valid) {
+      const int i = (int)(node % px);
+      const int64_t t = node / px;
+      const int j = (int)(t % py), k = (int)(t / py);
+      const int ci = i - (c & 1), cj = j - ((c >> 1) & 1), ck = (DIM == 3) ? k - ((c >> 2) & 1) : 0;
+      const bool inb = ci >= 0 && ci < nx && cj >= 0 && cj < ny && (DIM == 2 || (ck >= 0 && ck < nzl));
+      if (inb) cell = ci + (int64_t)nx * (cj + (int64_t)ny * ck);
+    }
+    double Kr[NB], Mr[NB];
+    int32_t nd[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) { Kr[b] = 0.0; Mr[b] = 0.0; nd[b] = -1; }
+    if (cell >= 0) {
+      double X[NB][DIM];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        nd[b] = cells[cell * NB + b];
+        X[b][0] = cx[nd[b]];
+        X[b][1] = cy[nd[b]];
+        if constexpr (DIM == 3) X[b][2] = cz[nd[b]];
+      }
+#pragma unroll 1
+      for (int q = 0; q < NB; ++q) {
+        double J[DIM][DIM];
+#pragma unroll
+        for (int e = 0; e < DIM; ++e)
+#pragma unroll
+          for (int d = 0; d < DIM; ++d) J[e][d] = 0.0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+          for (int e = 0; e < DIM; ++e)
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) J[e][d] += sdN[q][b][e] * X[b][d];
+        double det, I[DIM][DIM];
+        if constexpr (DIM == 2) {
+          det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+          const double r = 1.0 / det;
+          I[0][0] = J[1][1] * r;  I[0][1] = -J[0][1] * r;
+          I[1][0] = -J[1][0] * r; I[1][1] = J[0][0] * r;
+        } else {
+          const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+          const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+          const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+          det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+          const double r = 1.0 / det;
+          I[0][0] = c00 * r;
+          I[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
+          I[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
+          I[1][0] = c01 * r;
+          I[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
+          I[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
+          I[2][0] = c02 * r;
+          I[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
+          I[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
+        }
+        const double wdet = fabs(det);
+        double Ga[DIM];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) {
+          double g = 0.0;
+#pragma unroll
+          for (int e = 0; e < DIM; ++e) g += I[d][e] * sdN[q][c][e];
+          Ga[d] = g;
+        }
+        const double Na = sN[q][c];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          double dotg = 0.0;
+#pragma unroll
+          for (int d = 0; d < DIM; ++d) {
+            double g = 0.0;
+#pragma unroll
+            for (int e = 0; e < DIM; ++e) g += I[d][e] * sdN[q][b][e];
+            dotg += Ga[d] * g;
+          }
+          Kr[b] += wdet * dotg;
+          Mr[b] += wdet * Na * sN[q][b];
+        }
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      sK[ln][c][b] = Kr[b];
+      sM[ln][c][b] = Mr[b];
+      sC[ln][c][b] = nd[b];
+    }
+    __syncthreads();
+    if (valid) {
+      const int64_t s = rowptr[node], e = rowptr[node + 1];
+      for (int64_t k = s + c; k < e; k += NB) {
+        const int32_t j = col[k];
+        double kv = 0.0, mv = 0.0;
+#pragma unroll
+        for (int cc = 0; cc < NB; ++cc)
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            const bool hit = sC[ln][cc][b] == j;
+            kv += hit ? sK[ln][cc][b] : 0.0;
+            mv += hit ? sM[ln][cc][b] : 0.0;
+          }
+        K[k] = kv;
+        M[k] = mv;
+      }
+    }
+  }
+}
+
 int pph_launch_assemble_KM(pph_ctx* ctx_, MeshData& mesh) {
   pph_ctx* ctx = ctx_;
   PPH_TRY(mesh.K.alloc(ctx, (size_t)mesh.nnzb));
   PPH_TRY(mesh.M.alloc(ctx, (size_t)mesh.nnzb));
+  const int64_t ncell = mesh.ncell;
+  const bool multilinear = (mesh.kind == PPH_CELL_QUAD || mesh.kind == PPH_CELL_HEX);
+  if (multilinear && ctx->asm_kernel == 1) {
+    // node-centred gather: writes every entry once, no memset, no atomics
+    const int npb = 256 / mesh.m;
+    int64_t nbatch = ceil_div64(mesh.n, npb);
+    int grid = (int)(nbatch < 256 * 16 ? nbatch : 256 * 16);
+    if (mesh.kind == PPH_CELL_QUAD)
+      hipLaunchKernelGGL(k_asm_gather<2>, dim3(grid), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p, mesh.cy.p,
+                         mesh.cz.p, mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, mesh.nx, mesh.ny, 0, mesh.px, mesh.py,
+                         mesh.n);
+    else
+      hipLaunchKernelGGL(k_asm_gather<3>, dim3(grid), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p, mesh.cy.p,
+                         mesh.cz.p, mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, mesh.nx, mesh.ny, mesh.nzl, mesh.px,
+                         mesh.py, mesh.n);
+    PPH_HIP(ctx, hipGetLastError());
+    return PPH_OK;
+  }
   PPH_HIP(ctx, hipMemsetAsync(mesh.K.p, 0, sizeof(double) * mesh.nnzb, ctx->stream));
   PPH_HIP(ctx, hipMemsetAsync(mesh.M.p, 0, sizeof(double) * mesh.nnzb, ctx->stream));
-  const int64_t ncell = mesh.ncell;
-  if (mesh.kind == PPH_CELL_QUAD || mesh.kind == PPH_CELL_HEX) {
+  if (multilinear) {
     const int cpb = 256 / mesh.m;
     int64_t nbatch = ceil_div64(ncell, cpb);
     int grid = (int)(nbatch < 256 * 16 ? nbatch : 256 * 16);

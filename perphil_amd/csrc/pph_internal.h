@@ -72,6 +72,7 @@ struct MeshData {
   int px = 0, py = 0, pzl = 0;          // local node dims
   int64_t n = 0, ncell = 0, nnzb = 0;   // nodes, cells, nnz of one scalar block
   int max_row = 0;                      // stencil size = longest row of the scalar pattern
+  bool km_valid = false;                // K and M hold the integrals of this mesh
   DevBuf<double> cx, cy, cz;            // nodal coordinates (SoA)
   DevBuf<int32_t> cells;                // cell -> dof map [ncell][m]
   DevBuf<int64_t> rowptr;               // scalar CSR pattern
@@ -140,7 +141,8 @@ struct pph_ctx {
   double* h_scal = nullptr;             // pinned host mirror
   std::vector<DevBuf<double>> work;     // named work vectors, grown on demand
   std::vector<MgLevel> mg;              // multigrid hierarchy (level 0 = fine)
-  bool mg_ok = false;
+  bool mg_ok = false;                   // hierarchy values (operators, masks, bounds) match the assembled system
+  bool mg_struct_ok = false;            // hierarchy structure (level meshes, patterns, buffers) matches mesh + communicator
 
   // timers (ms)
   double t_mesh = 0, t_asm = 0, t_bc = 0, t_solve = 0;
@@ -155,6 +157,7 @@ struct pph_ctx {
   std::vector<EvPair> ev_pool;          // reusable event pairs
   size_t ev_used = 0;                   // pairs recorded since the last harvest
   int spmv_lanes_override = 0;          // 0: pick from the mean row length
+  int asm_kernel = 1;                   // multilinear cells: 1 node-centred gather (deterministic), 0 cell-centred scatter-add
   int spmv_kernel = 3;                  // 3: aligned-wide CSR-vector (default); 0,1,2,4..8,10: variants kept for A/B runs
 };
 

@@ -223,6 +223,7 @@ void mg_release(pph_ctx* ctx) {
   }
   ctx->mg.clear();
   ctx->mg_ok = false;
+  ctx->mg_struct_ok = false;
 }
 
 // minimum of one integer per rank (collective); identity on a single rank
@@ -256,7 +257,8 @@ static int comm_max_double(pph_ctx* ctx, double v, double* out) {
 // every rank, right-hand side summed by one all-reduce) below that, so the cycle equals the 1-GPU one.
 int mg_setup(pph_ctx* ctx) {
   if (ctx->mg_ok) return PPH_OK;
-  mg_release(ctx);
+  const bool build = !ctx->mg_struct_ok;  // level meshes / patterns / buffers survive re-assembly
+  if (build) mg_release(ctx);
   const MeshData& fm = ctx->mesh;
   const bool dist = ctx->world > 1;
   PPH_REQUIRE(ctx, !dist || fm.dim == 3, "slab decomposition needs a 3D mesh");
@@ -276,7 +278,8 @@ int mg_setup(pph_ctx* ctx) {
     while (l + 1 < nlev && (c0 % (2 << l)) == 0 && (c1 % (2 << l)) == 0 && ((c1 - c0) >> (l + 1)) >= 2) ++l;
     PPH_TRY(comm_min_int(ctx, l + 1, &ndist));
   }
-  ctx->mg.resize(nlev);
+  if (build) ctx->mg.resize(nlev);
+  PPH_REQUIRE(ctx, (int)ctx->mg.size() == nlev, "multigrid hierarchy out of date");
   DevBuf<unsigned long long> lamdev;
   DevBuf<double> mtmp;
   PPH_TRY(lamdev.alloc(ctx, 2));
@@ -297,8 +300,11 @@ int mg_setup(pph_ctx* ctx) {
       if (fm.dim == 2) { m.z0 = 0; m.nzl = 0; m.glo = m.ghi = 0; }
       else if (L.replicated || !dist) { m.z0 = 0; m.nzl = m.nz; m.glo = m.ghi = 0; }
       else { m.glo = fm.glo; m.ghi = fm.ghi; m.z0 = (c0 >> l) - m.glo; m.nzl = (c1 >> l) - m.z0; }
-      PPH_TRY(pph_launch_mesh(ctx, m));
-      PPH_TRY(pph_launch_assemble_KM(ctx, m));
+      if (build) PPH_TRY(pph_launch_mesh(ctx, m));
+      if (!m.km_valid) {
+        PPH_TRY(pph_launch_assemble_KM(ctx, m));
+        m.km_valid = true;
+      }
       L.rowptr = m.rowptr.p; L.col = m.col.p; L.n = m.n; L.nnz = m.nnzb; L.px = m.px; L.py = m.py; L.pz = m.pzl;
       L.geom = &L.mesh;
       L.gz0 = m.z0;
@@ -317,8 +323,6 @@ int mg_setup(pph_ctx* ctx) {
         pph_launch_scalar_block(ctx, m, L.maskp[f], coefK[f], ctx->b, L.own_val[f].p);
         L.val[f] = L.own_val[f].p;
       }
-      PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      m.release_geometry();
     }
     if (l == 0) {
       L.gz0 = fm.z0;
@@ -354,6 +358,7 @@ int mg_setup(pph_ctx* ctx) {
   lamdev.release();
   mtmp.release();
   PPH_HIP(ctx, hipGetLastError());
+  ctx->mg_struct_ok = true;
   ctx->mg_ok = true;
   return PPH_OK;
 }

@@ -69,7 +69,8 @@ static Csr mono_csr(pph_ctx* ctx) {
 // ------------------------------------------------------------------------------------------------
 static int cg_solve(pph_ctx* ctx, const Csr& A, const double* b, double* x, const double* dinv, const ApplyFn& pc,
                     double rtol, double atol, int max_it, bool warm, double* r, double* z, double* p, double* q,
-                    int slot, KspOut* out, double* hist, int hist_cap, double bnorm_hint = -1.0) {
+                    int slot, KspOut* out, double* hist, int hist_cap, double bnorm_hint = -1.0,
+                    double reduction = 0.0) {
   const int64_t n = A.nrows;
   // reductions run over the owned entries of a slab (whole vector on a single GPU)
   const int64_t ob = A.geom ? A.geom->own_begin() : 0;
@@ -106,7 +107,8 @@ static int cg_solve(pph_ctx* ctx, const Csr& A, const double* b, double* x, cons
   double rz = ctx->h_scal[slot];
   double res = std::sqrt(ctx->h_scal[slot + 1]);
   if (bnorm < 0.0) bnorm = res;
-  const double tol = std::fmax(rtol * bnorm, atol);
+  // `reduction` > 0: also accept a drop by that factor from the initial residual of THIS solve
+  const double tol = std::fmax(std::fmax(rtol * bnorm, atol), reduction > 0.0 ? reduction * res : 0.0);
   out->its = 0; out->res = res; out->converged = false; out->breakdown = false; out->bnorm = bnorm;
   if (hist && hist_cap > 0) hist[0] = res;
   if (!(res == res)) { out->breakdown = true; return PPH_OK; }
@@ -321,7 +323,8 @@ struct BlockSolver {
       return PPH_OK;
     }
     PPH_TRY(cg_solve(ctx, A[which], rhs, z, dinv[which], pc, cfg->inner_rtol, cfg->inner_atol, cfg->inner_max_it,
-                     warm, r, zz, p, q, S_INNER, &ko, nullptr, 0, warm ? bnorm_cache[which] : -1.0));
+                     warm, r, zz, p, q, S_INNER, &ko, nullptr, 0, warm ? bnorm_cache[which] : -1.0,
+                     cfg->inner_reduction));
     if (!warm) bnorm_cache[which] = ko.bnorm;
     last_resid = r;
     total_its += ko.its;
@@ -347,6 +350,7 @@ static int validate_cfg(pph_ctx* ctx, const pph_solver_cfg* cfg) {
   PPH_REQUIRE(ctx, cfg->restart >= 1 && cfg->restart <= 30, "GMRES restart %d outside [1,30]", cfg->restart);
   PPH_REQUIRE(ctx, cfg->max_it >= 0 && cfg->inner_max_it >= 0 && cfg->picard_max_it >= 0, "negative max_it");
   PPH_REQUIRE(ctx, cfg->rtol >= 0 && cfg->atol >= 0 && cfg->inner_rtol >= 0 && cfg->inner_atol >= 0, "negative tolerance");
+  PPH_REQUIRE(ctx, cfg->inner_reduction >= 0 && cfg->inner_reduction < 1, "inner_reduction must be in [0,1)");
   PPH_REQUIRE(ctx, cfg->inner_ksp_type == PPH_KSP_PREONLY || cfg->inner_ksp_type == PPH_KSP_CG,
               "inner ksp_type %d not supported (preonly, cg)", cfg->inner_ksp_type);
   if (!cfg->picard) {
