@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--inner-rtol", type=float, default=1e-10)
     ap.add_argument("--smooth", type=int, default=1)
     ap.add_argument("--inner-reduction", type=float, default=1e-2)
-    ap.add_argument("--asm-kernel", type=int, default=1)
+    ap.add_argument("--asm-kernel", type=int, default=2)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

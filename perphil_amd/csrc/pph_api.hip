@@ -408,7 +408,7 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
   }
   if (!strcmp(name, "asm_kernel")) {
     const int v = (int)value;
-    PPH_REQUIRE(ctx, v == 0 || v == 1, "asm_kernel: 0 cell-centred scatter-add (atomics), 1 node-centred gather");
+    PPH_REQUIRE(ctx, v >= 0 && v <= 2, "asm_kernel: 0 cell-centred scatter-add (atomics), 1 node-centred gather, 2 two-pass gather");
     ctx->asm_kernel = v;
     ctx->mesh.km_valid = false;
     for (auto& L : ctx->mg) L.mesh.km_valid = false;

@@ -442,12 +442,233 @@ __global__ __launch_bounds__(256) void k_asm_gather(const int32_t* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Two-pass deterministic assembly for multilinear cells (default).
+// Pass 1 (cell-centred): lane (cell, q) evaluates the Jacobian, its inverse and the physical basis
+// gradients at ONE Gauss point and shares them through LDS; lane (cell, a) then contracts them into row a
+// of K_e and M_e and streams the row (16 doubles) to an element-matrix buffer.  The Jacobian work is done
+// once per (cell, Gauss point) instead of once per (cell, row, Gauss point).
+// Pass 2 (node-centred): the 2^d lanes of a node fetch the rows that belong to it from its incident cells
+// and sum matching columns into the CSR row in a fixed order: no atomics, bitwise reproducible, every
+// CSR entry written once.
+// ------------------------------------------------------------------------------------------------
+template <int DIM>
+__global__ __launch_bounds__(256) void k_elem_rows(const int32_t* __restrict__ cells, const double* __restrict__ cx,
+                                                   const double* __restrict__ cy, const double* __restrict__ cz,
+                                                   double* __restrict__ erows, int64_t ncell) {
+  constexpr int NB = 1 << DIM;
+  constexpr int CPB = 256 / NB;
+  __shared__ double sN[NB][NB];
+  __shared__ double sdN[NB][NB][DIM];
+  __shared__ double sX[CPB][NB][DIM];
+  __shared__ double sG[CPB][NB][NB][DIM];  // [cell][q][b][d] physical gradients
+  __shared__ double sW[CPB][NB];           // [cell][q] |det J| (Gauss weights are 1)
+  const int tid = threadIdx.x;
+  const int lc = tid / NB, a = tid % NB;
+  if (tid < NB * NB) {
+    const int q = tid / NB, b = tid % NB;
+    const double gp = 0.57735026918962576451;
+    double xi[DIM], sg[DIM];
+#pragma unroll
+    for (int e = 0; e < DIM; ++e) {
+      xi[e] = ((q >> e) & 1) ? gp : -gp;
+      sg[e] = ((b >> e) & 1) ? 1.0 : -1.0;
+    }
+    double nv = 1.0;
+#pragma unroll
+    for (int e = 0; e < DIM; ++e) nv *= 0.5 * (1.0 + sg[e] * xi[e]);
+    sN[q][b] = nv;
+#pragma unroll
+    for (int e = 0; e < DIM; ++e) {
+      double d = 1.0;
+#pragma unroll
+      for (int f = 0; f < DIM; ++f) d *= (f == e) ? 0.5 * sg[f] : 0.5 * (1.0 + sg[f] * xi[f]);
+      sdN[q][b][e] = d;
+    }
+  }
+  const int64_t nbatch = (ncell + CPB - 1) / CPB;
+  for (int64_t batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+    __syncthreads();
+    const int64_t cell = batch * CPB + lc;
+    const bool valid = cell < ncell;
+    if (valid) {
+      const int32_t node = cells[cell * NB + a];
+      sX[lc][a][0] = cx[node];
+      sX[lc][a][1] = cy[node];
+      if constexpr (DIM == 3) sX[lc][a][2] = cz[node];
+    }
+    __syncthreads();
+    if (valid) {
+      const int q = a;  // this lane's Gauss point
+      double J[DIM][DIM];
+#pragma unroll
+      for (int e = 0; e < DIM; ++e)
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) J[e][d] = 0.0;
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int e = 0; e < DIM; ++e)
+#pragma unroll
+          for (int d = 0; d < DIM; ++d) J[e][d] += sdN[q][b][e] * sX[lc][b][d];
+      double det, I[DIM][DIM];
+      if constexpr (DIM == 2) {
+        det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+        const double r = 1.0 / det;
+        I[0][0] = J[1][1] * r;  I[0][1] = -J[0][1] * r;
+        I[1][0] = -J[1][0] * r; I[1][1] = J[0][0] * r;
+      } else {
+        const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+        const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+        const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+        det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+        const double r = 1.0 / det;
+        I[0][0] = c00 * r;
+        I[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
+        I[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
+        I[1][0] = c01 * r;
+        I[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
+        I[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
+        I[2][0] = c02 * r;
+        I[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
+        I[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
+      }
+      sW[lc][q] = fabs(det);
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) {
+          double g = 0.0;
+#pragma unroll
+          for (int e = 0; e < DIM; ++e) g += I[d][e] * sdN[q][b][e];
+          sG[lc][q][b][d] = g;
+        }
+    }
+    __syncthreads();
+    if (valid) {
+      double Kr[NB], Mr[NB];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) { Kr[b] = 0.0; Mr[b] = 0.0; }
+#pragma unroll 2
+      for (int q = 0; q < NB; ++q) {
+        const double w = sW[lc][q];
+        double ga[DIM];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) ga[d] = w * sG[lc][q][a][d];
+        const double na = w * sN[q][a];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          double dotg = 0.0;
+#pragma unroll
+          for (int d = 0; d < DIM; ++d) dotg += ga[d] * sG[lc][q][b][d];
+          Kr[b] += dotg;
+          Mr[b] += na * sN[q][b];
+        }
+      }
+      double* out = erows + (cell * NB + a) * (2 * NB);
+#pragma unroll
+      for (int b = 0; b < NB; b += 2) {
+        *reinterpret_cast<double2*>(out + b) = make_double2(Kr[b], Kr[b + 1]);
+        *reinterpret_cast<double2*>(out + NB + b) = make_double2(Mr[b], Mr[b + 1]);
+      }
+    }
+  }
+}
+
+template <int DIM>
+__global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__ cells,
+                                                     const double* __restrict__ erows,
+                                                     const int64_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ col, double* __restrict__ K,
+                                                     double* __restrict__ M, int nx, int ny, int nzl, int px, int py,
+                                                     int64_t n) {
+  constexpr int NB = 1 << DIM;
+  constexpr int NPB = 256 / NB;
+  __shared__ double sK[NPB][NB][NB + 1];  // +1: rows of different incident cells land in different banks
+  __shared__ double sM[NPB][NB][NB + 1];
+  __shared__ int32_t sC[NPB][NB][NB];
+  const int tid = threadIdx.x;
+  const int ln = tid / NB, c = tid % NB;
+  const int64_t nbatch = (n + NPB - 1) / NPB;
+  for (int64_t batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+    __syncthreads();
+    const int64_t node = batch * NPB + ln;
+    const bool valid = node < n;
+    int64_t cell = -1;
+    if (valid) {
+      const int i = (int)(node % px);
+      const int64_t t = node / px;
+      const int j = (int)(t % py), k = (int)(t / py);
+      const int ci = i - (c & 1), cj = j - ((c >> 1) & 1), ck = (DIM == 3) ? k - ((c >> 2) & 1) : 0;
+      const bool inb = ci >= 0 && ci < nx && cj >= 0 && cj < ny && (DIM == 2 || (ck >= 0 && ck < nzl));
+      if (inb) cell = ci + (int64_t)nx * (cj + (int64_t)ny * ck);
+    }
+    if (cell >= 0) {
+      // the node is local vertex c of this cell (checked against the cell->dof map below)
+      const double* in = erows + (cell * NB + c) * (2 * NB);
+      const int32_t* cn = cells + cell * NB;
+      const bool ok = cn[c] == (int32_t)node;
+#pragma unroll
+      for (int b = 0; b < NB; b += 2) {
+        const double2 kk = *reinterpret_cast<const double2*>(in + b);
+        const double2 mm = *reinterpret_cast<const double2*>(in + NB + b);
+        sK[ln][c][b] = kk.x; sK[ln][c][b + 1] = kk.y;
+        sM[ln][c][b] = mm.x; sM[ln][c][b + 1] = mm.y;
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b) sC[ln][c][b] = ok ? cn[b] : -1;
+    } else {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) sC[ln][c][b] = -1;
+    }
+    __syncthreads();
+    if (valid) {
+      const int64_t s = rowptr[node], e = rowptr[node + 1];
+      for (int64_t k = s + c; k < e; k += NB) {
+        const int32_t j = col[k];
+        double kv = 0.0, mv = 0.0;
+#pragma unroll 1
+        for (int cc = 0; cc < NB; ++cc)
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            const bool hit = sC[ln][cc][b] == j;
+            kv += hit ? sK[ln][cc][b] : 0.0;
+            mv += hit ? sM[ln][cc][b] : 0.0;
+          }
+        K[k] = kv;
+        M[k] = mv;
+      }
+    }
+  }
+}
+
 int pph_launch_assemble_KM(pph_ctx* ctx_, MeshData& mesh) {
   pph_ctx* ctx = ctx_;
   PPH_TRY(mesh.K.alloc(ctx, (size_t)mesh.nnzb));
   PPH_TRY(mesh.M.alloc(ctx, (size_t)mesh.nnzb));
   const int64_t ncell = mesh.ncell;
   const bool multilinear = (mesh.kind == PPH_CELL_QUAD || mesh.kind == PPH_CELL_HEX);
+  if (multilinear && ctx->asm_kernel == 2) {
+    // two-pass: element rows to a buffer (Jacobians shared through LDS), then node-centred gather
+    PPH_TRY(mesh.erows.alloc(ctx, (size_t)ncell * mesh.m * 2 * mesh.m));
+    const int cpb = 256 / mesh.m;
+    int64_t nb1 = ceil_div64(ncell, cpb), nb2 = ceil_div64(mesh.n, cpb);
+    int g1 = (int)(nb1 < 256 * 16 ? nb1 : 256 * 16), g2 = (int)(nb2 < 256 * 16 ? nb2 : 256 * 16);
+    if (mesh.kind == PPH_CELL_QUAD) {
+      hipLaunchKernelGGL(k_elem_rows<2>, dim3(g1), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p, mesh.cy.p,
+                         mesh.cz.p, mesh.erows.p, ncell);
+      hipLaunchKernelGGL(k_gather_rows<2>, dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
+                         mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, mesh.nx, mesh.ny, 0, mesh.px, mesh.py, mesh.n);
+    } else {
+      hipLaunchKernelGGL(k_elem_rows<3>, dim3(g1), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p, mesh.cy.p,
+                         mesh.cz.p, mesh.erows.p, ncell);
+      hipLaunchKernelGGL(k_gather_rows<3>, dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
+                         mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, mesh.nx, mesh.ny, mesh.nzl, mesh.px, mesh.py,
+                         mesh.n);
+    }
+    PPH_HIP(ctx, hipGetLastError());
+    return PPH_OK;
+  }
   if (multilinear && ctx->asm_kernel == 1) {
     // node-centred gather: writes every entry once, no memset, no atomics
     const int npb = 256 / mesh.m;

@@ -78,10 +78,11 @@ struct MeshData {
   DevBuf<int64_t> rowptr;               // scalar CSR pattern
   DevBuf<int32_t> col;
   DevBuf<double> K, M;                  // scalar stiffness / mass values
+  DevBuf<double> erows;                 // element-matrix rows [cell][a][K row | M row] of the two-pass assembly
   int64_t plane() const { return (int64_t)px * py; }
   int64_t own_begin() const { return glo ? plane() : 0; }           // owned entries = [own_begin, own_end)
   int64_t own_end() const { return n - (ghi ? plane() : 0); }
-  void release_geometry() { cx.release(); cy.release(); cz.release(); cells.release(); K.release(); M.release(); }
+  void release_geometry() { cx.release(); cy.release(); cz.release(); cells.release(); K.release(); M.release(); erows.release(); }
   void release_all() { release_geometry(); rowptr.release(); col.release(); }
 };
 
@@ -157,7 +158,7 @@ struct pph_ctx {
   std::vector<EvPair> ev_pool;          // reusable event pairs
   size_t ev_used = 0;                   // pairs recorded since the last harvest
   int spmv_lanes_override = 0;          // 0: pick from the mean row length
-  int asm_kernel = 1;                   // multilinear cells: 1 node-centred gather (deterministic), 0 cell-centred scatter-add
+  int asm_kernel = 2;                   // multilinear cells: 2 two-pass (element rows + node gather, default), 1 one-pass node gather, 0 cell-centred atomic scatter-add
   int spmv_kernel = 3;                  // 3: aligned-wide CSR-vector (default); 0,1,2,4..8,10: variants kept for A/B runs
 };
 

@@ -20,7 +20,7 @@ enum {
   W_GV, W_GW, W_GT,                     // GMRES basis / work
   W_FS1, W_FS2,                         // field-split temporaries
   W_DINV_M, W_DINV_1, W_DINV_2, W_BINV, // preconditioner data
-  W_DU, W_PB, W_T12, W_R1,              // Picard correction, block rhs, coupling term, macro residual
+  W_DU, W_PB, W_T12, W_TN, W_RHS1, W_R1, W_R2,  // Picard: correction, block rhs, coupling terms, block residuals
   W_COUNT
 };
 
@@ -70,7 +70,7 @@ static Csr mono_csr(pph_ctx* ctx) {
 static int cg_solve(pph_ctx* ctx, const Csr& A, const double* b, double* x, const double* dinv, const ApplyFn& pc,
                     double rtol, double atol, int max_it, bool warm, double* r, double* z, double* p, double* q,
                     int slot, KspOut* out, double* hist, int hist_cap, double bnorm_hint = -1.0,
-                    double reduction = 0.0) {
+                    double reduction = 0.0, const double* r_init = nullptr) {
   const int64_t n = A.nrows;
   // reductions run over the owned entries of a slab (whole vector on a single GPU)
   const int64_t ob = A.geom ? A.geom->own_begin() : 0;
@@ -95,7 +95,9 @@ static int cg_solve(pph_ctx* ctx, const Csr& A, const double* b, double* x, cons
       PPH_TRY(la_fetch(ctx, slot, 1));
       bnorm = std::sqrt(ctx->h_scal[slot]);
     }
-    la_spmv_resid(ctx, A, x, b, r);
+    // r_init: the caller already knows b - A x (residual bookkeeping of the Picard sweeps)
+    if (r_init) la_copy(ctx, r, r_init, n);
+    else la_spmv_resid(ctx, A, x, b, r);
   } else {
     la_set(ctx, x, 0.0, n);
     la_copy(ctx, r, b, n);
@@ -304,7 +306,7 @@ struct BlockSolver {
     return PPH_OK;
   }
 
-  int solve(int which, const double* rhs, double* z, bool warm) {
+  int solve(int which, const double* rhs, double* z, bool warm, const double* r_init = nullptr) {
     const int64_t n = ctx->n;
     double *r, *zz, *p, *q;
     PPH_TRY(work(ctx, W_IR, (size_t)n, &r));
@@ -324,7 +326,7 @@ struct BlockSolver {
     }
     PPH_TRY(cg_solve(ctx, A[which], rhs, z, dinv[which], pc, cfg->inner_rtol, cfg->inner_atol, cfg->inner_max_it,
                      warm, r, zz, p, q, S_INNER, &ko, nullptr, 0, warm ? bnorm_cache[which] : -1.0,
-                     cfg->inner_reduction));
+                     cfg->inner_reduction, warm ? r_init : nullptr));
     if (!warm) bnorm_cache[which] = ko.bnorm;
     last_resid = r;
     total_its += ko.its;
@@ -401,55 +403,66 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
     double res = r0;
     if (hist && hist_cap > 0) hist[0] = res;
     int its = 0;
-    // t12 holds A12 du2 of the previous sweep (zero at the start): it is both the coupling term of the
-    // next macro solve and what turns the macro CG's recurrence residual into the monolithic one:
-    //   r1 = b1 - A11 du1 - A12 du2_new = r_cg(A11) + A12 du2_old - A12 du2_new ;  r2 = r_cg(A22)
-    double *t12, *r1;
+    // Residual bookkeeping: R0 = b1 - A11 du1 - A12 du2 and R1 = b2 - A21 du1 - A22 du2 are carried along.
+    // A block solve leaves its CG recurrence residual; when the other block moves, the residual changes by
+    // the change of the coupling term, which the sweep computes anyway (t12 = A12 du2, rhs1 = b2 - A21 du1).
+    // So a sweep costs two coupling SpMVs, the warm-started solves start from a known residual, and
+    // ||(R0, R1)|| is the monolithic residual (confirmed once with a true residual at convergence).
+    double *t12, *tn, *rhs1, *R0, *R1;
     PPH_TRY(work(ctx, W_T12, (size_t)n, &t12));
-    PPH_TRY(work(ctx, W_R1, (size_t)n, &r1));
+    PPH_TRY(work(ctx, W_TN, (size_t)n, &tn));
+    PPH_TRY(work(ctx, W_RHS1, (size_t)n, &rhs1));
+    PPH_TRY(work(ctx, W_R1, (size_t)n, &R0));
+    PPH_TRY(work(ctx, W_R2, (size_t)n, &R1));
     la_set(ctx, t12, 0.0, n);
     const bool recur = (cfg->inner_ksp_type == PPH_KSP_CG);
     const int64_t pob = ctx->mesh.own_begin(), pon = ctx->mesh.own_end() - ctx->mesh.own_begin();
-    while (res > tol && its < cfg->picard_max_it) {
-      la_sub(ctx, pb, b1, t12, n);
-      PPH_TRY(bs.solve(0, pb, du1, its > 0));
-      if (recur) {  // r1 = r_cg + A12 du2_old
-        la_copy(ctx, r1, bs.last_resid, n);
-        la_axpy(ctx, r1, 1.0, t12, n);
-      }
-      la_spmv_resid(ctx, A21, du1, b2, pb);
-      PPH_TRY(bs.solve(1, pb, du2, its > 0));
-      ++its;
-      la_spmv(ctx, A12, du2, t12);
-      if (recur) {
-        la_axpy(ctx, r1, -1.0, t12, n);
-        la_dot(ctx, r1 + pob, r1 + pob, pon, S_A);
-        la_dot(ctx, bs.last_resid + pob, bs.last_resid + pob, pon, S_A + 1);
-      } else {
-        // inner "solves" without a residual recurrence (preonly): evaluate the monolithic residual
-        la_spmv_resid(ctx, bs.A[0], du1, b1, r1);
-        la_axpy(ctx, r1, -1.0, t12, n);
-        la_dot(ctx, r1 + pob, r1 + pob, pon, S_A);
-        la_spmv_resid(ctx, A21, du1, b2, r1);
-        la_spmv(ctx, bs.A[1], du2, t);
-        la_axpy(ctx, r1, -1.0, t, n);
-        la_dot(ctx, r1 + pob, r1 + pob, pon, S_A + 1);
-      }
+    auto true_residual = [&]() -> int {
+      la_spmv_resid(ctx, bs.A[0], du1, b1, R0);
+      la_axpy(ctx, R0, -1.0, t12, n);
+      la_spmv_resid(ctx, A21, du1, b2, R1);
+      la_spmv(ctx, bs.A[1], du2, t);
+      la_axpy(ctx, R1, -1.0, t, n);
+      la_dot(ctx, R0 + pob, R0 + pob, pon, S_A);
+      la_dot(ctx, R1 + pob, R1 + pob, pon, S_A + 1);
       PPH_TRY(la_fetch(ctx, S_A, 2));
       res = std::sqrt(ctx->h_scal[S_A] + ctx->h_scal[S_A + 1]);
+      return PPH_OK;
+    };
+    while (res > tol && its < cfg->picard_max_it) {
+      const bool warm = its > 0;
+      la_sub(ctx, pb, b1, t12, n);                                   // rhs of the macro block
+      PPH_TRY(bs.solve(0, pb, du1, warm, (warm && recur) ? R0 : nullptr));
+      if (recur) la_copy(ctx, R0, bs.last_resid, n);
+      if (warm && recur) {
+        la_spmv_resid(ctx, A21, du1, b2, tn);                        // new rhs of the micro block
+        la_axpy(ctx, R1, 1.0, tn, n);                                // R1 += rhs1_new - rhs1_old
+        la_axpy(ctx, R1, -1.0, rhs1, n);
+        la_copy(ctx, rhs1, tn, n);
+      } else {
+        la_spmv_resid(ctx, A21, du1, b2, rhs1);
+      }
+      PPH_TRY(bs.solve(1, rhs1, du2, warm, (warm && recur) ? R1 : nullptr));
+      if (recur) la_copy(ctx, R1, bs.last_resid, n);
+      ++its;
+      la_spmv(ctx, A12, du2, tn);                                    // new coupling term
+      if (recur) {
+        la_axpy(ctx, R0, 1.0, t12, n);                               // R0 += A12 du2_old - A12 du2_new
+        la_axpy(ctx, R0, -1.0, tn, n);
+        la_copy(ctx, t12, tn, n);
+        la_dot(ctx, R0 + pob, R0 + pob, pon, S_A);
+        la_dot(ctx, R1 + pob, R1 + pob, pon, S_A + 1);
+        PPH_TRY(la_fetch(ctx, S_A, 2));
+        res = std::sqrt(ctx->h_scal[S_A] + ctx->h_scal[S_A + 1]);
+      } else {
+        la_copy(ctx, t12, tn, n);
+        PPH_TRY(true_residual());
+      }
       if (hist && its < hist_cap) hist[its] = res;
       if (!(res == res)) break;
       if (res <= tol && recur) {
-        // confirm with the true residual once; keep sweeping if the recurrence was optimistic
-        la_spmv_resid(ctx, bs.A[0], du1, b1, r1);
-        la_axpy(ctx, r1, -1.0, t12, n);
-        la_dot(ctx, r1 + pob, r1 + pob, pon, S_A);
-        la_spmv_resid(ctx, A21, du1, b2, r1);
-        la_spmv(ctx, bs.A[1], du2, t);
-        la_axpy(ctx, r1, -1.0, t, n);
-        la_dot(ctx, r1 + pob, r1 + pob, pon, S_A + 1);
-        PPH_TRY(la_fetch(ctx, S_A, 2));
-        res = std::sqrt(ctx->h_scal[S_A] + ctx->h_scal[S_A + 1]);
+        // confirm with the true residual once; keep sweeping if the recurrences were optimistic
+        PPH_TRY(true_residual());
         if (hist && its < hist_cap) hist[its] = res;
       }
     }

@@ -109,7 +109,7 @@ def test_scatter_and_gather_assembly_agree(gpu_ctx_factory, nx, ny, nz):
     om = o.build_mesh(dim, kind, nx, ny, nz)
     Ko, Mo = o.assemble_scalar(om)
     res = {}
-    for mode in (0, 1, 1):
+    for mode in (0, 1, 1, 2, 2):
         ctx = gpu_ctx_factory()
         ctx.mesh_build(dim, kind, nx, ny, nz)
         ctx.set_option("asm_kernel", mode)
@@ -122,6 +122,8 @@ def test_scatter_and_gather_assembly_agree(gpu_ctx_factory, nx, ny, nz):
         res.setdefault(mode, []).append((K.data.copy(), M.data.copy()))
     np.testing.assert_array_equal(res[1][0][0], res[1][1][0])   # bitwise reproducible
     np.testing.assert_array_equal(res[1][0][1], res[1][1][1])
+    np.testing.assert_array_equal(res[2][0][0], res[2][1][0])
+    np.testing.assert_array_equal(res[2][0][1], res[2][1][1])
 
 
 @pytest.mark.parametrize("dim,kind,nx,ny,nz", CASES)

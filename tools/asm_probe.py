@@ -6,7 +6,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 ctx = _ffi.Context(0); ctx.mesh_build(3, _ffi.CELL_HEX, N, N, N)
 b, g1, g2 = bench.mms_boundary(N, 1.0, 1e-2, 1.0, 1.0)
 ctx.set_dirichlet(0, b, g1); ctx.set_dirichlet(1, b, g2)
-for mode in (0, 1, 0, 1):
+for mode in (0, 1, 2, 0, 1, 2):
     ctx.set_option("asm_kernel", mode)
     for rep in range(3):
         ctx.set_option("invalidate_KM", 1)
