@@ -56,7 +56,7 @@ def mms_boundary(n_cells, k1, k2, beta, mu):
     return b, p1(X), p2(X)
 
 
-def cpu_baseline(sample_n, k1, k2, beta, mu):
+def cpu_baseline(sample_n, k1, k2, beta, mu, smooth=1, reduction=1e-2, inner_rtol=1e-10):
     """The oracle (CPU port of the same algorithm: assembly + Picard with multigrid-CG block solves)
     timed on one host core on a smaller cube; returns DoF/s."""
     from oracle import dpp_oracle as o
@@ -82,15 +82,18 @@ def cpu_baseline(sample_n, k1, k2, beta, mu):
     res, its = r0, 0
     while res > max(1e-8 * r0, 1e-12) and its < 100:
         x0 = du[:n].copy() if its else None
-        du[:n] = o.pcg(A11, rhs[:n] - A12 @ du[n:], lambda v: mgo.vcycle(L1, v, 2), rtol=1e-10, x0=x0).x
+        du[:n] = o.pcg(A11, rhs[:n] - A12 @ du[n:], lambda v: mgo.vcycle(L1, v, smooth), rtol=inner_rtol, x0=x0,
+                       reduction=reduction).x
         x0 = du[n:].copy() if its else None
-        du[n:] = o.pcg(A22, rhs[n:] - A21 @ du[:n], lambda v: mgo.vcycle(L2, v, 2), rtol=1e-10, x0=x0).x
+        du[n:] = o.pcg(A22, rhs[n:] - A21 @ du[:n], lambda v: mgo.vcycle(L2, v, smooth), rtol=inner_rtol, x0=x0,
+                       reduction=reduction).x
         its += 1
         res = np.linalg.norm(rhs - A @ du)
     t = time.perf_counter() - t0
     return {"value": 2 * n / t, "unit": "DoF/s", "cores": 1, "kind": "port",
-            "sample": f"{sample_n}^3 Q1 unit cube ({2 * n} DoF), assemble + Picard ({its} sweeps) with multigrid-CG "
-                      f"block solves in NumPy/SciPy, {t:.1f} s (mesh build {t_mesh:.1f} s excluded)"}
+            "sample": f"{sample_n}^3 Q1 unit cube ({2 * n} DoF), same algorithm (assemble + inexact Picard, {its} sweeps, "
+                      f"V({smooth},{smooth}) multigrid-CG block solves, reduction {reduction:g}) in NumPy/SciPy, {t:.1f} s "
+                      f"(mesh build {t_mesh:.1f} s excluded)"}
 
 
 def main():
@@ -99,12 +102,13 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cells", type=int, default=256, help="cells per direction of the unit cube")
-    ap.add_argument("--cpu-sample-n", type=int, default=48)
+    ap.add_argument("--cpu-sample-n", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--inner-rtol", type=float, default=1e-10)
     ap.add_argument("--smooth", type=int, default=1)
     ap.add_argument("--inner-reduction", type=float, default=1e-2)
     ap.add_argument("--asm-kernel", type=int, default=2)
+    ap.add_argument("--skip-fine-bench", action="store_true", help="omit the isolated fine-level SpMV loop (PMC passes)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -190,17 +194,27 @@ def main():
     byts = tr["spmv_bytes"] + tr["spmv_dot_bytes"]
     achieved = (byts / 1e9) / (ms / 1e3) if ms > 0 else 0.0
     # fine-level scalar-block SpMV alone (the inner loop the 50 % target is stated on)
-    fine_ms = ctx.spmv_bench(_ffi.MAT_A11, 50)
     fine_bytes = 12.0 * ctx.nnzb + 20.0 * ctx.n
+    fine_ms = float("nan") if args.skip_fine_bench else ctx.spmv_bench(_ffi.MAT_A11, 50)
+    # HBM traffic of the same kernel mix from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB),
+    # measured offline with tools/pmc_summarize.py and committed under profiles/ (cannot be sampled in-process)
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_spmv_bench256.json")
+    if os.path.exists(pmc_file) and N == 256 and world == 1:
+        try:
+            with open(pmc_file) as f:
+                traffic = json.load(f).get("traffic_bytes_per_launch")
+        except (OSError, ValueError):
+            traffic = None
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
         "kernel": "k_spmv_wide<8,*,2> (aligned-wide CSR-vector SpMV, all multigrid levels of one step)",
         "launches_per_step": int(launches), "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
         "algorithmic_bytes_per_launch": round(byts / max(launches, 1), 0),
-        "fine_level": {"avg_launch_ms": round(fine_ms, 4), "algorithmic_bytes": fine_bytes,
-                       "achieved": round(fine_bytes / 1e9 / (fine_ms / 1e3), 1),
-                       "frac": round(fine_bytes / 1e9 / (fine_ms / 1e3) / HBM_PEAK_GBS, 4)},
+        "fine_level": {"avg_launch_ms": round(fine_ms, 4) if fine_ms == fine_ms else None, "algorithmic_bytes": fine_bytes,
+                       "achieved": round(fine_bytes / 1e9 / (fine_ms / 1e3), 1) if fine_ms == fine_ms else None,
+                       "frac": round(fine_bytes / 1e9 / (fine_ms / 1e3) / HBM_PEAK_GBS, 4) if fine_ms == fine_ms else None},
     }
 
     out = {
@@ -218,8 +232,9 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"3D UnitCube {N}^3 Q1, two-pressure DPP (k1=1, k2=1e-2, beta=mu=1), manufactured Dirichlet data, "
-                        f"assemble + block Picard (fixed-stress) to snes_rtol 1e-8, block solves = CG + geometric multigrid "
-                        f"(Chebyshev-Jacobi V({args.smooth},{args.smooth})) to rtol {args.inner_rtol:g} on CSR blocks",
+                        f"assemble + block Picard (fixed-stress) to snes_rtol 1e-8 (true residual), warm-started block solves = "
+                        f"CG + geometric multigrid (Chebyshev-Jacobi V({args.smooth},{args.smooth})) on CSR blocks, each to a "
+                        f"residual reduction of {args.inner_reduction:g} (or rtol {args.inner_rtol:g})",
             "cells": N ** 3, "dofs": int(dofs_global), "parallelism": f"slab{world}" if world > 1 else "single",
             "picard_sweeps": int(info.iterations), "inner_cg_iterations": int(info.inner_iterations),
             "picard_ms_per_sweep": round(tm["solve_ms"] / max(int(info.iterations), 1), 3),
@@ -230,7 +245,8 @@ def main():
         "roofline": roofline,
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, k1, k2, beta, mu)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, k1, k2, beta, mu, args.smooth, args.inner_reduction,
+                                           args.inner_rtol)
     elif rank == 0:
         out["cpu_baseline"] = None
     if dist is not None:

@@ -353,15 +353,16 @@ def gmres(A, b, M_apply: Optional[Callable] = None, rtol=1e-8, atol=1e-12, max_i
 
 
 def pcg(A, b, M_apply: Optional[Callable] = None, rtol=1e-8, atol=1e-12, max_it=50000,
-        x0: Optional[np.ndarray] = None) -> KspResult:
-    """Preconditioned CG, PETSc default norm: preconditioned residual ||z||_2."""
+        x0: Optional[np.ndarray] = None, reduction: float = 0.0) -> KspResult:
+    """Preconditioned CG, PETSc default norm: preconditioned residual ||z||_2.  ``reduction`` > 0 also accepts a
+    drop of the residual by that factor from its value at the start of this solve (inexact Picard sweeps)."""
     prec = (lambda v: v) if M_apply is None else M_apply
     x = np.zeros_like(b) if x0 is None else x0.copy()
     r = b - A @ x if x0 is not None else b.copy()
     z = prec(r)
     z0 = prec(b) if x0 is not None else z
-    tol = max(rtol * float(np.linalg.norm(z0)), atol)
     res = float(np.linalg.norm(z))
+    tol = max(rtol * float(np.linalg.norm(z0)), atol, reduction * res)
     hist = [res]
     if res <= tol:
         return KspResult(x, 0, res, hist, True)
