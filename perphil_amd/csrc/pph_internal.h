@@ -51,6 +51,9 @@ struct DevBuf {
   void release();
 };
 
+// index set of a reduction: [off1, off1+len1) U [off2, off2+len2) (owned entries of one or two fields)
+struct Seg { int64_t off1, len1, off2, len2; };
+
 struct MeshData;
 struct Csr {  // device CSR view (no ownership)
   const int64_t* rowptr = nullptr;
@@ -193,6 +196,8 @@ void la_sub(pph_ctx* ctx, double* z, const double* a, const double* b, int64_t n
 void la_block2_apply(pph_ctx* ctx, double* z, const double* binv /*[4][n]*/, const double* r, int64_t n);
 // k dots in one pass: out[slot+i] = dot(V_i, w), i < k  (V_i = V + i*ld)
 void la_mdot(pph_ctx* ctx, const double* V, int64_t ld, int k, const double* w, int64_t n, int slot);
+void la_mdot_seg(pph_ctx* ctx, const double* V, int64_t ld, int k, const double* w, Seg sg, int slot);
+void la_dot2_seg(pph_ctx* ctx, const double* x, const double* y, const double* z, Seg sg, int slot);
 // w -= sum_i h[i] V_i   (h on host)
 void la_maxpy_neg(pph_ctx* ctx, double* w, const double* V, int64_t ld, int k, const double* h, int64_t n);
 // x += sum_i y[i] V_i
@@ -202,7 +207,7 @@ void la_dot2(pph_ctx* ctx, const double* x, const double* y, const double* z, in
 // fused CG update with Jacobi-type PC: x += alpha p; r -= alpha q; z = dinv.*r (dinv may be null: z=r);
 // scal[slot] = r.z, scal[slot+1] = z.z
 void la_cg_update(pph_ctx* ctx, double* x, double* r, double* z, const double* p, const double* q,
-                  const double* dinv, double alpha, int64_t n, int slot, int64_t own_begin = 0, int64_t own_end = -1);
+                  const double* dinv, double alpha, int64_t n, int slot, Seg sg);
 void la_extract_diag_inv(pph_ctx* ctx, const Csr& A, double* dinv);
 // fetch `count` reduction results starting at slot into ctx->h_scal (synchronises the stream)
 int la_fetch(pph_ctx* ctx, int slot, int count);
@@ -231,5 +236,14 @@ void mg_release(pph_ctx* ctx);
 void mg_vcycle(pph_ctx* ctx, int which, const double* r, double* z, int nsmooth);
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// owned index set of a vector of `nrows` entries living on slab geometry g (null: everything)
+static inline Seg pph_owned_seg(const MeshData* g, int64_t nrows) {
+  Seg s;
+  if (!g) { s.off1 = 0; s.len1 = nrows; s.off2 = 0; s.len2 = 0; return s; }
+  s.off1 = g->own_begin(); s.len1 = g->own_end() - g->own_begin();
+  if (nrows == 2 * g->n) { s.off2 = g->n + s.off1; s.len2 = s.len1; } else { s.off2 = 0; s.len2 = 0; }
+  return s;
+}
 
 #define PPH_MAX_SCAL 4096  // reduction slots in ctx->scal

@@ -114,10 +114,11 @@ __global__ __launch_bounds__(256) void k_spmv_wide(const int64_t* __restrict__ r
   const int bpx = gridDim.x >> 3;
   const int64_t cpx = (nchunks + 7) >> 3;
   // MODE 2 (experiment): plain grid-stride chunk order instead of one contiguous eighth per XCD
-  const int64_t c_begin = (MODE == 2) ? 0 : (int64_t)xcd * cpx;
-  const int64_t c_end = (MODE == 2) ? nchunks : ((c_begin + cpx < nchunks) ? c_begin + cpx : nchunks);
-  const int64_t c_first = (MODE == 2) ? blockIdx.x : c_begin + bx;
-  const int64_t c_step = (MODE == 2) ? gridDim.x : bpx;
+  constexpr bool LINEAR = (MODE == 2 || MODE == 3);
+  const int64_t c_begin = LINEAR ? 0 : (int64_t)xcd * cpx;
+  const int64_t c_end = LINEAR ? nchunks : ((c_begin + cpx < nchunks) ? c_begin + cpx : nchunks);
+  const int64_t c_first = LINEAR ? blockIdx.x : c_begin + bx;
+  const int64_t c_step = LINEAR ? gridDim.x : bpx;
   double acc = 0.0;
   for (int64_t ch = c_first; ch < c_end; ch += c_step) {
     const int64_t row = ch * RPB + grp;
@@ -126,9 +127,22 @@ __global__ __launch_bounds__(256) void k_spmv_wide(const int64_t* __restrict__ r
       const int64_t s = rowptr[row], e = rowptr[row + 1];
       const int32_t safe = 0;  // column used by masked lanes (x[0] is always valid)
       for (int64_t base = (s & ~(int64_t)3) + 4 * sub; base < e; base += 4 * G) {
-        const int4 c = *reinterpret_cast<const int4*>(col + base);
-        const double2 v01 = *reinterpret_cast<const double2*>(val + base);
-        const double2 v23 = *reinterpret_cast<const double2*>(val + base + 2);
+        int4 c;
+        double2 v01, v23;
+        if (MODE == 3) {  // non-temporal matrix stream: keep the L2 for x
+          typedef int v4i __attribute__((ext_vector_type(4)));
+          typedef double v2d __attribute__((ext_vector_type(2)));
+          const v4i cc = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(col + base));
+          const v2d a01 = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(val + base));
+          const v2d a23 = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(val + base + 2));
+          c = make_int4(cc.x, cc.y, cc.z, cc.w);
+          v01 = make_double2(a01.x, a01.y);
+          v23 = make_double2(a23.x, a23.y);
+        } else {
+          c = *reinterpret_cast<const int4*>(col + base);
+          v01 = *reinterpret_cast<const double2*>(val + base);
+          v23 = *reinterpret_cast<const double2*>(val + base + 2);
+        }
         const bool k0 = base >= s, k1 = base + 1 >= s && base + 1 < e, k2 = base + 2 >= s && base + 2 < e,
                    k3 = base + 3 < e && base + 3 >= s;
         double x0, x1, x2, x3;
@@ -404,7 +418,10 @@ static int stream_T(int max_row) {
 template <bool DOT>
 static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const double* bvec, double* y, double* part) {
   const int variant = DOT ? 1 : 0;
-  if (A.geom) (void)la_halo(ctx, *A.geom, const_cast<double*>(x));  // ghost planes of x <- owners (slabs only)
+  if (A.geom) {  // ghost planes of x <- owners (slabs only); field-major mixed vectors carry two fields
+    (void)la_halo(ctx, *A.geom, const_cast<double*>(x));
+    if (A.nrows == 2 * A.geom->n) (void)la_halo(ctx, *A.geom, const_cast<double*>(x) + A.geom->n);
+  }
   pph_ctx::EvPair* ev = nullptr;
   if (ctx->time_spmv) {
     if (ctx->ev_used == ctx->ev_pool.size()) {
@@ -456,6 +473,9 @@ static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const doub
       hipLaunchKernelGGL((k_spmv_wide_u<8, DOT, 4>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
     else
       hipLaunchKernelGGL((k_spmv_wide_u<4, DOT, 4>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
+  } else if (ctx->spmv_kernel == 9) {
+    grid = spmv_grid(A.nrows, 256 / 8);
+    hipLaunchKernelGGL((k_spmv_wide<8, DOT, 3>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
   } else if (ctx->spmv_kernel == 10) {
     grid = spmv_grid(A.nrows, 256 / 8);
     hipLaunchKernelGGL((k_spmv_wide<8, DOT, 1>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
@@ -608,12 +628,14 @@ void la_block2_apply(pph_ctx* ctx, double* z, const double* binv, const double* 
 // k dots against one vector in a single pass over w: out[i] = V_i . w
 template <int KB>
 __global__ __launch_bounds__(256) void k_mdot(const double* __restrict__ V, int64_t ld, int k0,
-                                              const double* __restrict__ w, int64_t n, double* __restrict__ part) {
+                                              const double* __restrict__ w, Seg sg, double* __restrict__ part) {
   __shared__ double lds[4];
   double acc[KB];
 #pragma unroll
   for (int q = 0; q < KB; ++q) acc[q] = 0.0;
-  EW_LOOP(i, n) {
+  const int64_t n = sg.len1 + sg.len2;
+  EW_LOOP(ii, n) {
+    const int64_t i = ii < sg.len1 ? sg.off1 + ii : sg.off2 + (ii - sg.len1);
     const double wi = w[i];
 #pragma unroll
     for (int q = 0; q < KB; ++q) acc[q] += V[(int64_t)(k0 + q) * ld + i] * wi;
@@ -626,20 +648,27 @@ __global__ __launch_bounds__(256) void k_mdot(const double* __restrict__ V, int6
 }
 
 void la_mdot(pph_ctx* ctx, const double* V, int64_t ld, int k, const double* w, int64_t n, int slot) {
+  Seg sg;
+  sg.off1 = 0; sg.len1 = n; sg.off2 = 0; sg.len2 = 0;
+  la_mdot_seg(ctx, V, ld, k, w, sg, slot);
+}
+
+void la_mdot_seg(pph_ctx* ctx, const double* V, int64_t ld, int k, const double* w, Seg sg, int slot) {
   double* part = partials(ctx);
+  const int64_t n = sg.len1 + sg.len2;
   int grid = ew_grid(n);
   if (grid > RED_BLOCKS) grid = RED_BLOCKS;
   int k0 = 0;
   while (k0 < k) {
     const int rem = k - k0;
     if (rem >= 4) {
-      hipLaunchKernelGGL(k_mdot<4>, dim3(grid), dim3(256), 0, ctx->stream, V, ld, k0, w, n, part);
+      hipLaunchKernelGGL(k_mdot<4>, dim3(grid), dim3(256), 0, ctx->stream, V, ld, k0, w, sg, part);
       k0 += 4;
     } else if (rem >= 2) {
-      hipLaunchKernelGGL(k_mdot<2>, dim3(grid), dim3(256), 0, ctx->stream, V, ld, k0, w, n, part);
+      hipLaunchKernelGGL(k_mdot<2>, dim3(grid), dim3(256), 0, ctx->stream, V, ld, k0, w, sg, part);
       k0 += 2;
     } else {
-      hipLaunchKernelGGL(k_mdot<1>, dim3(grid), dim3(256), 0, ctx->stream, V, ld, k0, w, n, part);
+      hipLaunchKernelGGL(k_mdot<1>, dim3(grid), dim3(256), 0, ctx->stream, V, ld, k0, w, sg, part);
       k0 += 1;
     }
   }
@@ -649,10 +678,12 @@ void la_mdot(pph_ctx* ctx, const double* V, int64_t ld, int k, const double* w, 
 void la_dot(pph_ctx* ctx, const double* x, const double* y, int64_t n, int slot) { la_mdot(ctx, x, 0, 1, y, n, slot); }
 
 __global__ __launch_bounds__(256) void k_dot2(const double* __restrict__ x, const double* __restrict__ y,
-                                              const double* __restrict__ z, int64_t n, double* __restrict__ part) {
+                                              const double* __restrict__ z, Seg sg, double* __restrict__ part) {
   __shared__ double lds[4];
   double a = 0.0, b = 0.0;
-  EW_LOOP(i, n) {
+  const int64_t n = sg.len1 + sg.len2;
+  EW_LOOP(ii, n) {
+    const int64_t i = ii < sg.len1 ? sg.off1 + ii : sg.off2 + (ii - sg.len1);
     a += x[i] * y[i];
     const double zi = z[i];
     b += zi * zi;
@@ -666,10 +697,17 @@ __global__ __launch_bounds__(256) void k_dot2(const double* __restrict__ x, cons
 }
 
 void la_dot2(pph_ctx* ctx, const double* x, const double* y, const double* z, int64_t n, int slot) {
+  Seg sg;
+  sg.off1 = 0; sg.len1 = n; sg.off2 = 0; sg.len2 = 0;
+  la_dot2_seg(ctx, x, y, z, sg, slot);
+}
+
+void la_dot2_seg(pph_ctx* ctx, const double* x, const double* y, const double* z, Seg sg, int slot) {
   double* part = partials(ctx);
+  const int64_t n = sg.len1 + sg.len2;
   int grid = ew_grid(n);
   if (grid > RED_BLOCKS) grid = RED_BLOCKS;
-  hipLaunchKernelGGL(k_dot2, dim3(grid), dim3(256), 0, ctx->stream, x, y, z, n, part);
+  hipLaunchKernelGGL(k_dot2, dim3(grid), dim3(256), 0, ctx->stream, x, y, z, sg, part);
   hipLaunchKernelGGL(k_reduce_final, dim3(2), dim3(256), 0, ctx->stream, part, grid, ctx->scal.p + slot);
 }
 
@@ -700,8 +738,7 @@ void la_maxpy(pph_ctx* ctx, double* x, const double* V, int64_t ld, int k, const
 __global__ __launch_bounds__(256) void k_cg_update(double* __restrict__ x, double* __restrict__ r,
                                                    double* __restrict__ z, const double* __restrict__ p,
                                                    const double* __restrict__ q, const double* __restrict__ dinv,
-                                                   double alpha, int64_t n, int64_t ob, int64_t oe,
-                                                   double* __restrict__ part) {
+                                                   double alpha, int64_t n, Seg sg, double* __restrict__ part) {
   __shared__ double lds[4];
   double a = 0.0, b = 0.0;
   EW_LOOP(i, n) {
@@ -710,7 +747,7 @@ __global__ __launch_bounds__(256) void k_cg_update(double* __restrict__ x, doubl
     r[i] = ri;
     const double zi = dinv ? dinv[i] * ri : ri;
     z[i] = zi;
-    if (i >= ob && i < oe) {  // reductions over owned entries only (ghost planes belong to a neighbour)
+    if ((i >= sg.off1 && i < sg.off1 + sg.len1) || (i >= sg.off2 && i < sg.off2 + sg.len2)) {  // owned entries only
       a += ri * zi;
       b += zi * zi;
     }
@@ -724,12 +761,11 @@ __global__ __launch_bounds__(256) void k_cg_update(double* __restrict__ x, doubl
 }
 
 void la_cg_update(pph_ctx* ctx, double* x, double* r, double* z, const double* p, const double* q,
-                  const double* dinv, double alpha, int64_t n, int slot, int64_t ob, int64_t oe) {
-  if (oe < 0) { ob = 0; oe = n; }
+                  const double* dinv, double alpha, int64_t n, int slot, Seg sg) {
   double* part = partials(ctx);
   int grid = ew_grid(n);
   if (grid > RED_BLOCKS) grid = RED_BLOCKS;
-  hipLaunchKernelGGL(k_cg_update, dim3(grid), dim3(256), 0, ctx->stream, x, r, z, p, q, dinv, alpha, n, ob, oe, part);
+  hipLaunchKernelGGL(k_cg_update, dim3(grid), dim3(256), 0, ctx->stream, x, r, z, p, q, dinv, alpha, n, sg, part);
   hipLaunchKernelGGL(k_reduce_final, dim3(2), dim3(256), 0, ctx->stream, part, grid, ctx->scal.p + slot);
 }
 

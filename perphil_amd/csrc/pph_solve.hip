@@ -58,6 +58,7 @@ static Csr mono_csr(pph_ctx* ctx) {
   Csr A;
   A.rowptr = ctx->mrowptr.p; A.col = ctx->mcol.p; A.val = ctx->mval.p; A.nrows = 2 * ctx->n; A.nnz = 4 * ctx->nnzb;
   A.max_row = 2 * ctx->mesh.max_row;
+  A.geom = (ctx->world > 1) ? &ctx->mesh : nullptr;
   A.lanes = pph_pick_lanes(ctx, A.nnz, A.nrows);
   return A;
 }
@@ -73,9 +74,7 @@ static int cg_solve(pph_ctx* ctx, const Csr& A, const double* b, double* x, cons
                     double reduction = 0.0, const double* r_init = nullptr) {
   const int64_t n = A.nrows;
   // reductions run over the owned entries of a slab (whole vector on a single GPU)
-  const int64_t ob = A.geom ? A.geom->own_begin() : 0;
-  const int64_t oe = A.geom ? A.geom->own_end() : n;
-  const int64_t on = oe - ob;
+  const Seg sg = pph_owned_seg(A.geom, n);
   const bool fused = (dinv != nullptr) || !pc;
   auto apply_pc = [&](const double* in, double* o) {
     if (dinv) la_pointwise_mult(ctx, o, dinv, in, n);
@@ -91,7 +90,7 @@ static int cg_solve(pph_ctx* ctx, const Csr& A, const double* b, double* x, cons
       bnorm = bnorm_hint;
     } else {
       apply_pc(b, z);
-      la_dot(ctx, z + ob, z + ob, on, slot);
+      la_mdot_seg(ctx, z, 0, 1, z, sg, slot);
       PPH_TRY(la_fetch(ctx, slot, 1));
       bnorm = std::sqrt(ctx->h_scal[slot]);
     }
@@ -104,7 +103,7 @@ static int cg_solve(pph_ctx* ctx, const Csr& A, const double* b, double* x, cons
     bnorm = -1.0;
   }
   apply_pc(r, z);
-  la_dot2(ctx, r + ob, z + ob, z + ob, on, slot);
+  la_dot2_seg(ctx, r, z, z, sg, slot);
   PPH_TRY(la_fetch(ctx, slot, 2));
   double rz = ctx->h_scal[slot];
   double res = std::sqrt(ctx->h_scal[slot + 1]);
@@ -125,12 +124,12 @@ static int cg_solve(pph_ctx* ctx, const Csr& A, const double* b, double* x, cons
     const double alpha = rz / pq;
     double rz_new;
     if (fused) {
-      la_cg_update(ctx, x, r, z, p, q, dinv, alpha, n, slot, ob, oe);
+      la_cg_update(ctx, x, r, z, p, q, dinv, alpha, n, slot, sg);
     } else {
       la_axpy(ctx, x, alpha, p, n);
       la_axpy(ctx, r, -alpha, q, n);
       pc(r, z);
-      la_dot2(ctx, r + ob, z + ob, z + ob, on, slot);
+      la_dot2_seg(ctx, r, z, z, sg, slot);
     }
     PPH_TRY(la_fetch(ctx, slot, 2));
     rz_new = ctx->h_scal[slot];
@@ -161,7 +160,8 @@ int pph_cg_jacobi(pph_ctx* ctx, const Csr& A, const double* b, double* x, const 
 // per step), Givens recurrence on the host
 // ------------------------------------------------------------------------------------------------
 static int gmres_solve(pph_ctx* ctx, const ApplyFn& Aop, int64_t n, const double* b, double* x, const ApplyFn& pc,
-                       int restart, double rtol, double atol, int max_it, KspOut* out, double* hist, int hist_cap) {
+                       int restart, double rtol, double atol, int max_it, KspOut* out, double* hist, int hist_cap,
+                       Seg sg) {
   double *V, *w, *t;
   PPH_TRY(work(ctx, W_GV, (size_t)(restart + 1) * (size_t)n, &V));
   PPH_TRY(work(ctx, W_GW, (size_t)n, &w));
@@ -175,7 +175,7 @@ static int gmres_solve(pph_ctx* ctx, const ApplyFn& Aop, int64_t n, const double
   la_set(ctx, x, 0.0, n);
   // r0 = P^-1 b  (zero initial guess)
   apply_pc(b, V);
-  la_dot(ctx, V, V, n, S_A);
+  la_mdot_seg(ctx, V, 0, 1, V, sg, S_A);
   PPH_TRY(la_fetch(ctx, S_A, 1));
   double beta = std::sqrt(ctx->h_scal[S_A]);
   const double tol = std::fmax(rtol * beta, atol);
@@ -192,7 +192,7 @@ static int gmres_solve(pph_ctx* ctx, const ApplyFn& Aop, int64_t n, const double
       Aop(x, t);
       la_sub(ctx, t, b, t, n);
       apply_pc(t, V);
-      la_dot(ctx, V, V, n, S_A);
+      la_mdot_seg(ctx, V, 0, 1, V, sg, S_A);
       PPH_TRY(la_fetch(ctx, S_A, 1));
       beta = std::sqrt(ctx->h_scal[S_A]);
     }
@@ -207,11 +207,11 @@ static int gmres_solve(pph_ctx* ctx, const ApplyFn& Aop, int64_t n, const double
       double* vk1 = V + (size_t)(k + 1) * n;
       Aop(vk, t);
       apply_pc(t, w);
-      la_mdot(ctx, V, n, k + 1, w, n, S_MDOT);
+      la_mdot_seg(ctx, V, n, k + 1, w, sg, S_MDOT);
       PPH_TRY(la_fetch(ctx, S_MDOT, k + 1));
       for (int i = 0; i <= k; ++i) hcol[i] = ctx->h_scal[S_MDOT + i];
       la_maxpy_neg(ctx, w, V, n, k + 1, hcol.data(), n);
-      la_dot(ctx, w, w, n, S_A);
+      la_mdot_seg(ctx, w, 0, 1, w, sg, S_A);
       PPH_TRY(la_fetch(ctx, S_A, 1));
       const double hn = std::sqrt(ctx->h_scal[S_A]);
       for (int i = 0; i <= k; ++i) Hat(i, k) = hcol[i];
@@ -270,6 +270,10 @@ __global__ void k_block2_build(const int64_t* __restrict__ rowptr, const int32_t
     }
     const double d11 = A11[lo], d22 = A22[lo], d12 = A12[lo], d21 = A21[lo];
     const double det = d11 * d22 - d12 * d21;
+    if (det == 0.0) {  // empty (ghost) rows: identity
+      binv[row] = 1.0; binv[n + row] = 0.0; binv[2 * n + row] = 0.0; binv[3 * n + row] = 1.0;
+      continue;
+    }
     const double r = 1.0 / det;
     binv[row] = d22 * r;          // z1 <- r1
     binv[n + row] = -d12 * r;     // z1 <- r2
@@ -356,7 +360,6 @@ static int validate_cfg(pph_ctx* ctx, const pph_solver_cfg* cfg) {
   PPH_REQUIRE(ctx, cfg->inner_ksp_type == PPH_KSP_PREONLY || cfg->inner_ksp_type == PPH_KSP_CG,
               "inner ksp_type %d not supported (preonly, cg)", cfg->inner_ksp_type);
   if (!cfg->picard) {
-    PPH_REQUIRE(ctx, ctx->world == 1, "slab-decomposed (multi-GPU) solves support the Picard / block-solve path only");
     PPH_REQUIRE(ctx, cfg->pc_type != PPH_PC_MG, "pc_type mg applies to the scalar blocks: use it as inner_pc_type");
     PPH_REQUIRE(ctx, ctx->mono_ok, "monolithic Krylov solve needs pph_assemble_dpp(..., monolithic=1)");
   }
@@ -514,7 +517,7 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
                        r, z, p, q, S_B, &ko, hist, hist_cap));
     } else {
       PPH_TRY(gmres_solve(ctx, Aop, N, ctx->rhs.p, du, pc, cfg->restart, cfg->rtol, cfg->atol, cfg->max_it, &ko, hist,
-                          hist_cap));
+                          hist_cap, pph_owned_seg(A.geom, N)));
     }
     inf.iterations = ko.its;
     inf.inner_iterations = bs.total_its;

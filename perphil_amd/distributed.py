@@ -181,11 +181,12 @@ class SlabSolver:
         cfg.mg_smooth = smooth
         self.cfg = cfg
         self.info = None
+        self.monolithic = False  # True: also materialise the monolithic CSR (monolithic Krylov solves)
 
     def step(self):
         k1, k2, beta, mu = self.params
         self.ctx.set_option("invalidate_KM", 1)
-        self.ctx.assemble(k1, k2, beta, mu, monolithic=False)
+        self.ctx.assemble(k1, k2, beta, mu, monolithic=self.monolithic)
         _, self.info, _ = self.ctx.solve(self.cfg, fetch=False)
         return self.info
 

@@ -14,6 +14,7 @@ ap.add_argument("--cells", type=int, default=16)
 ap.add_argument("--backend", default="gloo")
 ap.add_argument("--kind", default="hex")
 ap.add_argument("--inner-pc", default="mg")
+ap.add_argument("--solver", default="picard", choices=["picard", "gmres_fs", "cg_block2", "gmres_jacobi"])
 args = ap.parse_args()
 
 from perphil_amd import _ffi  # noqa: E402  (before torch: the library binds the system HIP runtime first)
@@ -32,6 +33,13 @@ kind = _ffi.CELL_HEX if args.kind == "hex" else _ffi.CELL_TET
 pc = _ffi.PC_MG if args.inner_pc == "mg" else _ffi.PC_JACOBI
 k1, k2, beta, mu = 1.0, 1e-2, 1.0, 1.0
 solver = SlabSolver(args.cells, world, rank, device, k1, k2, beta, mu, kind=kind, inner_pc=pc)
+mono = args.solver != "picard"
+if mono:
+    solver.cfg.picard = 0
+    solver.cfg.inner_rtol = 1e-12
+    solver.cfg.ksp_type = _ffi.KSP_CG if args.solver == "cg_block2" else _ffi.KSP_GMRES
+    solver.cfg.pc_type = {"gmres_fs": _ffi.PC_FIELDSPLIT, "cg_block2": _ffi.PC_BLOCK2, "gmres_jacobi": _ffi.PC_JACOBI}[args.solver]
+    solver.monolithic = True
 info = solver.step()
 full = solver.gather_solution()
 ok = True
@@ -48,13 +56,13 @@ if rank == 0:
         g1, g2 = p1(X), p2(X)
     ctx.set_dirichlet(0, b, g1)
     ctx.set_dirichlet(1, b, g2)
-    ctx.assemble(k1, k2, beta, mu, monolithic=False)
+    ctx.assemble(k1, k2, beta, mu, monolithic=mono)
     x1, info1, _ = ctx.solve(solver.cfg)
     err = np.abs(full - x1).max() / np.abs(x1).max()
-    print(f"world={world} n={args.cells} kind={args.kind} pc={args.inner_pc}: sweeps {info.iterations} vs {info1.iterations}, "
+    print(f"world={world} n={args.cells} kind={args.kind} solver={args.solver} pc={args.inner_pc}: sweeps {info.iterations} vs {info1.iterations}, "
           f"inner its {info.inner_iterations} vs {info1.inner_iterations}, residual {info.resnorm:.3e} vs {info1.resnorm:.3e}, "
           f"max rel diff {err:.3e}, halo calls {solver.comm.halo_calls}, allreduce calls {solver.comm.allreduce_calls}", flush=True)
-    ok = (err < 1e-9 and info.iterations == info1.iterations and abs(info.inner_iterations - info1.inner_iterations) <= 1
+    ok = (err < (1e-9 if not mono else 1e-7) and abs(info.iterations - info1.iterations) <= (0 if not mono else 2) and abs(info.inner_iterations - info1.inner_iterations) <= max(1, info1.inner_iterations // 50)
           and info.converged == 1)
 flag = torch.tensor([1.0 if ok else 0.0])
 if args.backend == "nccl":
