@@ -157,6 +157,14 @@ int pph_spmv(pph_ctx* ctx, int which, const double* x_host, double* y_host);
 /* `reps` back-to-back device SpMVs on resident vectors, average kernel ms via HIP events */
 int pph_spmv_bench(pph_ctx* ctx, int which, int reps, double* avg_ms);
 
+/* ---- error norms (post-processing) -----------------------------------------------------------------
+ * replaces: l2_error() / h1_seminorm_error() (reference src/perphil/utils/postprocessing.py:89-124) for
+ * the manufactured pressures of src/perphil/utils/manufactured_solutions.py:39-51 (2D), :87-88 (3D).
+ * `nodal_host`: the n nodal values of p1_h (field 0) or p2_h (field 1); nq-point Gauss rule per
+ * direction (1..8) on quadrilateral / hexahedral cells. */
+int pph_error_norms_mms(pph_ctx* ctx, int field, const double* nodal_host, double k1, double k2, double beta,
+                        double mu, int nq, double* l2_out, double* h1s_out);
+
 /* ---- multi-GPU communication hooks -------------------------------------------------------------
  * replaces: PETSc's implicit VecScatter halo exchange and VecDot all-reduce under mpiexec (never run in
  * the reference).  One context per rank holds one cell slab (pph_mesh_build with

@@ -33,7 +33,7 @@ EXPORTS = [
     "pph_solve", "pph_solve_device", "pph_get_solution",
     "pph_csr_sizes", "pph_get_csr", "pph_get_rhs", "pph_spmv", "pph_spmv_bench",
     "pph_get_timers", "pph_set_option", "pph_comm_set_callbacks",
-    "pph_rccl_unique_id", "pph_comm_init_rccl", "pph_comm_selftest",
+    "pph_rccl_unique_id", "pph_comm_init_rccl", "pph_comm_selftest", "pph_error_norms_mms",
 ]
 
 HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64)
@@ -124,6 +124,8 @@ def _load() -> C.CDLL:
         "pph_rccl_unique_id": ([C.c_char_p, C.c_void_p], C.c_int),
         "pph_comm_init_rccl": ([p, C.c_int, C.c_int, C.c_void_p, C.c_char_p], C.c_int),
         "pph_comm_selftest": ([p], C.c_int),
+        "pph_error_norms_mms": ([p, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, f64p,
+                                 f64p], C.c_int),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = ABI mismatch: fail loudly
@@ -268,6 +270,16 @@ class Context:
         ms = C.c_double()
         self._check(lib.pph_spmv_bench(self._h, which, int(reps), C.byref(ms)))
         return ms.value
+
+    def error_norms_mms(self, field: int, nodal: np.ndarray, k1: float, k2: float, beta: float, mu: float, nq: int = 6):
+        """(L2 error, H1-seminorm error) of a nodal CG-1 field against the manufactured pressure `field`."""
+        nodal = np.ascontiguousarray(nodal, dtype=np.float64)
+        if nodal.shape != (self.n,):
+            raise ValueError("nodal array must have one value per mesh vertex")
+        l2, h1 = C.c_double(), C.c_double()
+        self._check(lib.pph_error_norms_mms(self._h, int(field), _ptr(nodal), float(k1), float(k2), float(beta), float(mu),
+                                            int(nq), C.byref(l2), C.byref(h1)))
+        return l2.value, h1.value
 
     def timers(self) -> dict:
         t = np.zeros(11, dtype=np.float64)

@@ -1,0 +1,86 @@
+"""
+Matrix export + condition numbers — mirror of reference ``src/perphil/solvers/conditioning.py``
+(SURVEY.md §8f rank 4): ``get_matrix_data_from_form`` (:66-102) assembles on the device and returns the
+SciPy CSR the reference extracts from PETSc (``getValuesCSR`` + ``eliminate_zeros``);
+``calculate_condition_number`` (:105-218) is the same dense-SVD / extreme-singular-value computation the
+reference runs in SciPy on the host (it is analysis code there as well, not part of the solve).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import attr
+import numpy as np
+from scipy.sparse import csr_matrix
+
+from . import _ffi, fd
+from .forms import DPPBilinearForm, ScalarBlockForm
+
+DEFAULT_CONDITION_NUMBER_TOLERANCE = 1e-7
+
+
+@attr.define(frozen=True)
+class MatrixData:
+    """Same fields as the reference's MatrixData minus the PETSc handles (there is no PETSc here)."""
+    is_symmetric: bool
+    sparse_csr_data: csr_matrix
+    number_of_nonzero_entries: int
+    number_of_dofs: int
+    symmetry_tolerance: float
+
+
+def _set_bcs(ctx, space, bcs: List[fd.DirichletBC]) -> None:
+    empty = (np.zeros(0, np.int64), np.zeros(0))
+    per_field = {0: empty, 1: empty}
+    for bc in bcs or []:
+        per_field[bc.field] = bc.nodes_and_values()
+    for f in (0, 1):
+        ctx.set_dirichlet(f, *per_field[f])
+
+
+def get_matrix_data_from_form(form, boundary_conditions: List[fd.DirichletBC], symmetry_tolerance: float = 1e-8) -> MatrixData:
+    """Assemble `form` (monolithic DPP form or one Picard block) with the BCs and export it as SciPy CSR."""
+    if isinstance(form, DPPBilinearForm):
+        mesh = form.space.mesh()
+        ctx = mesh.context()
+        _set_bcs(ctx, form.space, boundary_conditions)
+        ctx.assemble(form.k1, form.k2, form.beta, form.mu, monolithic=True)
+        csr = ctx.csr(_ffi.MAT_MONO)
+    elif isinstance(form, ScalarBlockForm) and form.rank == 2:
+        mesh = form.space.mesh()
+        ctx = mesh.context()
+        # a scalar block (coef_K K + coef_M M): assemble the pair with the block's coefficients on its own field
+        bcs = [fd.DirichletBC(_as_field(bc, form.field), bc.value, bc.sub_domain) for bc in boundary_conditions or []]
+        _set_bcs(ctx, form.space, bcs)
+        k = form.coef_K if form.coef_K > 0 else 1.0
+        ctx.assemble(k, k, form.coef_M, 1.0, monolithic=False)
+        csr = ctx.csr(_ffi.MAT_A11 if form.field == 0 else _ffi.MAT_A22)
+    else:
+        raise TypeError(f"cannot assemble {type(form)}")
+    csr = csr_matrix(csr)
+    csr.eliminate_zeros()
+    asym = abs(csr - csr.T)
+    is_symmetric = bool((asym.max() if asym.nnz else 0.0) <= symmetry_tolerance)
+    return MatrixData(is_symmetric, csr, int(csr.nnz), int(csr.shape[0]), symmetry_tolerance)
+
+
+class _FieldView(fd.FunctionSpace):
+    def __init__(self, V, field):
+        super().__init__(V.mesh(), "CG", 1)
+        self.index = field
+
+
+def _as_field(bc: fd.DirichletBC, field: int):
+    return _FieldView(bc.function_space(), field)
+
+
+def calculate_condition_number(scipy_csr_sparse_matrix: csr_matrix, num_singular_values: Optional[int] = None,
+                               use_sparse: bool = False, zero_tol: float = DEFAULT_CONDITION_NUMBER_TOLERANCE,
+                               num_of_factors: Optional[int] = None) -> float:
+    """sigma_max / sigma_min over singular values above `zero_tol` (reference conditioning.py:134-154)."""
+    A = scipy_csr_sparse_matrix
+    s = np.linalg.svd(A.toarray() if hasattr(A, "toarray") else np.asarray(A), compute_uv=False)
+    s = s[s > zero_tol]
+    if s.size == 0:
+        raise ValueError("no singular value above the tolerance")
+    return float(s.max() / s.min())

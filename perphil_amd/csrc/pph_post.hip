@@ -1,0 +1,236 @@
+// Error norms of a CG-1 field against the manufactured DPP pressures, on the device.
+//
+// Replaces l2_error / h1_seminorm_error (reference src/perphil/utils/postprocessing.py:89-124, which
+// assemble ||p_h - p||^2 and |p_h - p|_1^2 with Firedrake) for the exact solutions of
+// src/perphil/utils/manufactured_solutions.py:39-51 (2D) and :87-88 (3D) — SURVEY.md §8f rank 2.
+// One thread per multilinear cell, nq-point Gauss rule per direction on the isoparametric map; the
+// exact pressure and its gradient are evaluated in closed form at every quadrature point.
+#include "pph_internal.h"
+#include <cmath>
+
+struct GaussRule {
+  int nq;
+  double x[8], w[8];
+};
+
+struct MmsPar {
+  double mu_over_pi, coef_e, eta;  // p = (mu/pi) e^{pi x} S(y,z) + coef_e E(y,z);  coef_e = -mu/(beta k1) or +mu/(beta k2)
+  double mu;
+};
+
+template <int DIM>
+__global__ __launch_bounds__(256) void k_error_norms(const int32_t* __restrict__ cells, const double* __restrict__ cx,
+                                                     const double* __restrict__ cy, const double* __restrict__ cz,
+                                                     const double* __restrict__ u, GaussRule g, MmsPar p,
+                                                     int64_t ncell, double* __restrict__ part) {
+  constexpr int NB = 1 << DIM;
+  __shared__ double lds[4];
+  const double PI = 3.14159265358979323846;
+  double l2 = 0.0, h1 = 0.0;
+  for (int64_t cell = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; cell < ncell;
+       cell += (int64_t)gridDim.x * blockDim.x) {
+    double X[NB][DIM], U[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int32_t nd = cells[cell * NB + b];
+      X[b][0] = cx[nd];
+      X[b][1] = cy[nd];
+      if constexpr (DIM == 3) X[b][2] = cz[nd];
+      U[b] = u[nd];
+    }
+    const int nq = g.nq;
+    const int npts = (DIM == 2) ? nq * nq : nq * nq * nq;
+    for (int q = 0; q < npts; ++q) {
+      int qi[3] = {q % nq, (q / nq) % nq, q / (nq * nq)};
+      double xi[DIM], w = 1.0;
+#pragma unroll
+      for (int e = 0; e < DIM; ++e) { xi[e] = g.x[qi[e]]; w *= g.w[qi[e]]; }
+      double N[NB], dN[NB][DIM];
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        double nv = 1.0;
+#pragma unroll
+        for (int e = 0; e < DIM; ++e) {
+          const double s = ((b >> e) & 1) ? 1.0 : -1.0;
+          nv *= 0.5 * (1.0 + s * xi[e]);
+        }
+        N[b] = nv;
+#pragma unroll
+        for (int e = 0; e < DIM; ++e) {
+          double d = 1.0;
+#pragma unroll
+          for (int f = 0; f < DIM; ++f) {
+            const double s = ((b >> f) & 1) ? 1.0 : -1.0;
+            d *= (f == e) ? 0.5 * s : 0.5 * (1.0 + s * xi[f]);
+          }
+          dN[b][e] = d;
+        }
+      }
+      double J[DIM][DIM], xq[DIM], uh = 0.0, gu_ref[DIM];
+#pragma unroll
+      for (int e = 0; e < DIM; ++e) {
+        gu_ref[e] = 0.0;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) J[e][d] = 0.0;
+      }
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) xq[d] = 0.0;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        uh += N[b] * U[b];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) xq[d] += N[b] * X[b][d];
+#pragma unroll
+        for (int e = 0; e < DIM; ++e) {
+          gu_ref[e] += dN[b][e] * U[b];
+#pragma unroll
+          for (int d = 0; d < DIM; ++d) J[e][d] += dN[b][e] * X[b][d];
+        }
+      }
+      double det, I[DIM][DIM];
+      if constexpr (DIM == 2) {
+        det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+        const double r = 1.0 / det;
+        I[0][0] = J[1][1] * r;  I[0][1] = -J[0][1] * r;
+        I[1][0] = -J[1][0] * r; I[1][1] = J[0][0] * r;
+      } else {
+        const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+        const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+        const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+        det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+        const double r = 1.0 / det;
+        I[0][0] = c00 * r;
+        I[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
+        I[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
+        I[1][0] = c01 * r;
+        I[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
+        I[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
+        I[2][0] = c02 * r;
+        I[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
+        I[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
+      }
+      // exact pressure and gradient
+      const double ex = exp(PI * xq[0]);
+      double S = sin(PI * xq[1]), E = exp(p.eta * xq[1]);
+      double pe, ge[DIM];
+      if constexpr (DIM == 3) {
+        const double Sz = sin(PI * xq[2]), Ez = exp(p.eta * xq[2]);
+        pe = p.mu_over_pi * ex * (S + Sz) + p.coef_e * (E + Ez);
+        ge[0] = p.mu * ex * (S + Sz);
+        ge[1] = p.mu * ex * cos(PI * xq[1]) + p.coef_e * p.eta * E;
+        ge[2] = p.mu * ex * cos(PI * xq[2]) + p.coef_e * p.eta * Ez;
+      } else {
+        pe = p.mu_over_pi * ex * S + p.coef_e * E;
+        ge[0] = p.mu * ex * S;
+        ge[1] = p.mu * ex * cos(PI * xq[1]) + p.coef_e * p.eta * E;
+      }
+      const double wd = w * fabs(det);
+      const double du = uh - pe;
+      l2 += wd * du * du;
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) {
+        double gh = 0.0;
+#pragma unroll
+        for (int e = 0; e < DIM; ++e) gh += I[d][e] * gu_ref[e];
+        const double dg = gh - ge[d];
+        h1 += wd * dg * dg;
+      }
+    }
+  }
+  // block sums -> partials [0][block], [1][block]
+  auto bsum = [&](double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) lds[wv] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) for (int q = 0; q < (int)(blockDim.x >> 6); ++q) t += lds[q];
+    return t;
+  };
+  const double a = bsum(l2);
+  const double b = bsum(h1);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = a;
+    part[2048 + blockIdx.x] = b;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ part, int nblocks, double* __restrict__ out) {
+  __shared__ double lds[256];
+  const double* p = part + (int64_t)blockIdx.x * 2048;
+  double v = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) v += p[i];
+  lds[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) lds[threadIdx.x] += lds[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[blockIdx.x] = lds[0];
+}
+
+static void gauss_legendre(int n, double* x, double* w) {
+  // Newton iteration on P_n; n <= 8
+  for (int i = 0; i < n; ++i) {
+    double z = std::cos(3.14159265358979323846 * (i + 0.75) / (n + 0.5));
+    double pp = 0.0;
+    for (int it = 0; it < 100; ++it) {
+      double p1 = 1.0, p2 = 0.0;
+      for (int j = 0; j < n; ++j) {
+        const double p3 = p2;
+        p2 = p1;
+        p1 = ((2.0 * j + 1.0) * z * p2 - j * p3) / (j + 1.0);
+      }
+      pp = n * (z * p1 - p2) / (z * z - 1.0);
+      const double z1 = z;
+      z = z1 - p1 / pp;
+      if (std::fabs(z - z1) < 1e-15) break;
+    }
+    x[i] = -z;
+    w[i] = 2.0 / ((1.0 - z * z) * pp * pp);
+  }
+}
+
+extern "C" int pph_error_norms_mms(pph_ctx* ctx, int field, const double* nodal_host, double k1, double k2,
+                                   double beta, double mu, int nq, double* l2_out, double* h1s_out) {
+  if (!ctx) return PPH_ERR_INVALID;
+  PPH_REQUIRE(ctx, ctx->mesh_ok, "pph_error_norms_mms before pph_mesh_build");
+  PPH_REQUIRE(ctx, ctx->world == 1, "error norms are implemented for single-context meshes");
+  const MeshData& m = ctx->mesh;
+  PPH_REQUIRE(ctx, m.kind == PPH_CELL_QUAD || m.kind == PPH_CELL_HEX, "error norms: quadrilateral / hexahedral cells only");
+  PPH_REQUIRE(ctx, field == 0 || field == 1, "field must be 0 or 1");
+  PPH_REQUIRE(ctx, nq >= 1 && nq <= 8 && nodal_host && l2_out && h1s_out, "bad arguments");
+  PPH_REQUIRE(ctx, k1 > 0 && k2 > 0 && mu > 0 && beta > 0, "need positive parameters");
+  PPH_HIP(ctx, hipSetDevice(ctx->device));
+  DevBuf<double> u, part;
+  PPH_TRY(u.alloc(ctx, (size_t)m.n));
+  PPH_TRY(part.alloc(ctx, 2 * 2048 + 2));
+  PPH_HIP(ctx, hipMemcpyAsync(u.p, nodal_host, sizeof(double) * (size_t)m.n, hipMemcpyHostToDevice, ctx->stream));
+  GaussRule g;
+  g.nq = nq;
+  gauss_legendre(nq, g.x, g.w);
+  MmsPar p;
+  p.mu = mu;
+  p.mu_over_pi = mu / 3.14159265358979323846;
+  p.eta = std::sqrt(beta * (k1 + k2) / (k1 * k2));
+  p.coef_e = (field == 0) ? -mu / (beta * k1) : mu / (beta * k2);
+  int64_t nb = ceil_div64(m.ncell, 256);
+  const int grid = (int)(nb < 2048 ? nb : 2048);
+  if (m.kind == PPH_CELL_QUAD)
+    hipLaunchKernelGGL(k_error_norms<2>, dim3(grid), dim3(256), 0, ctx->stream, m.cells.p, m.cx.p, m.cy.p, m.cz.p, u.p, g,
+                       p, m.ncell, part.p);
+  else
+    hipLaunchKernelGGL(k_error_norms<3>, dim3(grid), dim3(256), 0, ctx->stream, m.cells.p, m.cx.p, m.cy.p, m.cz.p, u.p, g,
+                       p, m.ncell, part.p);
+  hipLaunchKernelGGL(k_sum_partials, dim3(2), dim3(256), 0, ctx->stream, part.p, grid, part.p + 4096);
+  double r[2];
+  PPH_HIP(ctx, hipMemcpyAsync(r, part.p + 4096, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
+  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  PPH_HIP(ctx, hipGetLastError());
+  *l2_out = std::sqrt(r[0]);
+  *h1s_out = std::sqrt(r[1]);
+  u.release();
+  part.release();
+  return PPH_OK;
+}

@@ -17,6 +17,18 @@ from .parameters import DPPParameters
 PointFn = Callable[[np.ndarray], np.ndarray]
 
 
+class MMSPressure:
+    """Callable manufactured pressure p1 (field 0) or p2 (field 1); carries its parameters so that the
+    device error-norm kernel (``pph_error_norms_mms``) can evaluate the same closed form."""
+
+    def __init__(self, fn: PointFn, field: int, dim: int, k1: float, k2: float, beta: float, mu: float):
+        self._fn, self.field, self.dim = fn, field, dim
+        self.k1, self.k2, self.beta, self.mu = k1, k2, beta, mu
+
+    def __call__(self, X: np.ndarray) -> np.ndarray:
+        return self._fn(X)
+
+
 def exact_expressions(mesh: fd.Mesh, dpp_params: DPPParameters) -> Tuple[PointFn, PointFn, PointFn, PointFn]:
     """(u1, p1, u2, p2) on the unit square (manufactured_solutions.py:39-51)."""
     k1, k2 = float(dpp_params.k1), float(dpp_params.k2)
@@ -41,7 +53,7 @@ def exact_expressions(mesh: fd.Mesh, dpp_params: DPPParameters) -> Tuple[PointFn
         return np.stack([-k2 * np.exp(pi * x) * np.sin(pi * y),
                          -k2 * (np.exp(pi * x) * np.cos(pi * y) + (eta / (beta * k2)) * np.exp(eta * y))], axis=1)
 
-    return u1, p1, u2, p2
+    return u1, MMSPressure(p1, 0, 2, k1, k2, beta, mu), u2, MMSPressure(p2, 1, 2, k1, k2, beta, mu)
 
 
 def exact_expressions_3d(mesh: fd.Mesh, dpp_params: DPPParameters) -> Tuple[PointFn, PointFn, PointFn, PointFn]:
@@ -63,8 +75,8 @@ def exact_expressions_3d(mesh: fd.Mesh, dpp_params: DPPParameters) -> Tuple[Poin
                          mu * ex * np.cos(pi * y) + c * np.exp(eta * y),
                          mu * ex * np.cos(pi * z) + c * np.exp(eta * z)], axis=1)
 
-    p1 = lambda X: _p(X, -1.0, k1)
-    p2 = lambda X: _p(X, +1.0, k2)
+    p1 = MMSPressure(lambda X: _p(X, -1.0, k1), 0, 3, k1, k2, beta, mu)
+    p2 = MMSPressure(lambda X: _p(X, +1.0, k2), 1, 3, k1, k2, beta, mu)
     u1 = lambda X: -(k1 / mu) * _grad(X, -1.0, k1)
     u2 = lambda X: -(k2 / mu) * _grad(X, +1.0, k2)
     return u1, p1, u2, p2

@@ -1,0 +1,56 @@
+"""
+Post-processing — mirror of reference ``src/perphil/utils/postprocessing.py``:
+``split_dpp_solution`` (:6-31), ``slice_along_x`` (:66-86), ``l2_error`` (:89-105), ``h1_seminorm_error``
+(:108-124).  The two error norms run on the device (``pph_error_norms_mms``): a Gauss rule per cell on
+the isoparametric map with the manufactured pressure evaluated in closed form at every quadrature point.
+"""
+from __future__ import annotations
+
+from typing import Tuple
+
+import numpy as np
+
+from . import fd
+from .manufactured_solutions import MMSPressure
+
+
+def split_dpp_solution(dpp_solution: fd.Function) -> Tuple[fd.Function, fd.Function]:
+    """(p1_h, p2_h) as independent Functions; ValueError unless the space is a 2-field mixed space."""
+    W = dpp_solution.function_space()
+    if not hasattr(W, "num_sub_spaces") or W.num_sub_spaces() != 2:
+        raise ValueError(f"Expected a 2-field MixedFunctionSpace, got {type(W)}")
+    p1 = fd.Function(W.sub(0), dpp_solution.sub(0).vector().copy(), name="p1_h")
+    p2 = fd.Function(W.sub(1), dpp_solution.sub(1).vector().copy(), name="p2_h")
+    return p1, p2
+
+
+def slice_along_x(scalar_field: fd.Function, x_value: float) -> Tuple[np.ndarray, np.ndarray]:
+    """(y_points, values) of a scalar field along the vertical line x = x_value (a grid line)."""
+    mesh = scalar_field.function_space().mesh()
+    if mesh.dim != 2:
+        raise NotImplementedError("slice_along_x is a 2D utility (as in the reference)")
+    y_points = np.arange(mesh.ny + 1) / mesh.ny
+    values = np.array([scalar_field.at((x_value, y)) for y in y_points])
+    return y_points, values
+
+
+def _norms(numerical: fd.Function, exact_expr, quadrature_points: int):
+    if not isinstance(exact_expr, MMSPressure):
+        raise NotImplementedError("device error norms are available against the manufactured pressures "
+                                  "returned by exact_expressions / exact_expressions_3d")
+    mesh = numerical.function_space().mesh()
+    if exact_expr.dim != mesh.dim:
+        raise ValueError("exact expression and mesh have different dimensions")
+    ctx = mesh.context()
+    e = exact_expr
+    return ctx.error_norms_mms(e.field, numerical.vector(), e.k1, e.k2, e.beta, e.mu, quadrature_points)
+
+
+def l2_error(numerical: fd.Function, exact_expr, quadrature_points: int = 6) -> float:
+    """||numerical - exact||_{L2} (reference postprocessing.py:89-105)."""
+    return float(_norms(numerical, exact_expr, quadrature_points)[0])
+
+
+def h1_seminorm_error(numerical: fd.Function, exact_expr, quadrature_points: int = 6) -> float:
+    """|numerical - exact|_{H1} (reference postprocessing.py:108-124)."""
+    return float(_norms(numerical, exact_expr, quadrature_points)[1])

@@ -406,3 +406,81 @@ def test_high_contrast_gmres_fieldsplit(gpu_ctx_factory, hexa, n):
     assert np.abs(sol.solution.vector() - ud).max() / np.abs(ud).max() < 1e-7
     ref = o.gmres(osys.A, osys.rhs, o.fieldsplit_multiplicative_apply(osys.A, osys.n))
     assert sol.iteration_number == ref.its
+
+
+def test_G10_error_norms_on_device(gpu_ctx_factory, goldens):
+    """l2_error / h1_seminorm_error through the public API against the reference's convergence.csv
+    (2D Q1, MUMPS rows) and against the oracle's high-order quadrature."""
+    import perphil_amd as pa
+    from perphil_amd import fd, solver_parameters as spar
+    from perphil_amd.postprocessing import l2_error, h1_seminorm_error, split_dpp_solution
+
+    params = pa.DPPParameters()   # convergence_2d.py uses the defaults
+    for N in (16, 32):
+        g = next(r for r in goldens["G10_convergence_2d"] if r["solver"] == "Monolithic LU with MUMPS" and int(r["N"]) == N)
+        mesh = pa.create_mesh(N, N, quadrilateral=True)
+        _, V = pa.create_function_spaces(mesh)
+        W = fd.MixedFunctionSpace((V, V))
+        _, p1e, _, p2e = pa.exact_expressions(mesh, params)
+        bcs = [fd.DirichletBC(W.sub(0), p1e, "on_boundary"), fd.DirichletBC(W.sub(1), p2e, "on_boundary")]
+        sol = pa.solve_dpp(W, params, bcs, solver_parameters=spar.LINEAR_SOLVER_PARAMS)
+        p1h, p2h = split_dpp_solution(sol.solution)
+        vals = (l2_error(p1h, p1e), l2_error(p2h, p2e), h1_seminorm_error(p1h, p1e), h1_seminorm_error(p2h, p2e))
+        for v, key in zip(vals, ("e1_L2", "e2_L2", "e1_H1s", "e2_H1s")):
+            assert v == pytest.approx(g[key], rel=2e-3), (N, key)
+    # against the oracle's quadrature of the same fields (tight)
+    om = o.build_mesh(2, o.CELL_QUAD, 32, 32)
+    Pd = o.Params()
+    import math
+    eta, pi = Pd.eta, math.pi
+    ex = lambda X: (Pd.mu / pi) * np.exp(pi * X[:, 0]) * np.sin(pi * X[:, 1]) - (Pd.mu / (Pd.beta * Pd.k1)) * np.exp(eta * X[:, 1])
+    gr = lambda X: np.stack([Pd.mu * np.exp(pi * X[:, 0]) * np.sin(pi * X[:, 1]),
+                             Pd.mu * np.exp(pi * X[:, 0]) * np.cos(pi * X[:, 1]) - (Pd.mu / (Pd.beta * Pd.k1)) * eta * np.exp(eta * X[:, 1])], 1)
+    e1, h1 = o.error_norms(om, p1h.vector(), ex, gr, nq=6)
+    assert vals[0] == pytest.approx(e1, rel=1e-10) and vals[2] == pytest.approx(h1, rel=1e-10)
+    # 3D hex: second-order L2 convergence of the manufactured problem
+    errs = []
+    for N in (8, 16):
+        mesh = fd.UnitCubeMesh(N, N, N, hexahedral=True)
+        V = fd.FunctionSpace(mesh, "CG", 1)
+        W = V * V
+        p3 = pa.DPPParameters(k1=1.0, k2=0.01)
+        _, p1e, _, p2e = pa.exact_expressions_3d(mesh, p3)
+        bcs = [fd.DirichletBC(W.sub(0), p1e, "on_boundary"), fd.DirichletBC(W.sub(1), p2e, "on_boundary")]
+        sol = pa.solve_dpp(W, p3, bcs, solver_parameters=spar.FIELDSPLIT_MG_PARAMS)
+        errs.append(l2_error(sol.solution.sub(0), p1e))
+    assert 1.6 < np.log2(errs[0] / errs[1]) < 2.3
+
+
+def test_conditioning_and_harness_api(gpu_ctx_factory, goldens):
+    """get_matrix_data_from_form / calculate_condition_number / Approach harness (reference
+    solvers/_tests/test_conditioning.py:16-56, experiments/_tests/test_iterative_bench.py:16-29) and the
+    reference's conditioning goldens G3 / G4 through the public API."""
+    import perphil_amd as pa
+    from perphil_amd import fd, conditioning, iterative_bench as ib
+
+    mesh = pa.create_mesh(10, 10, quadrilateral=True)
+    _, V = pa.create_function_spaces(mesh)
+    W = V * V
+    params = pa.DPPParameters(k1=1.0, k2=1 / 1e2, beta=1.0, mu=1)
+    _, p1e, _, p2e = pa.exact_expressions(mesh, params)
+    bcs = [fd.DirichletBC(W.sub(0), p1e, "on_boundary"), fd.DirichletBC(W.sub(1), p2e, "on_boundary")]
+    a, _ = pa.dpp_form(W, params)
+    md = conditioning.get_matrix_data_from_form(a, bcs)
+    assert md.is_symmetric and md.number_of_dofs == W.dim() and md.number_of_nonzero_entries == md.sparse_csr_data.nnz
+    g = goldens["G3_condition_numbers_10x10"]
+    assert conditioning.calculate_condition_number(md.sparse_csr_data, None) == pytest.approx(g["monolithic"], rel=1e-10)
+    (am, _), (ai, _) = pa.dpp_delayed_form(V, V, params, fd.Function(V), fd.Function(V))
+    assert conditioning.calculate_condition_number(conditioning.get_matrix_data_from_form(am, [bcs[0]]).sparse_csr_data) == \
+        pytest.approx(g["macro"], rel=1e-10)
+    assert conditioning.calculate_condition_number(conditioning.get_matrix_data_from_form(ai, [bcs[1]]).sparse_csr_data) == \
+        pytest.approx(g["micro"], rel=1e-10)
+    # harness: homogeneous BCs, conditioning.csv row N=8
+    _, _, W8 = ib.build_spaces(ib.build_mesh(8, 8))
+    c = ib.estimate_condition_numbers(W8)
+    g4 = goldens["G4_conditioning_2d"][1]
+    assert c["monolithic"] == pytest.approx(g4["cond_monolithic"], rel=1e-10)
+    assert c["macro"] == pytest.approx(g4["cond_macro"], rel=1e-10) and c["micro"] == pytest.approx(g4["cond_micro"], rel=1e-10)
+    assert ib.params_for(ib.Approach.SS_GMRES)["pc_type"] == "fieldsplit"
+    res = ib.solve_on_mesh(W8, ib.Approach.SS_GMRES)
+    assert isinstance(res, ib.SolveResult) and res.iteration_number >= 0 and res.fields is not None
