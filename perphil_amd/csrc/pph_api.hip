@@ -45,6 +45,7 @@ void DevBuf<T>::release() {
 }
 
 template struct DevBuf<double>;
+template struct DevBuf<float>;
 template struct DevBuf<int32_t>;
 template struct DevBuf<int64_t>;
 template struct DevBuf<uint8_t>;
@@ -404,6 +405,11 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
     const int v = (int)value;
     PPH_REQUIRE(ctx, (v >= 0 && v <= 11), "spmv_kernel: 0 vector, 1 vector+preload, 2 LDS stream, 3 aligned-wide (default), 4 LDS-transposed, 5-7 multi-row, 8 aligned-wide XCD-contiguous, 10 no-gather probe");
     ctx->spmv_kernel = v;
+    return PPH_OK;
+  }
+  if (!strcmp(name, "mg_fp32")) {
+    ctx->mg_fp32 = value != 0.0 ? 1 : 0;
+    ctx->mg_ok = false;
     return PPH_OK;
   }
   if (!strcmp(name, "asm_kernel")) {

@@ -59,6 +59,7 @@ struct Csr {  // device CSR view (no ownership)
   const int64_t* rowptr = nullptr;
   const int32_t* col = nullptr;
   const double* val = nullptr;
+  const float* val32 = nullptr;   // when set: fp32 copy of the values, used instead of `val` (preconditioner operands)
   int64_t nrows = 0;
   int64_t nnz = 0;
   const MeshData* geom = nullptr;  // slab geometry of the rows (halo exchange of x before the product); may be null
@@ -98,6 +99,7 @@ struct MgLevel {
   int64_t n = 0, nnz = 0;
   int px = 0, py = 0, pz = 0;
   DevBuf<double> own_val[2];     // storage of val[] on coarse levels
+  DevBuf<float> val32[2];        // fp32 copies of val[] for the smoother / residual SpMVs of the V-cycle
   DevBuf<double> dinv[2];
   DevBuf<uint8_t> mask[2];       // per field: non-zero where the dof is constrained
   const uint8_t* maskp[2] = {nullptr, nullptr};
@@ -161,6 +163,7 @@ struct pph_ctx {
   std::vector<EvPair> ev_pool;          // reusable event pairs
   size_t ev_used = 0;                   // pairs recorded since the last harvest
   int spmv_lanes_override = 0;          // 0: pick from the mean row length
+  int mg_fp32 = 1;                      // V-cycle SpMVs read fp32 operator values (8 instead of 12 B per non-zero)
   int asm_kernel = 2;                   // multilinear cells: 2 two-pass (element rows + node gather, default), 1 one-pass node gather, 0 cell-centred atomic scatter-add
   int spmv_kernel = 3;                  // 3: aligned-wide CSR-vector (default); 0,1,2,4..8,10: variants kept for A/B runs
 };

@@ -99,9 +99,9 @@ __global__ __launch_bounds__(256) void k_spmv(const int64_t* __restrict__ rowptr
 // entries outside [rowptr[row], rowptr[row+1]) are masked.  8-byte and 4-byte-per-lane streams reach a
 // markedly lower share of the HBM rate than 16-byte-per-lane streams on gfx950.  Device buffers carry
 // 64 bytes of slack, so the rounded reads stay inside the allocations.
-template <int G, bool DOT, int MODE = 0>
+template <int G, bool DOT, int MODE = 0, typename VT = double>
 __global__ __launch_bounds__(256) void k_spmv_wide(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                   const double* __restrict__ val, const double* __restrict__ x,
+                                                   const VT* __restrict__ val, const double* __restrict__ x,
                                                    const double* __restrict__ bvec, double* __restrict__ y,
                                                    int64_t nrows, double* __restrict__ part) {
   constexpr int RPB = 256 / G;
@@ -129,19 +129,26 @@ __global__ __launch_bounds__(256) void k_spmv_wide(const int64_t* __restrict__ r
       for (int64_t base = (s & ~(int64_t)3) + 4 * sub; base < e; base += 4 * G) {
         int4 c;
         double2 v01, v23;
-        if (MODE == 3) {  // non-temporal matrix stream: keep the L2 for x
+        if constexpr (sizeof(VT) == 4) {
+          // values stored in fp32 (multigrid preconditioner operands): one 16-byte load carries 4 of them;
+          // products and sums stay in fp64
+          c = *reinterpret_cast<const int4*>(col + base);
+          const float4 vf = *reinterpret_cast<const float4*>(val + base);
+          v01 = make_double2((double)vf.x, (double)vf.y);
+          v23 = make_double2((double)vf.z, (double)vf.w);
+        } else if (MODE == 3) {  // non-temporal matrix stream: keep the L2 for x
           typedef int v4i __attribute__((ext_vector_type(4)));
           typedef double v2d __attribute__((ext_vector_type(2)));
           const v4i cc = __builtin_nontemporal_load(reinterpret_cast<const v4i*>(col + base));
-          const v2d a01 = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(val + base));
-          const v2d a23 = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(val + base + 2));
+          const v2d a01 = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(reinterpret_cast<const double*>(val) + base));
+          const v2d a23 = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(reinterpret_cast<const double*>(val) + base + 2));
           c = make_int4(cc.x, cc.y, cc.z, cc.w);
           v01 = make_double2(a01.x, a01.y);
           v23 = make_double2(a23.x, a23.y);
         } else {
           c = *reinterpret_cast<const int4*>(col + base);
-          v01 = *reinterpret_cast<const double2*>(val + base);
-          v23 = *reinterpret_cast<const double2*>(val + base + 2);
+          v01 = *reinterpret_cast<const double2*>(reinterpret_cast<const double*>(val) + base);
+          v23 = *reinterpret_cast<const double2*>(reinterpret_cast<const double*>(val) + base + 2);
         }
         const bool k0 = base >= s, k1 = base + 1 >= s && base + 1 < e, k2 = base + 2 >= s && base + 2 < e,
                    k3 = base + 3 < e && base + 3 >= s;
@@ -436,6 +443,23 @@ static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const doub
     }
   }
   int grid = 8;
+  double bytes_per_nnz = 12.0;
+  if (A.val32) {
+    // fp32-valued operator (multigrid levels): aligned-wide kernel, 8 lanes per row
+    const int G = (A.max_row > 0 && A.max_row + 3 <= 16) ? 4 : 8;
+    grid = spmv_grid(A.nrows, 256 / G);
+    bytes_per_nnz = 8.0;
+    if (G == 4)
+      hipLaunchKernelGGL((k_spmv_wide<4, DOT, 2, float>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val32, x,
+                         bvec, y, A.nrows, part);
+    else
+      hipLaunchKernelGGL((k_spmv_wide<8, DOT, 2, float>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val32, x,
+                         bvec, y, A.nrows, part);
+    if (ev) (void)hipEventRecord(ev->e1, ctx->stream);
+    ctx->n_spmv[variant]++;
+    ctx->spmv_bytes[variant] += bytes_per_nnz * (double)A.nnz + 20.0 * (double)A.nrows;
+    return grid;
+  }
   const bool can_stream = A.max_row > 0 && A.max_row <= 8 * 64;
   if (ctx->spmv_kernel == 2 && can_stream) {
     const int T = stream_T(A.max_row);

@@ -75,6 +75,10 @@ __global__ void k_inject_mask(double* __restrict__ mc, const uint8_t* __restrict
   }
 }
 
+__global__ void k_to_float(float* __restrict__ o, const double* __restrict__ v, int64_t n) {
+  NODE_LOOP(id, n) o[id] = (float)v[id];
+}
+
 __global__ void k_mask_from_double(uint8_t* __restrict__ m, const double* __restrict__ v, int64_t n, int64_t plane,
                                    int glo, int ghi) {
   NODE_LOOP(id, n) {
@@ -197,9 +201,11 @@ static inline int mg_grid(int64_t n) {
   return (int)b;
 }
 
-static Csr level_csr(const pph_ctx* ctx, const MgLevel& L, int which) {
+// lowp: the fp32 copy of the level operator (smoother / residual SpMVs inside the V-cycle)
+static Csr level_csr(const pph_ctx* ctx, const MgLevel& L, int which, bool lowp = false) {
   Csr A;
   A.rowptr = L.rowptr; A.col = L.col; A.val = L.val[which]; A.nrows = L.n; A.nnz = L.nnz;
+  if (lowp && ctx->mg_fp32 && L.val32[which].p) A.val32 = L.val32[which].p;
   A.max_row = ctx->mesh.max_row;
   A.geom = (ctx->world > 1 && !L.replicated) ? L.geom : nullptr;
   A.lanes = pph_pick_lanes(ctx, A.nnz, A.nrows);
@@ -218,7 +224,7 @@ void mg_release(pph_ctx* ctx) {
   for (size_t l = 0; l < ctx->mg.size(); ++l) {
     MgLevel& L = ctx->mg[l];
     if (l > 0) L.mesh.release_all();
-    for (int f = 0; f < 2; ++f) { L.own_val[f].release(); L.dinv[f].release(); L.mask[f].release(); }
+    for (int f = 0; f < 2; ++f) { L.own_val[f].release(); L.dinv[f].release(); L.mask[f].release(); L.val32[f].release(); }
     L.x.release(); L.b.release(); L.r.release(); L.d.release(); L.t.release(); L.w.release();
   }
   ctx->mg.clear();
@@ -334,6 +340,10 @@ int mg_setup(pph_ctx* ctx) {
     for (int f = 0; f < 2; ++f) {
       PPH_TRY(L.dinv[f].alloc(ctx, (size_t)L.n));
       la_extract_diag_inv(ctx, level_csr(ctx, L, f), L.dinv[f].p);
+      if (ctx->mg_fp32) {
+        PPH_TRY(L.val32[f].alloc(ctx, (size_t)L.nnz));
+        hipLaunchKernelGGL(k_to_float, dim3(mg_grid(L.nnz)), dim3(256), 0, ctx->stream, L.val32[f].p, L.val[f], L.nnz);
+      }
     }
     PPH_HIP(ctx, hipMemsetAsync(lamdev.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
     for (int f = 0; f < 2; ++f)
@@ -365,7 +375,7 @@ int mg_setup(pph_ctx* ctx) {
 
 // `steps` Chebyshev-Jacobi steps on A x = b.  zero_guess: x is overwritten, no initial SpMV.
 static void chebyshev(pph_ctx* ctx, MgLevel& L, int which, const double* b, double* x, int steps, bool zero_guess) {
-  const Csr A = level_csr(ctx, L, which);
+  const Csr A = level_csr(ctx, L, which, true);
   const double hi = L.lam[which], lo = MG_CHEB_LOWER * hi;
   const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo);
   const double sigma = theta / delta;
@@ -406,7 +416,7 @@ void mg_vcycle(pph_ctx* ctx, int which, const double* rin, double* zout, int nsm
     double* x = (l == 0) ? zout : L.x.p;
     ctx->comm_suspended = L.replicated;
     chebyshev(ctx, L, which, b, x, nsmooth, true);
-    la_spmv_resid(ctx, level_csr(ctx, L, which), x, b, L.r.p);
+    la_spmv_resid(ctx, level_csr(ctx, L, which, true), x, b, L.r.p);
     if (dist && !L.replicated) (void)la_halo(ctx, *L.geom, L.r.p);  // restriction reads one fine plane beyond the owned ones
     hipLaunchKernelGGL(k_restrict, dim3(mg_grid(C.n)), dim3(256), 0, ctx->stream, C.b.p, L.r.p, st, C.maskp[which],
                        L.maskp[which], tgeom(L, C));
