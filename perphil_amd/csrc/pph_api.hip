@@ -403,7 +403,7 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
   }
   if (!strcmp(name, "spmv_kernel")) {
     const int v = (int)value;
-    PPH_REQUIRE(ctx, (v >= 0 && v <= 11), "spmv_kernel: 0 vector, 1 vector+preload, 2 LDS stream, 3 aligned-wide (default), 4 LDS-transposed, 5-7 multi-row, 8 aligned-wide XCD-contiguous, 10 no-gather probe");
+    PPH_REQUIRE(ctx, (v >= 0 && v <= 14), "spmv_kernel: 0 vector, 1 vector+preload, 2 LDS stream, 3 aligned-wide (default), 4 LDS-transposed, 5-7 multi-row, 8 aligned-wide XCD-contiguous, 10 no-gather probe");
     ctx->spmv_kernel = v;
     return PPH_OK;
   }

@@ -624,17 +624,48 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__
     __syncthreads();
     if (valid) {
       const int64_t s = rowptr[node], e = rowptr[node + 1];
+      // closed-form matching needs an unambiguous decode of the column offset (>= 2 cells per direction)
+      const bool closed = px >= 3 && py >= 3 && (DIM == 2 || nzl >= 2);
       for (int64_t k = s + c; k < e; k += NB) {
         const int32_t j = col[k];
         double kv = 0.0, mv = 0.0;
+        if (closed) {
+          // column = node + (dx, dy, dz); incident cell cc = (cx,cy,cz) holds the node at local corner cc and the
+          // column at corner b = cc + d: per direction d=0 -> corners (0,0),(1,1); d=+1 -> (0,1); d=-1 -> (1,0)
+          const int64_t pxy = (int64_t)px * py;
+          int64_t d = (int64_t)j - node;
+          int dz = 0;
+          if (DIM == 3) { dz = (d > pxy / 2) ? 1 : (d < -(pxy / 2)) ? -1 : 0; d -= dz * pxy; }
+          const int dy = (d > px / 2) ? 1 : (d < -(px / 2)) ? -1 : 0;
+          const int dx = (int)(d - (int64_t)dy * px);
+          const int dd[3] = {dx, dy, dz};
 #pragma unroll 1
-        for (int cc = 0; cc < NB; ++cc)
+          for (int m = 0; m < NB; ++m) {   // m enumerates the candidate corner bits of the incident cell
+            int cc = 0, b = 0;
+            bool okc = true;
 #pragma unroll
-          for (int b = 0; b < NB; ++b) {
-            const bool hit = sC[ln][cc][b] == j;
-            kv += hit ? sK[ln][cc][b] : 0.0;
-            mv += hit ? sM[ln][cc][b] : 0.0;
+            for (int a = 0; a < DIM; ++a) {
+              const int cb = (m >> a) & 1;          // corner bit of the node in the cell
+              const int bb = cb + dd[a];            // corner bit of the column node
+              okc = okc && (bb == 0 || bb == 1);
+              cc |= cb << a;
+              b |= (bb & 1) << a;
+            }
+            if (okc && sC[ln][cc][0] >= 0) {
+              kv += sK[ln][cc][b];
+              mv += sM[ln][cc][b];
+            }
           }
+        } else {
+#pragma unroll 1
+          for (int cc = 0; cc < NB; ++cc)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+              const bool hit = sC[ln][cc][b] == j;
+              kv += hit ? sK[ln][cc][b] : 0.0;
+              mv += hit ? sM[ln][cc][b] : 0.0;
+            }
+        }
         K[k] = kv;
         M[k] = mv;
       }

@@ -35,6 +35,22 @@ __device__ inline double block_sum(double v, double* lds) {
   return v;
 }
 
+// sum over groups of 8 consecutive lanes with DPP row shifts (no LDS crossbar): lane 0 of each group gets
+// the group total
+template <int CTRL>
+__device__ inline double dpp_row_shl(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ inline double group8_sum(double v) {
+  v += dpp_row_shl<0x104>(v);  // row_shl:4
+  v += dpp_row_shl<0x102>(v);  // row_shl:2
+  v += dpp_row_shl<0x101>(v);  // row_shl:1
+  return v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // CSR SpMV, G lanes per row, persistent workgroups, XCD-aware chunk order:
 // workgroups with equal (blockIdx % 8) share an XCD (and its 4 MiB L2), so each XCD walks one
@@ -114,7 +130,7 @@ __global__ __launch_bounds__(256) void k_spmv_wide(const int64_t* __restrict__ r
   const int bpx = gridDim.x >> 3;
   const int64_t cpx = (nchunks + 7) >> 3;
   // MODE 2 (experiment): plain grid-stride chunk order instead of one contiguous eighth per XCD
-  constexpr bool LINEAR = (MODE == 2 || MODE == 3);
+  constexpr bool LINEAR = (MODE >= 2);
   const int64_t c_begin = LINEAR ? 0 : (int64_t)xcd * cpx;
   const int64_t c_end = LINEAR ? nchunks : ((c_begin + cpx < nchunks) ? c_begin + cpx : nchunks);
   const int64_t c_first = LINEAR ? blockIdx.x : c_begin + bx;
@@ -155,14 +171,22 @@ __global__ __launch_bounds__(256) void k_spmv_wide(const int64_t* __restrict__ r
         double x0, x1, x2, x3;
         if (MODE == 1) {  // experiment: no gather (streams the matrix only); results are wrong on purpose
           x0 = x1 = x2 = x3 = (double)(c.x + c.y + c.z + c.w);
+        } else if (MODE == 4) {  // experiment: same 4 gathers, but all addresses inside one 512-byte window of x
+          x0 = x[c.x & 63]; x1 = x[c.y & 63]; x2 = x[c.z & 63]; x3 = x[c.w & 63];
+        } else if (MODE == 5) {  // experiment: one gather instead of four
+          x0 = x[k0 ? c.x : safe]; x1 = x0 + (double)c.y; x2 = x0 + (double)c.z; x3 = x0 + (double)c.w;
         } else {
           x0 = x[k0 ? c.x : safe]; x1 = x[k1 ? c.y : safe]; x2 = x[k2 ? c.z : safe]; x3 = x[k3 ? c.w : safe];
         }
         sum += (k0 ? v01.x : 0.0) * x0 + (k1 ? v01.y : 0.0) * x1 + (k2 ? v23.x : 0.0) * x2 + (k3 ? v23.y : 0.0) * x3;
       }
     }
+    if constexpr (G == 8) {
+      sum = group8_sum(sum);
+    } else {
 #pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, G);
+      for (int o = G / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, G);
+    }
     if (sub == 0 && row < nrows) {
       y[row] = bvec ? bvec[row] - sum : sum;
       if (DOT) acc += sum * x[row];
@@ -171,6 +195,89 @@ __global__ __launch_bounds__(256) void k_spmv_wide(const int64_t* __restrict__ r
   if (DOT) {
     acc = block_sum(acc, lds);
     if (threadIdx.x == 0) part[blockIdx.x] = acc;
+  }
+}
+
+// Row-block streaming variant (one wavefront per workgroup): R consecutive rows own a contiguous range of
+// non-zeros; the wave streams that range with fully contiguous 16-byte loads (columns straight to registers
+// for the x gather, values through LDS because their 2-per-lane layout differs from the columns' 4-per-lane
+// layout), parks the products in LDS and lets two lanes per row sum them.  No masked over-read beyond the
+// 4-alignment of the block start, no per-row pointer dependency in front of the loads.
+// Needs R * max_row + 3 <= 1024.
+template <int R, bool DOT>
+__global__ __launch_bounds__(64) void k_spmv_block(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                   const double* __restrict__ val, const double* __restrict__ x,
+                                                   const double* __restrict__ bvec, double* __restrict__ y,
+                                                   int64_t nrows, double* __restrict__ part) {
+  constexpr int SLOTS = 1024;
+  constexpr int LPR = 64 / R;  // lanes per row in the summation phase (R = 32: 2, R = 16: 4)
+  __shared__ __attribute__((aligned(16))) double sv[SLOTS + 8];
+  __shared__ __attribute__((aligned(16))) double sp[SLOTS + 8];
+  const int lane = threadIdx.x;
+  const int64_t nchunks = (nrows + R - 1) / R;
+  double acc = 0.0;
+  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const int64_t r0 = ch * R;
+    const int64_t rend = (r0 + R < nrows) ? r0 + R : nrows;
+    const int64_t s = rowptr[r0], e = rowptr[rend];
+    const int64_t s4 = s & ~(int64_t)3;
+    const int span = (int)(e - s4);
+    const int lead = (int)(s - s4);
+    // my row's range (summation phase), requested early
+    const int rl = lane / LPR, hl = lane % LPR;
+    const int64_t myrow = r0 + rl;
+    int b = 0, en = 0;
+    if (myrow < rend) {
+      b = (int)(rowptr[myrow] - s4);
+      en = (int)(rowptr[myrow + 1] - s4);
+    }
+    int4 c[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int k = 4 * (lane + 64 * t);
+      c[t] = (k < span) ? *reinterpret_cast<const int4*>(col + s4 + k) : make_int4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = 2 * (lane + 64 * u);
+      if (k < span) *reinterpret_cast<double2*>(sv + k) = *reinterpret_cast<const double2*>(val + s4 + k);
+    }
+    double xs[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int k = 4 * (lane + 64 * t);
+      const bool v0 = k >= lead && k < span, v1 = k + 1 >= lead && k + 1 < span, v2 = k + 2 >= lead && k + 2 < span,
+                 v3 = k + 3 >= lead && k + 3 < span;
+      xs[t][0] = v0 ? x[c[t].x] : 0.0;
+      xs[t][1] = v1 ? x[c[t].y] : 0.0;
+      xs[t][2] = v2 ? x[c[t].z] : 0.0;
+      xs[t][3] = v3 ? x[c[t].w] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int k = 4 * (lane + 64 * t);
+      if (k < span) {
+        const double2 a01 = *reinterpret_cast<const double2*>(sv + k);
+        const double2 a23 = *reinterpret_cast<const double2*>(sv + k + 2);
+        *reinterpret_cast<double2*>(sp + k) = make_double2(a01.x * xs[t][0], a01.y * xs[t][1]);
+        *reinterpret_cast<double2*>(sp + k + 2) = make_double2(a23.x * xs[t][2], a23.y * xs[t][3]);
+      }
+    }
+    __syncthreads();
+    double sum = 0.0;
+    for (int i = b + hl; i < en; i += LPR) sum += sp[i];
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, LPR);
+    if (hl == 0 && myrow < rend) {
+      y[myrow] = bvec ? bvec[myrow] - sum : sum;
+      if (DOT) acc += sum * x[myrow];
+    }
+    __syncthreads();
+  }
+  if (DOT) {
+    acc = wave_sum(acc);
+    if (lane == 0) part[blockIdx.x] = acc;
   }
 }
 
@@ -497,12 +604,27 @@ static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const doub
       hipLaunchKernelGGL((k_spmv_wide_u<8, DOT, 4>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
     else
       hipLaunchKernelGGL((k_spmv_wide_u<4, DOT, 4>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
+  } else if (ctx->spmv_kernel == 14 && A.max_row > 0 && A.max_row * 16 + 3 <= 1024) {
+    const bool r32 = A.max_row * 32 + 3 <= 1024;
+    const int64_t nchunks = ceil_div64(A.nrows, r32 ? 32 : 16);
+    const int64_t cap = (int64_t)g_spmv_blocks * 4;  // one wave per workgroup: 4x the workgroups of the 256-thread kernels
+    grid = (int)(nchunks < cap ? nchunks : cap);
+    if (r32)
+      hipLaunchKernelGGL((k_spmv_block<32, DOT>), dim3(grid), dim3(64), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
+    else
+      hipLaunchKernelGGL((k_spmv_block<16, DOT>), dim3(grid), dim3(64), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
   } else if (ctx->spmv_kernel == 9) {
     grid = spmv_grid(A.nrows, 256 / 8);
     hipLaunchKernelGGL((k_spmv_wide<8, DOT, 3>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
   } else if (ctx->spmv_kernel == 10) {
     grid = spmv_grid(A.nrows, 256 / 8);
     hipLaunchKernelGGL((k_spmv_wide<8, DOT, 1>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
+  } else if (ctx->spmv_kernel == 12) {
+    grid = spmv_grid(A.nrows, 256 / 8);
+    hipLaunchKernelGGL((k_spmv_wide<8, DOT, 4>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
+  } else if (ctx->spmv_kernel == 13) {
+    grid = spmv_grid(A.nrows, 256 / 8);
+    hipLaunchKernelGGL((k_spmv_wide<8, DOT, 5>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
   } else if (ctx->spmv_kernel == 3 || ctx->spmv_kernel == 8 || ctx->spmv_kernel == 11) {
     // lanes per row: one 4-wide step covers 4 G entries; rows of up to 29 entries fit G = 8
     int G = ctx->spmv_lanes_override > 0 ? ctx->spmv_lanes_override : (A.max_row > 0 && A.max_row + 3 <= 16 ? 4 : 8);

@@ -173,10 +173,10 @@ __global__ __launch_bounds__(256) void k_lam_bound(const int64_t* __restrict__ r
 
 // d = dinv .* r / theta ; x = d (zero guess) or x += d
 __global__ void k_cheb_init(double* __restrict__ x, double* __restrict__ d, const double* __restrict__ r,
-                            const double* __restrict__ dinv, double inv_theta, int zero_guess, int64_t n) {
+                            const double* __restrict__ dinv, double inv_theta, int zero_guess, int write_d, int64_t n) {
   NODE_LOOP(i, n) {
     const double di = dinv[i] * r[i] * inv_theta;
-    d[i] = di;
+    if (write_d) d[i] = di;  // only the multi-step recurrence needs the direction
     x[i] = zero_guess ? di : x[i] + di;
   }
 }
@@ -382,13 +382,15 @@ static void chebyshev(pph_ctx* ctx, MgLevel& L, int which, const double* b, doub
   double rho = 1.0 / sigma;
   double* r = L.r.p;
   const int grid = mg_grid(L.n);
+  const double* r0 = r;  // residual the first step starts from
   if (zero_guess) {
-    la_copy(ctx, r, b, L.n);
+    if (steps > 1) la_copy(ctx, r, b, L.n);  // the recurrence updates r in place
+    else r0 = b;                              // single step: read b directly
   } else {
     la_spmv_resid(ctx, A, x, b, r);
   }
-  hipLaunchKernelGGL(k_cheb_init, dim3(grid), dim3(256), 0, ctx->stream, x, L.d.p, r, L.dinv[which].p, 1.0 / theta,
-                     zero_guess ? 1 : 0, L.n);
+  hipLaunchKernelGGL(k_cheb_init, dim3(grid), dim3(256), 0, ctx->stream, x, L.d.p, r0, L.dinv[which].p, 1.0 / theta,
+                     zero_guess ? 1 : 0, steps > 1 ? 1 : 0, L.n);
   for (int s = 1; s < steps; ++s) {
     la_spmv(ctx, A, L.d.p, L.t.p);
     const double rho_new = 1.0 / (2.0 * sigma - rho);
