@@ -304,7 +304,7 @@ static int select_csr(pph_ctx* ctx, int which, Csr* A) {
     case 3: PPH_REQUIRE(ctx, ctx->asm_ok, "blocks not assembled"); A->val = ctx->A11.p; return PPH_OK;
     case 4: PPH_REQUIRE(ctx, ctx->asm_ok, "blocks not assembled"); A->val = ctx->A22.p; return PPH_OK;
     case 5: PPH_REQUIRE(ctx, ctx->asm_ok, "blocks not assembled"); A->val = ctx->A12.p; return PPH_OK;
-    case 6: PPH_REQUIRE(ctx, ctx->asm_ok, "blocks not assembled"); A->val = ctx->A21.p; return PPH_OK;
+    case 6: PPH_REQUIRE(ctx, ctx->asm_ok, "blocks not assembled"); A->val = ctx->A21p(); return PPH_OK;
     default: pph_set_error(ctx, "unknown matrix selector %d", which); return PPH_ERR_INVALID;
   }
 }

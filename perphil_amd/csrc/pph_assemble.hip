@@ -780,6 +780,10 @@ __global__ __launch_bounds__(256) void k_lift_rhs(const int64_t* __restrict__ ro
   }
 }
 
+// 8 lanes per row, every lane owns 4 consecutive entries of the row range rounded down to a multiple of 4 (the
+// layout of the SpMV kernel): 16-byte aligned loads of K, M, col and 16-byte aligned stores of the blocks;
+// entries of neighbouring rows that share a 16/32-byte unit are written by neighbouring lane groups of the same
+// wave instruction.  A21 == A12 when both fields carry the same Dirichlet set: then A21 is not written (null).
 __global__ __launch_bounds__(256) void k_blocks(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                 const double* __restrict__ K, const double* __restrict__ M,
                                                 const uint8_t* __restrict__ m1, const uint8_t* __restrict__ m2,
@@ -790,18 +794,60 @@ __global__ __launch_bounds__(256) void k_blocks(const int64_t* __restrict__ rowp
   for (int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / BC_LANES; row < n;
        row += ((int64_t)gridDim.x * blockDim.x) / BC_LANES) {
     const uint8_t r1 = m1[row], r2 = m2[row];
-    for (int64_t k = rowptr[row] + sub; k < rowptr[row + 1]; k += BC_LANES) {
-      const int32_t j = col[k];
-      const double kk = K[k], mm = M[k];
-      const bool diag = (j == (int32_t)row);
-      const bool c1 = (m1[j] & 1) != 0, c2 = (m2[j] & 1) != 0;
-      // ghost rows (bit 1) belong to the neighbouring slab: empty here; Dirichlet rows: identity
-      A11[k] = (r1 & 2) ? 0.0 : (r1 & 1) ? (diag ? 1.0 : 0.0) : (c1 ? 0.0 : a * kk + b * mm);
-      A22[k] = (r2 & 2) ? 0.0 : (r2 & 1) ? (diag ? 1.0 : 0.0) : (c2 ? 0.0 : c * kk + b * mm);
-      A12[k] = (r1 != 0 || c2) ? 0.0 : -b * mm;
-      A21[k] = (r2 != 0 || c1) ? 0.0 : -b * mm;
+    const int64_t s = rowptr[row], e = rowptr[row + 1];
+    for (int64_t base = (s & ~(int64_t)3) + 4 * sub; base < e; base += 4 * BC_LANES) {
+      const int4 cj = *reinterpret_cast<const int4*>(col + base);
+      const double2 k01 = *reinterpret_cast<const double2*>(K + base), k23 = *reinterpret_cast<const double2*>(K + base + 2);
+      const double2 q01 = *reinterpret_cast<const double2*>(M + base), q23 = *reinterpret_cast<const double2*>(M + base + 2);
+      const int32_t jj[4] = {cj.x, cj.y, cj.z, cj.w};
+      const double kk4[4] = {k01.x, k01.y, k23.x, k23.y};
+      const double mm4[4] = {q01.x, q01.y, q23.x, q23.y};
+      double o11[4], o22[4], o12[4], o21[4];
+      bool in[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        in[t] = base + t >= s && base + t < e;
+        const int32_t j = in[t] ? jj[t] : 0;
+        const double kk = kk4[t], mm = mm4[t];
+        const bool diag = (j == (int32_t)row);
+        const bool c1 = (m1[j] & 1) != 0, c2 = (m2[j] & 1) != 0;
+        // ghost rows (bit 1) belong to the neighbouring slab: empty here; Dirichlet rows: identity
+        o11[t] = (r1 & 2) ? 0.0 : (r1 & 1) ? (diag ? 1.0 : 0.0) : (c1 ? 0.0 : a * kk + b * mm);
+        o22[t] = (r2 & 2) ? 0.0 : (r2 & 1) ? (diag ? 1.0 : 0.0) : (c2 ? 0.0 : c * kk + b * mm);
+        o12[t] = (r1 != 0 || c2) ? 0.0 : -b * mm;
+        o21[t] = (r2 != 0 || c1) ? 0.0 : -b * mm;
+      }
+      if (in[0] && in[1] && in[2] && in[3]) {
+        *reinterpret_cast<double2*>(A11 + base) = make_double2(o11[0], o11[1]);
+        *reinterpret_cast<double2*>(A11 + base + 2) = make_double2(o11[2], o11[3]);
+        *reinterpret_cast<double2*>(A22 + base) = make_double2(o22[0], o22[1]);
+        *reinterpret_cast<double2*>(A22 + base + 2) = make_double2(o22[2], o22[3]);
+        *reinterpret_cast<double2*>(A12 + base) = make_double2(o12[0], o12[1]);
+        *reinterpret_cast<double2*>(A12 + base + 2) = make_double2(o12[2], o12[3]);
+        if (A21) {
+          *reinterpret_cast<double2*>(A21 + base) = make_double2(o21[0], o21[1]);
+          *reinterpret_cast<double2*>(A21 + base + 2) = make_double2(o21[2], o21[3]);
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          if (in[t]) {
+            A11[base + t] = o11[t];
+            A22[base + t] = o22[t];
+            A12[base + t] = o12[t];
+            if (A21) A21[base + t] = o21[t];
+          }
+      }
     }
   }
+}
+
+__global__ void k_mask_diff(const uint8_t* __restrict__ m1, const uint8_t* __restrict__ m2, int64_t n,
+                            int* __restrict__ out) {
+  int d = 0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    d |= (m1[i] != m2[i]) ? 1 : 0;
+  if (d) atomicOr(out, 1);
 }
 
 // monolithic field-major CSR: row i < n = [A11 row | A12 row], row n+i = [A21 row | A22 row]
@@ -840,7 +886,18 @@ int pph_launch_blocks(pph_ctx* ctx, int monolithic) {
   PPH_TRY(ctx->A11.alloc(ctx, (size_t)nnzb));
   PPH_TRY(ctx->A22.alloc(ctx, (size_t)nnzb));
   PPH_TRY(ctx->A12.alloc(ctx, (size_t)nnzb));
-  PPH_TRY(ctx->A21.alloc(ctx, (size_t)nnzb));
+  // same Dirichlet set on both fields (every reference configuration): A21 == A12, stored once
+  {
+    int* flag = reinterpret_cast<int*>(ctx->scal.p + (PPH_MAX_SCAL - 200));
+    int h = 0;
+    PPH_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(k_mask_diff, dim3(1024), dim3(256), 0, ctx->stream, ctx->bcmask[0].p, ctx->bcmask[1].p, n, flag);
+    PPH_HIP(ctx, hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->a21_alias = (h == 0);
+  }
+  if (ctx->a21_alias) ctx->A21.release();
+  else PPH_TRY(ctx->A21.alloc(ctx, (size_t)nnzb));
   PPH_TRY(ctx->rhs.alloc(ctx, (size_t)(2 * n)));
   PPH_TRY(ctx->u0.alloc(ctx, (size_t)(2 * n)));
   PPH_TRY(ctx->sol.alloc(ctx, (size_t)(2 * n)));
@@ -851,7 +908,7 @@ int pph_launch_blocks(pph_ctx* ctx, int monolithic) {
                      n, ctx->rhs.p, ctx->u0.p);
   hipLaunchKernelGGL(k_blocks, dim3(grid), dim3(256), 0, ctx->stream, ctx->mesh.rowptr.p, ctx->mesh.col.p, ctx->mesh.K.p, ctx->mesh.M.p,
                      ctx->bcmask[0].p, ctx->bcmask[1].p, ctx->a, ctx->b, ctx->c, n, ctx->A11.p, ctx->A22.p,
-                     ctx->A12.p, ctx->A21.p);
+                     ctx->A12.p, ctx->a21_alias ? nullptr : ctx->A21.p);
   PPH_HIP(ctx, hipGetLastError());
   ctx->mono_ok = false;
   if (monolithic) {
@@ -863,7 +920,7 @@ int pph_launch_blocks(pph_ctx* ctx, int monolithic) {
     int g2 = (int)(ceil_div64(n + 1, 256) < 4096 ? ceil_div64(n + 1, 256) : 4096);
     hipLaunchKernelGGL(k_mono_rowptr, dim3(g2), dim3(256), 0, ctx->stream, ctx->mesh.rowptr.p, n, nnzb, ctx->mrowptr.p);
     hipLaunchKernelGGL(k_mono_fill, dim3(grid), dim3(256), 0, ctx->stream, ctx->mesh.rowptr.p, ctx->mesh.col.p, ctx->A11.p,
-                       ctx->A22.p, ctx->A12.p, ctx->A21.p, n, nnzb, ctx->mcol.p, ctx->mval.p);
+                       ctx->A22.p, ctx->A12.p, ctx->a21_alias ? ctx->A12.p : ctx->A21.p, n, nnzb, ctx->mcol.p, ctx->mval.p);
     PPH_HIP(ctx, hipGetLastError());
     ctx->mono_ok = true;
   }

@@ -125,6 +125,8 @@ struct pph_ctx {
   DevBuf<uint8_t> bcmask[2];            // per field: 1 Dirichlet, 2 ghost, 0 free
   DevBuf<double> g[2];                  // per field Dirichlet values (dense, 0 elsewhere)
   DevBuf<double> A11, A22, A12, A21;    // eliminated blocks on the scalar pattern
+  bool a21_alias = false;               // both fields share one Dirichlet set: A21 == A12, A21 not stored
+  const double* A21p() const { return a21_alias ? A12.p : A21.p; }
   DevBuf<double> rhs, u0, sol;          // length 2n
   DevBuf<int64_t> mrowptr;              // monolithic CSR
   DevBuf<int32_t> mcol;

@@ -386,7 +386,7 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
   PPH_TRY(work(ctx, W_DU, (size_t)N, &du));
   BlockSolver bs;
   bs.ctx = ctx; bs.cfg = cfg;
-  const Csr A12 = block_csr(ctx, ctx->A12.p), A21 = block_csr(ctx, ctx->A21.p);
+  const Csr A12 = block_csr(ctx, ctx->A12.p), A21 = block_csr(ctx, ctx->A21p());
   int status = PPH_OK;
 
   if (cfg->picard) {
@@ -488,7 +488,7 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
       PPH_TRY(work(ctx, W_BINV, (size_t)(4 * n), &binv));
       int grid = (int)(ceil_div64(n, 256) < 2048 ? ceil_div64(n, 256) : 2048);
       hipLaunchKernelGGL(k_block2_build, dim3(grid), dim3(256), 0, ctx->stream, ctx->mesh.rowptr.p, ctx->mesh.col.p,
-                         ctx->A11.p, ctx->A22.p, ctx->A12.p, ctx->A21.p, n, binv);
+                         ctx->A11.p, ctx->A22.p, ctx->A12.p, ctx->A21p(), n, binv);
       pc = [&, binv](const double* in, double* o) { la_block2_apply(ctx, o, binv, in, n); };
     } else if (cfg->pc_type == PPH_PC_FIELDSPLIT) {
       // multiplicative: z1 = A11^-1 r1 ; z2 = A22^-1 (r2 - A21 z1)   (parameters.py:30-37)
