@@ -749,7 +749,7 @@ void la_set(pph_ctx* ctx, double* x, double v, int64_t n) {
   hipLaunchKernelGGL(k_set, dim3(ew_grid(n)), dim3(256), 0, ctx->stream, x, v, n);
 }
 void la_copy(pph_ctx* ctx, double* dst, const double* src, int64_t n) {
-  hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream);
+  (void)hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream);
 }
 void la_axpy(pph_ctx* ctx, double* y, double alpha, const double* x, int64_t n) {
   hipLaunchKernelGGL(k_axpy, dim3(ew_grid(n)), dim3(256), 0, ctx->stream, y, alpha, x, n);
@@ -870,7 +870,7 @@ static void maxpy_impl(pph_ctx* ctx, double* w, const double* V, int64_t ld, int
                        int64_t n) {
   // coefficients travel through a device slot region at the end of the result area
   double* dh = ctx->scal.p + (PPH_MAX_SCAL - 64);
-  hipMemcpyAsync(dh, h, sizeof(double) * (size_t)k, hipMemcpyHostToDevice, ctx->stream);
+  (void)hipMemcpyAsync(dh, h, sizeof(double) * (size_t)k, hipMemcpyHostToDevice, ctx->stream);
   hipLaunchKernelGGL(k_maxpy, dim3(ew_grid(n)), dim3(256), 0, ctx->stream, w, V, ld, k, dh, sign, n);
 }
 void la_maxpy_neg(pph_ctx* ctx, double* w, const double* V, int64_t ld, int k, const double* h, int64_t n) {

@@ -94,6 +94,8 @@ def main():
     g["G7_G9_perf_2d_q1"] = perf(os.path.join(NB, "results-conforming-2d/petsc_profiling/petsc_perf_breakdown.csv"))
     g["G10_convergence_2d"] = [
         {k: (v if k == "solver" else float(v)) for k, v in r.items()} for r in _rows(os.path.join(NB, "results-conforming-2d/convergence.csv"))]
+    with open(os.path.join(NB, "results-conforming-3d/petsc_profiling/petsc_perf_breakdown_3d.csv")) as f:
+        g["perf_csv_columns_3d"] = f.readline().strip().split(",")
     g["G12_structure"] = {"mesh_2x2_dofs": 18, "mesh_2x2_num_cells": 4, "form_integrals": 4, "form_rank": 2}
     here = os.path.dirname(os.path.abspath(__file__))
     with open(os.path.join(here, "reference_goldens.json"), "w") as f:

@@ -484,3 +484,25 @@ def test_conditioning_and_harness_api(gpu_ctx_factory, goldens):
     assert ib.params_for(ib.Approach.SS_GMRES)["pc_type"] == "fieldsplit"
     res = ib.solve_on_mesh(W8, ib.Approach.SS_GMRES)
     assert isinstance(res, ib.SolveResult) and res.iteration_number >= 0 and res.fields is not None
+
+
+def test_perf_harness_row_schema(gpu_ctx_factory, goldens):
+    """run_perf_once_3d mirrors the reference's flat row: same column names, dofs / cells / iteration
+    counts of the committed CSV for the rows that are algorithm-independent (reference
+    experiments/_tests/test_petsc_profiling.py:16-58)."""
+    import warnings
+    from perphil_amd.iterative_bench import Approach
+    from perphil_amd.profiling_3d import run_perf_once_3d, run_perf_sweep_3d
+
+    cols = [c for c in goldens["perf_csv_columns_3d"]]
+    row = run_perf_once_3d(4, Approach.PLAIN_GMRES, repeats=2)
+    assert list(row.keys()) == cols
+    g = next(r for r in goldens["G6_G9_perf_3d_tets"] if r["approach"] == "GMRES" and r["nx"] == 4)
+    assert row["dofs"] == g["dofs"] and row["num_cells"] == g["num_cells"] and abs(row["iterations"] - g["iterations"]) <= 1
+    assert row["time_MatMult"] > 0 and row["time_KSPSolve"] >= row["time_MatMult"] and row["mflops_MatMult"] > 0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        df = run_perf_sweep_3d([4, 8], [Approach.SS_GMRES, Approach.MONOLITHIC_MUMPS], repeats=1)
+    assert list(df.columns) == cols and len(df) == 4
+    assert list(df[df.approach == "Scale-Splitting GMRES"].iterations) == [4, 4]     # G9
+    assert list(df[df.approach == "Monolithic LU with MUMPS"].iterations) == [1, 1]
