@@ -673,6 +673,125 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Node-centred assembly for simplices (P1 triangles: 2 per square, P1 tetrahedra: 6 Kuhn tets per cube):
+// one thread per node walks the cells of its (up to) 2^d incident boxes, keeps those that contain the node
+// (membership and local index from the cell->dof map), evaluates the constant gradients and adds the node's
+// row of K_e / M_e into the CSR row held in registers; fixed order, no atomics, every entry written once.
+// ------------------------------------------------------------------------------------------------
+template <int DIM>
+__global__ __launch_bounds__(256) void k_asm_simplex_gather(const int32_t* __restrict__ cells,
+                                                            const double* __restrict__ cx, const double* __restrict__ cy,
+                                                            const double* __restrict__ cz,
+                                                            const int64_t* __restrict__ rowptr,
+                                                            const int32_t* __restrict__ col, double* __restrict__ K,
+                                                            double* __restrict__ M, int nx, int ny, int nzl, int px, int py,
+                                                            int64_t n) {
+  constexpr int NB = DIM + 1;
+  constexpr int NSUB = (DIM == 2) ? 2 : 6;
+  constexpr int MAXROW = (DIM == 2) ? 7 : 15;
+  for (int64_t node = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; node < n;
+       node += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(node % px);
+    const int64_t t = node / px;
+    const int j = (int)(t % py), k = (int)(t / py);
+    const int64_t s = rowptr[node];
+    const int len = (int)(rowptr[node + 1] - s);
+    int32_t cl[MAXROW];
+    double aK[MAXROW], aM[MAXROW];
+#pragma unroll
+    for (int q = 0; q < MAXROW; ++q) {
+      cl[q] = (q < len) ? col[s + q] : -1;
+      aK[q] = 0.0;
+      aM[q] = 0.0;
+    }
+    for (int c = 0; c < (1 << DIM); ++c) {
+      const int bi = i - (c & 1), bj = j - ((c >> 1) & 1), bk = (DIM == 3) ? k - ((c >> 2) & 1) : 0;
+      if (bi < 0 || bi >= nx || bj < 0 || bj >= ny || (DIM == 3 && (bk < 0 || bk >= nzl))) continue;
+      const int64_t box = bi + (int64_t)nx * (bj + (int64_t)ny * bk);
+      for (int sub = 0; sub < NSUB; ++sub) {
+        const int64_t cell = box * NSUB + sub;
+        int32_t nd[NB];
+        int a = -1;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          nd[b] = cells[cell * NB + b];
+          a = (nd[b] == (int32_t)node) ? b : a;
+        }
+        if (a < 0) continue;
+        double X[NB][DIM];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          X[b][0] = cx[nd[b]];
+          X[b][1] = cy[nd[b]];
+          if constexpr (DIM == 3) X[b][2] = cz[nd[b]];
+        }
+        double E[DIM][DIM];
+#pragma unroll
+        for (int r = 0; r < DIM; ++r)
+#pragma unroll
+          for (int d = 0; d < DIM; ++d) E[r][d] = X[r + 1][d] - X[0][d];
+        double det, G[NB][DIM];
+        if constexpr (DIM == 2) {
+          det = E[0][0] * E[1][1] - E[0][1] * E[1][0];
+          const double r = 1.0 / det;
+          G[1][0] = E[1][1] * r;  G[1][1] = -E[1][0] * r;
+          G[2][0] = -E[0][1] * r; G[2][1] = E[0][0] * r;
+        } else {
+          const double c00 = E[1][1] * E[2][2] - E[1][2] * E[2][1];
+          const double c01 = E[1][2] * E[2][0] - E[1][0] * E[2][2];
+          const double c02 = E[1][0] * E[2][1] - E[1][1] * E[2][0];
+          det = E[0][0] * c00 + E[0][1] * c01 + E[0][2] * c02;
+          const double r = 1.0 / det;
+          G[1][0] = c00 * r; G[1][1] = c01 * r; G[1][2] = c02 * r;
+          G[2][0] = (E[0][2] * E[2][1] - E[0][1] * E[2][2]) * r;
+          G[2][1] = (E[0][0] * E[2][2] - E[0][2] * E[2][0]) * r;
+          G[2][2] = (E[0][1] * E[2][0] - E[0][0] * E[2][1]) * r;
+          G[3][0] = (E[0][1] * E[1][2] - E[0][2] * E[1][1]) * r;
+          G[3][1] = (E[0][2] * E[1][0] - E[0][0] * E[1][2]) * r;
+          G[3][2] = (E[0][0] * E[1][1] - E[0][1] * E[1][0]) * r;
+        }
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) {
+          double sg = 0.0;
+#pragma unroll
+          for (int b = 1; b < NB; ++b) sg += G[b][d];
+          G[0][d] = -sg;
+        }
+        const double vol = fabs(det) / (DIM == 2 ? 2.0 : 6.0);
+        const double mfac = vol / (double)((DIM + 1) * (DIM + 2));
+        double Ga[DIM];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) {
+          double g = 0.0;
+#pragma unroll
+          for (int b = 0; b < NB; ++b) g = (b == a) ? G[b][d] : g;
+          Ga[d] = g;
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          double dotg = 0.0;
+#pragma unroll
+          for (int d = 0; d < DIM; ++d) dotg += Ga[d] * G[b][d];
+          const double kv = vol * dotg, mv = (b == a) ? 2.0 * mfac : mfac;
+#pragma unroll
+          for (int q = 0; q < MAXROW; ++q) {
+            const bool hit = cl[q] == nd[b];
+            aK[q] += hit ? kv : 0.0;
+            aM[q] += hit ? mv : 0.0;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < MAXROW; ++q)
+      if (q < len) {
+        K[s + q] = aK[q];
+        M[s + q] = aM[q];
+      }
+  }
+}
+
 int pph_launch_assemble_KM(pph_ctx* ctx_, MeshData& mesh) {
   pph_ctx* ctx = ctx_;
   PPH_TRY(mesh.K.alloc(ctx, (size_t)mesh.nnzb));
@@ -713,6 +832,21 @@ int pph_launch_assemble_KM(pph_ctx* ctx_, MeshData& mesh) {
       hipLaunchKernelGGL(k_asm_gather<3>, dim3(grid), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p, mesh.cy.p,
                          mesh.cz.p, mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, mesh.nx, mesh.ny, mesh.nzl, mesh.px,
                          mesh.py, mesh.n);
+    PPH_HIP(ctx, hipGetLastError());
+    return PPH_OK;
+  }
+  if (!multilinear && ctx->asm_kernel != 0) {
+    // simplices: node-centred gather (deterministic)
+    int64_t nb = ceil_div64(mesh.n, 256);
+    int grid = (int)(nb < 256 * 32 ? nb : 256 * 32);
+    if (mesh.kind == PPH_CELL_TRI)
+      hipLaunchKernelGGL(k_asm_simplex_gather<2>, dim3(grid), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p,
+                         mesh.cy.p, mesh.cz.p, mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, mesh.nx, mesh.ny, 0, mesh.px,
+                         mesh.py, mesh.n);
+    else
+      hipLaunchKernelGGL(k_asm_simplex_gather<3>, dim3(grid), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p,
+                         mesh.cy.p, mesh.cz.p, mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, mesh.nx, mesh.ny, mesh.nzl,
+                         mesh.px, mesh.py, mesh.n);
     PPH_HIP(ctx, hipGetLastError());
     return PPH_OK;
   }

@@ -100,6 +100,27 @@ def test_mesh_dofmap_pattern_bit_exact(gpu_ctx_factory, dim, kind, nx, ny, nz):
     assert A.shape == (2 * n, 2 * n)
 
 
+@pytest.mark.parametrize("dim,kind,nx,ny,nz", [(2, o.CELL_TRI, 5, 4, 0), (3, o.CELL_TET, 4, 3, 5), (3, o.CELL_TET, 7, 7, 7)])
+def test_simplex_scatter_and_gather_assembly_agree(gpu_ctx_factory, dim, kind, nx, ny, nz):
+    f = _ffi()
+    om = o.build_mesh(dim, kind, nx, ny, nz)
+    Ko, Mo = o.assemble_scalar(om)
+    out = []
+    for mode in (0, 2, 2):
+        ctx = gpu_ctx_factory()
+        ctx.mesh_build(dim, kind, nx, ny, nz)
+        ctx.set_option("asm_kernel", mode)
+        b = o.boundary_nodes(om)
+        ctx.set_dirichlet(0, b, np.zeros(len(b)))
+        ctx.set_dirichlet(1, b, np.zeros(len(b)))
+        ctx.assemble(1.0, 0.01, 1.0, 1.0, monolithic=False)
+        K, M = ctx.csr(f.MAT_K), ctx.csr(f.MAT_M)
+        assert abs(K - Ko).max() <= VAL_RTOL * abs(Ko).max() and abs(M - Mo).max() <= VAL_RTOL * abs(Mo).max()
+        out.append((K.data.copy(), M.data.copy()))
+    np.testing.assert_array_equal(out[1][0], out[2][0])   # gather: bitwise reproducible
+    np.testing.assert_array_equal(out[1][1], out[2][1])
+
+
 @pytest.mark.parametrize("nx,ny,nz", [(5, 3, 0), (3, 4, 5), (9, 9, 9)])
 def test_scatter_and_gather_assembly_agree(gpu_ctx_factory, nx, ny, nz):
     """The deterministic node-centred gather kernel (default) and the cell-centred atomic scatter-add
