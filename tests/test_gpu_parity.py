@@ -527,3 +527,23 @@ def test_perf_harness_row_schema(gpu_ctx_factory, goldens):
     assert list(df.columns) == cols and len(df) == 4
     assert list(df[df.approach == "Scale-Splitting GMRES"].iterations) == [4, 4]     # G9
     assert list(df[df.approach == "Monolithic LU with MUMPS"].iterations) == [1, 1]
+
+
+@pytest.mark.parametrize("dim,kind,nx,ny,nz", [(3, o.CELL_HEX, 12, 8, 4), (3, o.CELL_HEX, 9, 5, 7), (3, o.CELL_TET, 6, 10, 4),
+                                               (2, o.CELL_QUAD, 24, 8, 0), (2, o.CELL_TRI, 7, 9, 0), (3, o.CELL_HEX, 1, 1, 1),
+                                               (2, o.CELL_QUAD, 1, 3, 0)])
+def test_ragged_meshes_all_solvers(gpu_ctx_factory, dim, kind, nx, ny, nz):
+    """Non-cubic, odd and minimal meshes: partial multigrid hierarchies (coarsening stops at the first odd
+    direction; single level = polynomial preconditioner), every solver family against the direct solution."""
+    f = _ffi()
+    ctx, om, osys = _setup(gpu_ctx_factory, dim, kind, nx, ny, nz)
+    ud = o.solve_direct(osys)
+    scale = max(np.abs(ud).max(), 1e-300)
+    for cfg in (_cfg(picard=1, inner_pc_type=f.PC_MG, inner_rtol=1e-12, picard_rtol=1e-10),
+                _cfg(picard=1, inner_pc_type=f.PC_MG, inner_rtol=1e-12, picard_rtol=1e-10, inner_reduction=1e-2, mg_smooth=1),
+                _cfg(pc_type=f.PC_FIELDSPLIT, inner_pc_type=f.PC_MG, inner_rtol=1e-12, rtol=1e-10),
+                _cfg(ksp_type=f.KSP_CG, pc_type=f.PC_BLOCK2, rtol=1e-10),
+                _cfg(pc_type=f.PC_JACOBI, rtol=1e-10)):
+        x, info, _ = ctx.solve(cfg)
+        assert info.converged
+        assert np.abs(x - ud).max() / scale < 1e-7
