@@ -379,7 +379,7 @@ int pph_spmv_bench(pph_ctx* ctx, int which, int reps, double* avg_ms) {
   PPH_TRY(x.alloc(ctx, (size_t)A.nrows));
   PPH_TRY(y.alloc(ctx, (size_t)A.nrows));
   hipLaunchKernelGGL(k_fill_pattern, dim3(2048), dim3(256), 0, ctx->stream, x.p, A.nrows);
-  for (int i = 0; i < 3; ++i) la_spmv(ctx, A, x.p, y.p);
+  for (int i = 0; i < 20; ++i) la_spmv(ctx, A, x.p, y.p);  // warm-up (SURVEY.md §8d protocol: 20 + 200)
   PPH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   for (int i = 0; i < reps; ++i) la_spmv(ctx, A, x.p, y.p);
   PPH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -403,7 +403,7 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
   }
   if (!strcmp(name, "spmv_kernel")) {
     const int v = (int)value;
-    PPH_REQUIRE(ctx, (v >= 0 && v <= 14), "spmv_kernel: 0 vector, 1 vector+preload, 2 LDS stream, 3 aligned-wide (default), 4 LDS-transposed, 5-7 multi-row, 8 aligned-wide XCD-contiguous, 10 no-gather probe");
+    PPH_REQUIRE(ctx, (v >= 0 && v <= 15), "spmv_kernel: 0 vector, 1 vector+preload, 2 LDS stream, 3 aligned-wide (default), 4 LDS-transposed, 5-7 multi-row, 8 aligned-wide XCD-contiguous, 10 no-gather probe");
     ctx->spmv_kernel = v;
     return PPH_OK;
   }

@@ -281,6 +281,50 @@ __global__ __launch_bounds__(64) void k_spmv_block(const int64_t* __restrict__ r
   }
 }
 
+// Variant of the aligned-wide kernel in which every load INSTRUCTION of a lane group is contiguous: the group's
+// 32 slots are covered by two column loads (8 B per lane) and two value loads (16 B per lane) over slots
+// [2 sub, 2 sub + 1] and [16 + 2 sub, 17 + 2 sub] instead of one 16-byte column load and two interleaved value
+// loads per lane (which touch every 128-byte line of the values twice).
+template <bool DOT>
+__global__ __launch_bounds__(256) void k_spmv_wide2(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                    const double* __restrict__ val, const double* __restrict__ x,
+                                                    const double* __restrict__ bvec, double* __restrict__ y,
+                                                    int64_t nrows, double* __restrict__ part) {
+  constexpr int G = 8, RPB = 256 / G;
+  __shared__ double lds[4];
+  const int sub = threadIdx.x % G;
+  const int grp = threadIdx.x / G;
+  const int64_t nchunks = (nrows + RPB - 1) / RPB;
+  double acc = 0.0;
+  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const int64_t row = ch * RPB + grp;
+    double sum = 0.0;
+    if (row < nrows) {
+      const int64_t s = rowptr[row], e = rowptr[row + 1];
+      for (int64_t g0 = (s & ~(int64_t)3); g0 < e; g0 += 32) {
+        const int64_t ba = g0 + 2 * sub, bb = g0 + 16 + 2 * sub;
+        const bool la = ba < e, lb = bb < e;
+        int2 ca = make_int2(0, 0), cb = make_int2(0, 0);
+        double2 va = make_double2(0.0, 0.0), vb = make_double2(0.0, 0.0);
+        if (la) { ca = *reinterpret_cast<const int2*>(col + ba); va = *reinterpret_cast<const double2*>(val + ba); }
+        if (lb) { cb = *reinterpret_cast<const int2*>(col + bb); vb = *reinterpret_cast<const double2*>(val + bb); }
+        const bool k0 = ba >= s && ba < e, k1 = ba + 1 >= s && ba + 1 < e, k2 = bb >= s && bb < e, k3 = bb + 1 >= s && bb + 1 < e;
+        const double x0 = x[k0 ? ca.x : 0], x1 = x[k1 ? ca.y : 0], x2 = x[k2 ? cb.x : 0], x3 = x[k3 ? cb.y : 0];
+        sum += (k0 ? va.x : 0.0) * x0 + (k1 ? va.y : 0.0) * x1 + (k2 ? vb.x : 0.0) * x2 + (k3 ? vb.y : 0.0) * x3;
+      }
+    }
+    sum = group8_sum(sum);
+    if (sub == 0 && row < nrows) {
+      y[row] = bvec ? bvec[row] - sum : sum;
+      if (DOT) acc += sum * x[row];
+    }
+  }
+  if (DOT) {
+    acc = block_sum(acc, lds);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+  }
+}
+
 // Aligned-wide CSR-vector kernel with UR rows in flight per lane group: the dependent chain
 // rowptr -> (columns, values) -> x gather is latency-bound when a wave carries one row per group
 // (about 3 KB in flight), so every group walks UR row-chunks at once: all row pointers are requested
@@ -613,6 +657,9 @@ static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const doub
       hipLaunchKernelGGL((k_spmv_block<32, DOT>), dim3(grid), dim3(64), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
     else
       hipLaunchKernelGGL((k_spmv_block<16, DOT>), dim3(grid), dim3(64), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
+  } else if (ctx->spmv_kernel == 15) {
+    grid = spmv_grid(A.nrows, 256 / 8);
+    hipLaunchKernelGGL((k_spmv_wide2<DOT>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
   } else if (ctx->spmv_kernel == 9) {
     grid = spmv_grid(A.nrows, 256 / 8);
     hipLaunchKernelGGL((k_spmv_wide<8, DOT, 3>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);

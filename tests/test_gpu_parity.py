@@ -181,7 +181,7 @@ def test_G1_initial_residual_and_spmv(gpu_ctx_factory, goldens):
     rng = np.random.default_rng(20260313)
     x = rng.uniform(-1, 1, 2 * osys.n)
     ref = osys.A @ x
-    for kern in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 14):   # CSR-vector, with preload, CSR-stream, aligned-wide, LDS-transposed
+    for kern in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 14, 15):   # CSR-vector, with preload, CSR-stream, aligned-wide, LDS-transposed
         ctx.set_option("spmv_kernel", kern)
         for lanes in (0, 4, 8, 16, 32, 64):
             ctx.set_option("spmv_lanes", lanes)
