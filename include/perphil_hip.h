@@ -157,6 +157,10 @@ int pph_spmv(pph_ctx* ctx, int which, const double* x_host, double* y_host);
 /* `reps` back-to-back device SpMVs on resident vectors, average kernel ms via HIP events */
 int pph_spmv_bench(pph_ctx* ctx, int which, int reps, double* avg_ms);
 
+/* HBM bandwidth calibration on this device (tools/bw_probe.py, tools/pmc_probe.py): `bytes` streamed with
+ * 16 B per lane by `blocks` workgroups, mode 0 read-only, mode 1 copy; average ms per launch. */
+int pph_bw_probe(pph_ctx* ctx, int64_t bytes, int mode, int blocks, double* ms_out);
+
 /* ---- error norms (post-processing) -----------------------------------------------------------------
  * replaces: l2_error() / h1_seminorm_error() (reference src/perphil/utils/postprocessing.py:89-124) for
  * the manufactured pressures of src/perphil/utils/manufactured_solutions.py:39-51 (2D), :87-88 (3D).

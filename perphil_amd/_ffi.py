@@ -33,7 +33,7 @@ EXPORTS = [
     "pph_solve", "pph_solve_device", "pph_get_solution",
     "pph_csr_sizes", "pph_get_csr", "pph_get_rhs", "pph_spmv", "pph_spmv_bench",
     "pph_get_timers", "pph_set_option", "pph_comm_set_callbacks",
-    "pph_rccl_unique_id", "pph_comm_init_rccl", "pph_comm_selftest", "pph_error_norms_mms",
+    "pph_rccl_unique_id", "pph_comm_init_rccl", "pph_comm_selftest", "pph_error_norms_mms", "pph_bw_probe",
 ]
 
 HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64)
@@ -124,6 +124,7 @@ def _load() -> C.CDLL:
         "pph_rccl_unique_id": ([C.c_char_p, C.c_void_p], C.c_int),
         "pph_comm_init_rccl": ([p, C.c_int, C.c_int, C.c_void_p, C.c_char_p], C.c_int),
         "pph_comm_selftest": ([p], C.c_int),
+        "pph_bw_probe": ([p, C.c_int64, C.c_int, C.c_int, f64p], C.c_int),
         "pph_error_norms_mms": ([p, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, f64p,
                                  f64p], C.c_int),
     }

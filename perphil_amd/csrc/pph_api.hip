@@ -7,7 +7,6 @@
 #include <new>
 
 static thread_local std::string g_last_error;
-void la_set_spmv_blocks(int b);
 
 void pph_set_error(pph_ctx* ctx, const char* fmt, ...) {
   char buf[1024];
@@ -421,7 +420,7 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
     ctx->mg_ok = false;
     return PPH_OK;
   }
-  if (!strcmp(name, "spmv_blocks")) { la_set_spmv_blocks((int)value); return PPH_OK; }
+  if (!strcmp(name, "spmv_blocks")) { ctx->spmv_blocks = (int)value; return PPH_OK; }
   if (!strcmp(name, "time_spmv")) { ctx->time_spmv = value != 0.0; return PPH_OK; }
   if (!strcmp(name, "invalidate_KM")) {
     // forget the integrated K and M (all multigrid levels) so that the next assemble + solve integrates
@@ -464,6 +463,7 @@ int pph_get_timers(pph_ctx* ctx, double* out, int n) {
 }  // extern "C"
 
 // ---- bandwidth calibration (no reference counterpart; used by tools/ and DESIGN.md) -------------------
+
 __global__ __launch_bounds__(256) void k_bw_read(const double2* __restrict__ a, int64_t n2, double* __restrict__ out) {
   double s = 0.0;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n2; i += (int64_t)gridDim.x * blockDim.x) {

@@ -555,12 +555,10 @@ __global__ __launch_bounds__(256) void k_reduce_final(const double* __restrict__
   if (threadIdx.x == 0) out[blockIdx.x] = v;
 }
 
-static int g_spmv_blocks = SPMV_DEF_BLOCKS;  // tuning knob (option "spmv_blocks")
-void la_set_spmv_blocks(int b) { g_spmv_blocks = (b >= 8 && b <= SPMV_MAX_BLOCKS) ? (b / 8) * 8 : SPMV_DEF_BLOCKS; }
-
-static int spmv_grid(int64_t nrows, int rows_per_block) {
+static int spmv_grid(const pph_ctx* ctx, int64_t nrows, int rows_per_block) {
+  const int cap = (ctx->spmv_blocks >= 8 && ctx->spmv_blocks <= SPMV_MAX_BLOCKS) ? (ctx->spmv_blocks / 8) * 8 : SPMV_DEF_BLOCKS;
   int64_t nchunks = ceil_div64(nrows, rows_per_block);
-  int64_t g = nchunks < g_spmv_blocks ? nchunks : g_spmv_blocks;
+  int64_t g = nchunks < cap ? nchunks : cap;
   g = ((g + 7) / 8) * 8;
   return (int)g;
 }
@@ -598,7 +596,7 @@ static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const doub
   if (A.val32) {
     // fp32-valued operator (multigrid levels): aligned-wide kernel, 8 lanes per row
     const int G = (A.max_row > 0 && A.max_row + 3 <= 16) ? 4 : 8;
-    grid = spmv_grid(A.nrows, 256 / G);
+    grid = spmv_grid(ctx, A.nrows, 256 / G);
     bytes_per_nnz = 8.0;
     if (G == 4)
       hipLaunchKernelGGL((k_spmv_wide<4, DOT, 2, float>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val32, x,
@@ -614,7 +612,7 @@ static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const doub
   const bool can_stream = A.max_row > 0 && A.max_row <= 8 * 64;
   if (ctx->spmv_kernel == 2 && can_stream) {
     const int T = stream_T(A.max_row);
-    grid = spmv_grid(A.nrows, 256 / T);
+    grid = spmv_grid(ctx, A.nrows, 256 / T);
 #define PPH_STREAM_CASE(TT)                                                                                       \
   case TT:                                                                                                        \
     hipLaunchKernelGGL((k_spmv_stream<TT, DOT>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, \
@@ -641,7 +639,7 @@ static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const doub
     else
       hipLaunchKernelGGL((k_spmv_lds<4, DOT>), dim3(grid), dim3(64), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
   } else if (ctx->spmv_kernel >= 5 && ctx->spmv_kernel <= 7) {
-    grid = spmv_grid(A.nrows, 256 / 8);
+    grid = spmv_grid(ctx, A.nrows, 256 / 8);
     if (ctx->spmv_kernel == 5)
       hipLaunchKernelGGL((k_spmv_wide_u<8, DOT, 2>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
     else if (ctx->spmv_kernel == 6)
@@ -651,32 +649,32 @@ static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const doub
   } else if (ctx->spmv_kernel == 14 && A.max_row > 0 && A.max_row * 16 + 3 <= 1024) {
     const bool r32 = A.max_row * 32 + 3 <= 1024;
     const int64_t nchunks = ceil_div64(A.nrows, r32 ? 32 : 16);
-    const int64_t cap = (int64_t)g_spmv_blocks * 4;  // one wave per workgroup: 4x the workgroups of the 256-thread kernels
+    const int64_t cap = (int64_t)(ctx->spmv_blocks >= 8 ? ctx->spmv_blocks : SPMV_DEF_BLOCKS) * 4;  // one wave per workgroup
     grid = (int)(nchunks < cap ? nchunks : cap);
     if (r32)
       hipLaunchKernelGGL((k_spmv_block<32, DOT>), dim3(grid), dim3(64), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
     else
       hipLaunchKernelGGL((k_spmv_block<16, DOT>), dim3(grid), dim3(64), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
   } else if (ctx->spmv_kernel == 15) {
-    grid = spmv_grid(A.nrows, 256 / 8);
+    grid = spmv_grid(ctx, A.nrows, 256 / 8);
     hipLaunchKernelGGL((k_spmv_wide2<DOT>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
   } else if (ctx->spmv_kernel == 9) {
-    grid = spmv_grid(A.nrows, 256 / 8);
+    grid = spmv_grid(ctx, A.nrows, 256 / 8);
     hipLaunchKernelGGL((k_spmv_wide<8, DOT, 3>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
   } else if (ctx->spmv_kernel == 10) {
-    grid = spmv_grid(A.nrows, 256 / 8);
+    grid = spmv_grid(ctx, A.nrows, 256 / 8);
     hipLaunchKernelGGL((k_spmv_wide<8, DOT, 1>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
   } else if (ctx->spmv_kernel == 12) {
-    grid = spmv_grid(A.nrows, 256 / 8);
+    grid = spmv_grid(ctx, A.nrows, 256 / 8);
     hipLaunchKernelGGL((k_spmv_wide<8, DOT, 4>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
   } else if (ctx->spmv_kernel == 13) {
-    grid = spmv_grid(A.nrows, 256 / 8);
+    grid = spmv_grid(ctx, A.nrows, 256 / 8);
     hipLaunchKernelGGL((k_spmv_wide<8, DOT, 5>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
   } else if (ctx->spmv_kernel == 3 || ctx->spmv_kernel == 8 || ctx->spmv_kernel == 11) {
     // lanes per row: one 4-wide step covers 4 G entries; rows of up to 29 entries fit G = 8
     int G = ctx->spmv_lanes_override > 0 ? ctx->spmv_lanes_override : (A.max_row > 0 && A.max_row + 3 <= 16 ? 4 : 8);
     if (G != 4 && G != 8 && G != 16 && G != 32 && G != 64) G = 8;
-    grid = spmv_grid(A.nrows, 256 / G);
+    grid = spmv_grid(ctx, A.nrows, 256 / G);
 #define PPH_WIDE_CASE(GG)                                                                                       \
   case GG:                                                                                                      \
     if (ctx->spmv_kernel == 8)                                                                                  \
@@ -697,7 +695,7 @@ static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const doub
   } else {
     int G = A.lanes;
     if (G != 4 && G != 8 && G != 16 && G != 32 && G != 64) G = 8;
-    grid = spmv_grid(A.nrows, 256 / G);
+    grid = spmv_grid(ctx, A.nrows, 256 / G);
 #define PPH_SPMV_CASE(GG)                                                                                          \
   case GG:                                                                                                         \
     if (ctx->spmv_kernel == 0)                                                                                     \
