@@ -147,7 +147,9 @@ def main():
     if world > 1:
         from perphil_amd.distributed import SlabSolver
 
-        solver = SlabSolver(N, world, rank, device, k1, k2, beta, mu, inner_rtol=args.inner_rtol, smooth=args.smooth)
+        solver = SlabSolver(N, world, rank, device, k1, k2, beta, mu, inner_rtol=args.inner_rtol, smooth=args.smooth,
+                            inner_reduction=args.inner_reduction)
+        solver.ctx.set_option("asm_kernel", args.asm_kernel)
         dofs_global = solver.global_dofs
         step = solver.step
         ctx = solver.ctx
@@ -258,6 +260,7 @@ def main():
         out["cpu_baseline"] = None
     if dist is not None:
         dist.barrier()
+        ctx.close()  # destroys the library's RCCL communicator before the process group goes away
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))

@@ -406,6 +406,11 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
     ctx->spmv_kernel = v;
     return PPH_OK;
   }
+  if (!strcmp(name, "mg_replicate_below")) {
+    ctx->mg_replicate_below = (int64_t)value;
+    mg_release(ctx);
+    return PPH_OK;
+  }
   if (!strcmp(name, "mg_fp32")) {
     ctx->mg_fp32 = value != 0.0 ? 1 : 0;
     ctx->mg_ok = false;

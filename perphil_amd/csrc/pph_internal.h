@@ -166,6 +166,7 @@ struct pph_ctx {
   size_t ev_used = 0;                   // pairs recorded since the last harvest
   int spmv_lanes_override = 0;          // 0: pick from the mean row length
   int spmv_blocks = 0;                  // 0: default persistent grid (1024 workgroups)
+  int64_t mg_replicate_below = 40000;   // slabs: multigrid levels with at most this many global nodes are replicated
   int mg_fp32 = 0;                      // 1: V-cycle SpMVs read fp32 copies of the operator values (8 instead of 12 B per non-zero)
   int asm_kernel = 2;                   // multilinear cells: 2 two-pass (element rows + node gather, default), 1 one-pass node gather, 0 cell-centred atomic scatter-add
   int spmv_kernel = 3;                  // 3: aligned-wide CSR-vector (default); 0,1,2,4..8,10: variants kept for A/B runs

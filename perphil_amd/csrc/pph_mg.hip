@@ -282,7 +282,14 @@ int mg_setup(pph_ctx* ctx) {
   if (dist) {
     int l = 0;
     while (l + 1 < nlev && (c0 % (2 << l)) == 0 && (c1 % (2 << l)) == 0 && ((c1 - c0) >> (l + 1)) >= 2) ++l;
-    PPH_TRY(comm_min_int(ctx, l + 1, &ndist));
+    // small levels are latency-bound: below `mg_replicate_below` global nodes a level is replicated (one
+    // all-reduce of its right-hand side per cycle) instead of distributed (five halo exchanges per cycle)
+    int lr = l + 1;
+    for (int q = 1; q <= l; ++q) {
+      const int64_t gn = (int64_t)((fm.nx >> q) + 1) * ((fm.ny >> q) + 1) * ((fm.nz >> q) + 1);
+      if (gn <= ctx->mg_replicate_below) { lr = q; break; }
+    }
+    PPH_TRY(comm_min_int(ctx, lr, &ndist));
   }
   if (build) ctx->mg.resize(nlev);
   PPH_REQUIRE(ctx, (int)ctx->mg.size() == nlev, "multigrid hierarchy out of date");
