@@ -169,6 +169,12 @@ int pph_bw_probe(pph_ctx* ctx, int64_t bytes, int mode, int blocks, double* ms_o
 int pph_error_norms_mms(pph_ctx* ctx, int field, const double* nodal_host, double k1, double k2, double beta,
                         double mu, int nq, double* l2_out, double* h1s_out);
 
+/* Darcy velocity u = -conductivity * grad(p_h), L2-projected onto the CG-1 vector space of the mesh
+ * replaces: calculate_darcy_velocity_from_pressure() (reference src/perphil/utils/postprocessing.py:34-63,
+ * fd.project(-k grad p, VectorFunctionSpace(mesh, "CG", 1))).  p_host: n nodal pressures; u_host: [n][dim]
+ * (node-major, like a Firedrake vector Function's dat).  Mass-matrix solves run to rtol 1e-13. */
+int pph_darcy_velocity(pph_ctx* ctx, const double* p_host, double conductivity, double* u_host);
+
 /* ---- multi-GPU communication hooks -------------------------------------------------------------
  * replaces: PETSc's implicit VecScatter halo exchange and VecDot all-reduce under mpiexec (never run in
  * the reference).  One context per rank holds one cell slab (pph_mesh_build with

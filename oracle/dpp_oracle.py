@@ -506,3 +506,48 @@ def error_norms(mesh: Mesh, ph: np.ndarray, exact: Callable, exact_grad: Callabl
         l2 += float(np.sum(w * detJ * (uh - exact(xq)) ** 2))
         h1 += float(np.sum(w * detJ * np.sum((guh - exact_grad(xq)) ** 2, axis=1)))
     return math.sqrt(l2), math.sqrt(h1)
+
+
+# --------------------------------------------------------------------------------------
+# Darcy velocity (utils/postprocessing.py:34-63): fd.project(-k grad(p_h), VectorFunctionSpace(mesh, "CG", 1))
+# --------------------------------------------------------------------------------------
+def darcy_velocity(mesh: Mesh, ph: np.ndarray, conductivity: float, nq: int = 3) -> np.ndarray:
+    """L2 projection of -k grad(p_h) onto CG-1 vectors: solve M u_d = b_d (sparse direct); returns [n, dim]."""
+    d = mesh.dim
+    n = mesh.num_nodes
+    _, M = assemble_scalar(mesh)
+    X = mesh.coords[mesh.cells]
+    U = ph[mesh.cells]
+    m = X.shape[1]
+    b = np.zeros((n, d))
+    if mesh.kind in (CELL_QUAD, CELL_HEX):
+        pts, wts = np.polynomial.legendre.leggauss(nq)
+        grids = np.meshgrid(*([np.arange(nq)] * d), indexing="ij")
+        for q in zip(*[g.ravel() for g in grids]):
+            xi = [pts[t] for t in q]
+            w = float(np.prod([wts[t] for t in q]))
+            N = np.ones(m)
+            dN = np.ones((m, d))
+            for a in range(m):
+                for c in range(d):
+                    s = 1.0 if (a >> c) & 1 else -1.0
+                    N[a] *= 0.5 * (1.0 + s * xi[c])
+                    for e in range(d):
+                        dN[a, e] *= (0.5 * s) if e == c else 0.5 * (1.0 + s * xi[c])
+            J = np.einsum("ae,cad->ced", dN, X)
+            detJ = np.abs(np.linalg.det(J))
+            G = np.einsum("cde,ae->cad", np.linalg.inv(J), dN)
+            gp = np.einsum("ca,cad->cd", U, G)
+            contrib = (-conductivity * w) * detJ[:, None, None] * N[None, :, None] * gp[:, None, :]
+            for e in range(d):
+                np.add.at(b[:, e], mesh.cells.ravel(), contrib[:, :, e].ravel())
+    else:
+        E = X[:, 1:, :] - X[:, :1, :]                       # [cell][r][d] edge vectors
+        dP = U[:, 1:] - U[:, :1]
+        gp = np.linalg.solve(E, dP[:, :, None])[:, :, 0]    # E grad = dP
+        vol = np.abs(np.linalg.det(E)) / math.factorial(d)
+        contrib = (-conductivity / (d + 1)) * vol[:, None, None] * np.ones((1, m, 1)) * gp[:, None, :]
+        for e in range(d):
+            np.add.at(b[:, e], mesh.cells.ravel(), contrib[:, :, e].ravel())
+    lu = spla.splu(M.tocsc())
+    return np.column_stack([lu.solve(b[:, e]) for e in range(d)])

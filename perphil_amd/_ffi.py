@@ -34,6 +34,7 @@ EXPORTS = [
     "pph_csr_sizes", "pph_get_csr", "pph_get_rhs", "pph_spmv", "pph_spmv_bench",
     "pph_get_timers", "pph_set_option", "pph_comm_set_callbacks",
     "pph_rccl_unique_id", "pph_comm_init_rccl", "pph_comm_selftest", "pph_error_norms_mms", "pph_bw_probe",
+    "pph_darcy_velocity",
 ]
 
 HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64)
@@ -127,6 +128,7 @@ def _load() -> C.CDLL:
         "pph_bw_probe": ([p, C.c_int64, C.c_int, C.c_int, f64p], C.c_int),
         "pph_error_norms_mms": ([p, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, f64p,
                                  f64p], C.c_int),
+        "pph_darcy_velocity": ([p, C.c_void_p, C.c_double, C.c_void_p], C.c_int),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = ABI mismatch: fail loudly
@@ -281,6 +283,15 @@ class Context:
         self._check(lib.pph_error_norms_mms(self._h, int(field), _ptr(nodal), float(k1), float(k2), float(beta), float(mu),
                                             int(nq), C.byref(l2), C.byref(h1)))
         return l2.value, h1.value
+
+    def darcy_velocity(self, nodal: np.ndarray, conductivity: float) -> np.ndarray:
+        """L2 projection of -conductivity * grad(p_h) onto CG-1 vectors; returns [n, dim]."""
+        nodal = np.ascontiguousarray(nodal, dtype=np.float64)
+        if nodal.shape != (self.n,):
+            raise ValueError("nodal array must have one value per mesh vertex")
+        out = np.empty((self.n, self.dim), dtype=np.float64)
+        self._check(lib.pph_darcy_velocity(self._h, _ptr(nodal), float(conductivity), _ptr(out)))
+        return out
 
     def timers(self) -> dict:
         t = np.zeros(11, dtype=np.float64)

@@ -374,6 +374,7 @@ int pph_spmv_bench(pph_ctx* ctx, int which, int reps, double* avg_ms) {
   Csr A;
   PPH_TRY(select_csr(ctx, which, &A));
   A.lanes = pph_pick_lanes(ctx, A.nnz, A.nrows);
+  if (ctx->spmv_kernel == 16) return la_padded_experiment(ctx, A, reps, avg_ms);  // padded-row experiment
   DevBuf<double> x, y;
   PPH_TRY(x.alloc(ctx, (size_t)A.nrows));
   PPH_TRY(y.alloc(ctx, (size_t)A.nrows));
@@ -402,7 +403,7 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
   }
   if (!strcmp(name, "spmv_kernel")) {
     const int v = (int)value;
-    PPH_REQUIRE(ctx, (v >= 0 && v <= 15), "spmv_kernel: 0 vector, 1 vector+preload, 2 LDS stream, 3 aligned-wide (default), 4 LDS-transposed, 5-7 multi-row, 8 aligned-wide XCD-contiguous, 10 no-gather probe");
+    PPH_REQUIRE(ctx, (v >= 0 && v <= 16), "spmv_kernel: 0 vector, 1 vector+preload, 2 LDS stream, 3 aligned-wide (default), 4 LDS-transposed, 5-7 multi-row, 8 aligned-wide XCD-contiguous, 10 no-gather probe");
     ctx->spmv_kernel = v;
     return PPH_OK;
   }
@@ -482,6 +483,19 @@ __global__ __launch_bounds__(256) void k_bw_copy(const double2* __restrict__ a, 
     b[i] = a[i];
 }
 
+// mode 2: the SpMV's stream mix without any row logic: per lane and step 32 B of `a` (two 16-byte loads at a
+// 32-byte lane stride, like the values) and 16 B of `b` (like the columns)
+__global__ __launch_bounds__(256) void k_bw_mix(const double2* __restrict__ a, const int4* __restrict__ b, int64_t n4,
+                                                double* __restrict__ out) {
+  double s = 0.0;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const double2 v0 = a[2 * i], v1 = a[2 * i + 1];
+    const int4 c = b[i];
+    s += v0.x + v0.y + v1.x + v1.y + (double)(c.x + c.y + c.z + c.w);
+  }
+  if (s == 1.2345e300) out[0] = s;
+}
+
 extern "C" int pph_bw_probe(pph_ctx* ctx, int64_t bytes, int mode, int blocks, double* ms_out) {
   if (!ctx || !ms_out || bytes < 4096) return PPH_ERR_INVALID;
   PPH_HIP(ctx, hipSetDevice(ctx->device));
@@ -489,11 +503,14 @@ extern "C" int pph_bw_probe(pph_ctx* ctx, int64_t bytes, int mode, int blocks, d
   const size_t n = (size_t)(bytes / 8);
   PPH_TRY(a.alloc(ctx, n));
   if (mode == 1) PPH_TRY(b.alloc(ctx, n));
+  if (mode == 2) PPH_TRY(b.alloc(ctx, n / 2 + 8));
   PPH_HIP(ctx, hipMemsetAsync(a.p, 0, n * 8, ctx->stream));
   const int reps = 10;
   for (int it = 0; it < 2 + reps; ++it) {
     if (it == 2) PPH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    if (mode == 0)
+    if (mode == 2)
+      hipLaunchKernelGGL(k_bw_mix, dim3(blocks), dim3(256), 0, ctx->stream, (const double2*)a.p, (const int4*)b.p, (int64_t)(n / 4), ctx->scal.p);
+    else if (mode == 0)
       hipLaunchKernelGGL(k_bw_read, dim3(blocks), dim3(256), 0, ctx->stream, (const double2*)a.p, (int64_t)(n / 2), ctx->scal.p);
     else
       hipLaunchKernelGGL(k_bw_copy, dim3(blocks), dim3(256), 0, ctx->stream, (const double2*)a.p, (double2*)b.p, (int64_t)(n / 2));

@@ -216,6 +216,7 @@ void la_dot2(pph_ctx* ctx, const double* x, const double* y, const double* z, in
 void la_cg_update(pph_ctx* ctx, double* x, double* r, double* z, const double* p, const double* q,
                   const double* dinv, double alpha, int64_t n, int slot, Seg sg);
 void la_extract_diag_inv(pph_ctx* ctx, const Csr& A, double* dinv);
+int la_padded_experiment(pph_ctx* ctx, const Csr& A, int reps, double* avg_ms);  // timing experiment (spmv_kernel 16)
 // fetch `count` reduction results starting at slot into ctx->h_scal (synchronises the stream)
 int la_fetch(pph_ctx* ctx, int slot, int count);
 // ghost planes of v <- owner's values (no-op without neighbours / communicator)

@@ -325,6 +325,60 @@ __global__ __launch_bounds__(256) void k_spmv_wide2(const int64_t* __restrict__ 
   }
 }
 
+// Experiment: rows padded to a multiple of 4 entries with explicit zeros (column = the row itself) and
+// row starts aligned to 4: no masks at all in the inner loop, every 16-byte load is aligned inside its row.
+template <int G, bool DOT>
+__global__ __launch_bounds__(256) void k_spmv_padded(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                     const double* __restrict__ val, const double* __restrict__ x,
+                                                     const double* __restrict__ bvec, double* __restrict__ y,
+                                                     int64_t nrows, double* __restrict__ part) {
+  constexpr int RPB = 256 / G;
+  __shared__ double lds[4];
+  const int sub = threadIdx.x % G;
+  const int grp = threadIdx.x / G;
+  const int64_t nchunks = (nrows + RPB - 1) / RPB;
+  double acc = 0.0;
+  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    const int64_t row = ch * RPB + grp;
+    double sum = 0.0;
+    if (row < nrows) {
+      const int64_t s = rowptr[row], e = rowptr[row + 1];
+      for (int64_t base = s + 4 * sub; base < e; base += 4 * G) {
+        const int4 c = *reinterpret_cast<const int4*>(col + base);
+        const double2 v01 = *reinterpret_cast<const double2*>(val + base);
+        const double2 v23 = *reinterpret_cast<const double2*>(val + base + 2);
+        sum += v01.x * x[c.x] + v01.y * x[c.y] + v23.x * x[c.z] + v23.y * x[c.w];
+      }
+    }
+    if constexpr (G == 8) sum = group8_sum(sum);
+    else {
+#pragma unroll
+      for (int o = G / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, G);
+    }
+    if (sub == 0 && row < nrows) {
+      y[row] = bvec ? bvec[row] - sum : sum;
+      if (DOT) acc += sum * x[row];
+    }
+  }
+  if (DOT) {
+    acc = block_sum(acc, lds);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+  }
+}
+
+__global__ void k_pad_fill(const int64_t* __restrict__ rp, const int32_t* __restrict__ col, const double* __restrict__ val,
+                           const int64_t* __restrict__ rpp, int32_t* __restrict__ colp, double* __restrict__ valp,
+                           int64_t nrows) {
+  for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < nrows; row += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t s = rp[row], e = rp[row + 1], sp = rpp[row], ep = rpp[row + 1];
+    for (int64_t k = 0; k < ep - sp; ++k) {
+      const bool real = s + k < e;
+      colp[sp + k] = real ? col[s + k] : (int32_t)row;
+      valp[sp + k] = real ? val[s + k] : 0.0;
+    }
+  }
+}
+
 // Aligned-wide CSR-vector kernel with UR rows in flight per lane group: the dependent chain
 // rowptr -> (columns, values) -> x gather is latency-bound when a wave carries one row per group
 // (about 3 KB in flight), so every group walks UR row-chunks at once: all row pointers are requested
@@ -988,3 +1042,37 @@ int la_fetch(pph_ctx* ctx, int slot, int count) {
   if (reduce && !ctx->nccl_comm) PPH_TRY(comm_allreduce_host(ctx, ctx->h_scal + slot, (int64_t)count));
   return PPH_OK;
 }
+
+// builds the padded copy of A (host-side row-pointer scan: experiment only) and times `reps` launches
+int la_padded_experiment(pph_ctx* ctx, const Csr& A, int reps, double* avg_ms) {
+  std::vector<int64_t> rp((size_t)A.nrows + 1), rpp((size_t)A.nrows + 1);
+  PPH_HIP(ctx, hipMemcpy(rp.data(), A.rowptr, sizeof(int64_t) * rp.size(), hipMemcpyDeviceToHost));
+  rpp[0] = 0;
+  for (int64_t r = 0; r < A.nrows; ++r) rpp[(size_t)r + 1] = rpp[(size_t)r] + ((rp[(size_t)r + 1] - rp[(size_t)r] + 3) / 4) * 4;
+  const int64_t nnzp = rpp[(size_t)A.nrows];
+  DevBuf<int64_t> drpp;
+  DevBuf<int32_t> colp;
+  DevBuf<double> valp, x, y;
+  PPH_TRY(drpp.alloc(ctx, rpp.size()));
+  PPH_TRY(colp.alloc(ctx, (size_t)nnzp));
+  PPH_TRY(valp.alloc(ctx, (size_t)nnzp));
+  PPH_TRY(x.alloc(ctx, (size_t)A.nrows));
+  PPH_TRY(y.alloc(ctx, (size_t)A.nrows));
+  PPH_HIP(ctx, hipMemcpy(drpp.p, rpp.data(), sizeof(int64_t) * rpp.size(), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_pad_fill, dim3(2048), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, drpp.p, colp.p, valp.p, A.nrows);
+  hipLaunchKernelGGL(k_set, dim3(2048), dim3(256), 0, ctx->stream, x.p, 1.0, A.nrows);
+  const int grid = spmv_grid(ctx, A.nrows, 32);
+  for (int i = 0; i < 5 + reps; ++i) {
+    if (i == 5) PPH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL((k_spmv_padded<8, false>), dim3(grid), dim3(256), 0, ctx->stream, drpp.p, colp.p, valp.p, x.p,
+                       (const double*)nullptr, y.p, A.nrows, (double*)nullptr);
+  }
+  PPH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+  PPH_HIP(ctx, hipEventSynchronize(ctx->ev1));
+  float ms = 0.f;
+  PPH_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+  *avg_ms = ms / reps;
+  drpp.release(); colp.release(); valp.release(); x.release(); y.release();
+  return PPH_OK;
+}
+

@@ -234,3 +234,230 @@ extern "C" int pph_error_norms_mms(pph_ctx* ctx, int field, const double* nodal_
   part.release();
   return PPH_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Darcy velocity u = -k grad(p_h), L2-projected onto the CG-1 vector space: M u_d = b_d with
+// b_d[a] = int -k (d p_h / d x_d) phi_a  (reference src/perphil/utils/postprocessing.py:34-63, fd.project).
+// Node-centred right-hand side (one thread per node walks its incident cells; deterministic), then one
+// Jacobi-CG solve with the mass matrix per component.
+// ------------------------------------------------------------------------------------------------
+template <int DIM>
+__global__ __launch_bounds__(256) void k_darcy_rhs_multilinear(const int32_t* __restrict__ cells,
+                                                               const double* __restrict__ cx, const double* __restrict__ cy,
+                                                               const double* __restrict__ cz, const double* __restrict__ p,
+                                                               double kcond, int nx, int ny, int nzl, int px, int py,
+                                                               int64_t n, double* __restrict__ b /* [DIM][n] */) {
+  constexpr int NB = 1 << DIM;
+  const double gp = 0.57735026918962576451;
+  for (int64_t node = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; node < n;
+       node += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(node % px);
+    const int64_t t = node / px;
+    const int j = (int)(t % py), k = (int)(t / py);
+    double acc[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) acc[d] = 0.0;
+    for (int c = 0; c < NB; ++c) {
+      const int ci = i - (c & 1), cj = j - ((c >> 1) & 1), ck = (DIM == 3) ? k - ((c >> 2) & 1) : 0;
+      if (ci < 0 || ci >= nx || cj < 0 || cj >= ny || (DIM == 3 && (ck < 0 || ck >= nzl))) continue;
+      const int64_t cell = ci + (int64_t)nx * (cj + (int64_t)ny * ck);
+      double X[NB][DIM], P[NB];
+      int a = -1;
+#pragma unroll
+      for (int bb = 0; bb < NB; ++bb) {
+        const int32_t nd = cells[cell * NB + bb];
+        a = (nd == (int32_t)node) ? bb : a;
+        X[bb][0] = cx[nd];
+        X[bb][1] = cy[nd];
+        if constexpr (DIM == 3) X[bb][2] = cz[nd];
+        P[bb] = p[nd];
+      }
+      if (a < 0) continue;
+      for (int q = 0; q < NB; ++q) {
+        double xi[DIM];
+#pragma unroll
+        for (int e = 0; e < DIM; ++e) xi[e] = ((q >> e) & 1) ? gp : -gp;
+        double J[DIM][DIM], gref[DIM], Na = 1.0;
+#pragma unroll
+        for (int e = 0; e < DIM; ++e) {
+          gref[e] = 0.0;
+#pragma unroll
+          for (int d = 0; d < DIM; ++d) J[e][d] = 0.0;
+        }
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) {
+          double nv = 1.0, dn[DIM];
+#pragma unroll
+          for (int e = 0; e < DIM; ++e) {
+            const double s = ((bb >> e) & 1) ? 1.0 : -1.0;
+            nv *= 0.5 * (1.0 + s * xi[e]);
+            double dd = 1.0;
+#pragma unroll
+            for (int f = 0; f < DIM; ++f) {
+              const double sf = ((bb >> f) & 1) ? 1.0 : -1.0;
+              dd *= (f == e) ? 0.5 * sf : 0.5 * (1.0 + sf * xi[f]);
+            }
+            dn[e] = dd;
+          }
+          Na = (bb == a) ? nv : Na;
+#pragma unroll
+          for (int e = 0; e < DIM; ++e) {
+            gref[e] += dn[e] * P[bb];
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) J[e][d] += dn[e] * X[bb][d];
+          }
+        }
+        double det, I[DIM][DIM];
+        if constexpr (DIM == 2) {
+          det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+          const double r = 1.0 / det;
+          I[0][0] = J[1][1] * r;  I[0][1] = -J[0][1] * r;
+          I[1][0] = -J[1][0] * r; I[1][1] = J[0][0] * r;
+        } else {
+          const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+          const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+          const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+          det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+          const double r = 1.0 / det;
+          I[0][0] = c00 * r;
+          I[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
+          I[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
+          I[1][0] = c01 * r;
+          I[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
+          I[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
+          I[2][0] = c02 * r;
+          I[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
+          I[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
+        }
+        const double w = fabs(det) * Na * (-kcond);
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) {
+          double g = 0.0;
+#pragma unroll
+          for (int e = 0; e < DIM; ++e) g += I[d][e] * gref[e];
+          acc[d] += w * g;
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) b[(int64_t)d * n + node] = acc[d];
+  }
+}
+
+template <int DIM>
+__global__ __launch_bounds__(256) void k_darcy_rhs_simplex(const int32_t* __restrict__ cells, const double* __restrict__ cx,
+                                                           const double* __restrict__ cy, const double* __restrict__ cz,
+                                                           const double* __restrict__ p, double kcond, int nx, int ny,
+                                                           int nzl, int px, int py, int64_t n, double* __restrict__ b) {
+  constexpr int NB = DIM + 1;
+  constexpr int NSUB = (DIM == 2) ? 2 : 6;
+  for (int64_t node = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; node < n;
+       node += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(node % px);
+    const int64_t t = node / px;
+    const int j = (int)(t % py), k = (int)(t / py);
+    double acc[DIM];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) acc[d] = 0.0;
+    for (int c = 0; c < (1 << DIM); ++c) {
+      const int bi = i - (c & 1), bj = j - ((c >> 1) & 1), bk = (DIM == 3) ? k - ((c >> 2) & 1) : 0;
+      if (bi < 0 || bi >= nx || bj < 0 || bj >= ny || (DIM == 3 && (bk < 0 || bk >= nzl))) continue;
+      const int64_t box = bi + (int64_t)nx * (bj + (int64_t)ny * bk);
+      for (int sub = 0; sub < NSUB; ++sub) {
+        const int64_t cell = box * NSUB + sub;
+        double X[NB][DIM], P[NB];
+        bool has = false;
+#pragma unroll
+        for (int bb = 0; bb < NB; ++bb) {
+          const int32_t nd = cells[cell * NB + bb];
+          has = has || (nd == (int32_t)node);
+          X[bb][0] = cx[nd];
+          X[bb][1] = cy[nd];
+          if constexpr (DIM == 3) X[bb][2] = cz[nd];
+          P[bb] = p[nd];
+        }
+        if (!has) continue;
+        double E[DIM][DIM], dP[DIM];
+#pragma unroll
+        for (int r = 0; r < DIM; ++r) {
+          dP[r] = P[r + 1] - P[0];
+#pragma unroll
+          for (int d = 0; d < DIM; ++d) E[r][d] = X[r + 1][d] - X[0][d];
+        }
+        // grad p = E^-1 dP  (E rows = edge vectors): solve with the adjugate
+        double det, g[DIM];
+        if constexpr (DIM == 2) {
+          det = E[0][0] * E[1][1] - E[0][1] * E[1][0];
+          g[0] = (E[1][1] * dP[0] - E[0][1] * dP[1]) / det;
+          g[1] = (-E[1][0] * dP[0] + E[0][0] * dP[1]) / det;
+        } else {
+          const double c00 = E[1][1] * E[2][2] - E[1][2] * E[2][1];
+          const double c01 = E[1][2] * E[2][0] - E[1][0] * E[2][2];
+          const double c02 = E[1][0] * E[2][1] - E[1][1] * E[2][0];
+          det = E[0][0] * c00 + E[0][1] * c01 + E[0][2] * c02;
+          const double r = 1.0 / det;
+          g[0] = (c00 * dP[0] + (E[0][2] * E[2][1] - E[0][1] * E[2][2]) * dP[1] + (E[0][1] * E[1][2] - E[0][2] * E[1][1]) * dP[2]) * r;
+          g[1] = (c01 * dP[0] + (E[0][0] * E[2][2] - E[0][2] * E[2][0]) * dP[1] + (E[0][2] * E[1][0] - E[0][0] * E[1][2]) * dP[2]) * r;
+          g[2] = (c02 * dP[0] + (E[0][1] * E[2][0] - E[0][0] * E[2][1]) * dP[1] + (E[0][0] * E[1][1] - E[0][1] * E[1][0]) * dP[2]) * r;
+        }
+        const double w = -kcond * fabs(det) / (DIM == 2 ? 2.0 : 6.0) / (double)(DIM + 1);
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) acc[d] += w * g[d];
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) b[(int64_t)d * n + node] = acc[d];
+  }
+}
+
+extern "C" int pph_darcy_velocity(pph_ctx* ctx, const double* p_host, double conductivity, double* u_host) {
+  if (!ctx) return PPH_ERR_INVALID;
+  PPH_REQUIRE(ctx, ctx->mesh_ok && p_host && u_host, "pph_darcy_velocity: no mesh or NULL buffer");
+  PPH_REQUIRE(ctx, ctx->world == 1, "Darcy velocity projection is implemented for single-context meshes");
+  PPH_HIP(ctx, hipSetDevice(ctx->device));
+  MeshData& m = ctx->mesh;
+  if (!m.km_valid) {
+    PPH_TRY(pph_launch_assemble_KM(ctx, m));
+    m.km_valid = true;
+  }
+  const int64_t n = m.n;
+  const int dim = m.dim;
+  DevBuf<double> p, b, u, dinv, w1, w2, w3, w4;
+  PPH_TRY(p.alloc(ctx, (size_t)n));
+  PPH_TRY(b.alloc(ctx, (size_t)n * dim));
+  PPH_TRY(u.alloc(ctx, (size_t)n));
+  PPH_TRY(dinv.alloc(ctx, (size_t)n));
+  PPH_TRY(w1.alloc(ctx, (size_t)n)); PPH_TRY(w2.alloc(ctx, (size_t)n));
+  PPH_TRY(w3.alloc(ctx, (size_t)n)); PPH_TRY(w4.alloc(ctx, (size_t)n));
+  PPH_HIP(ctx, hipMemcpyAsync(p.p, p_host, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  int64_t nb = ceil_div64(n, 256);
+  const int grid = (int)(nb < 8192 ? nb : 8192);
+  const int nzl = (dim == 3) ? m.nzl : 0;
+  if (m.kind == PPH_CELL_QUAD)
+    hipLaunchKernelGGL(k_darcy_rhs_multilinear<2>, dim3(grid), dim3(256), 0, ctx->stream, m.cells.p, m.cx.p, m.cy.p, m.cz.p,
+                       p.p, conductivity, m.nx, m.ny, nzl, m.px, m.py, n, b.p);
+  else if (m.kind == PPH_CELL_HEX)
+    hipLaunchKernelGGL(k_darcy_rhs_multilinear<3>, dim3(grid), dim3(256), 0, ctx->stream, m.cells.p, m.cx.p, m.cy.p, m.cz.p,
+                       p.p, conductivity, m.nx, m.ny, nzl, m.px, m.py, n, b.p);
+  else if (m.kind == PPH_CELL_TRI)
+    hipLaunchKernelGGL(k_darcy_rhs_simplex<2>, dim3(grid), dim3(256), 0, ctx->stream, m.cells.p, m.cx.p, m.cy.p, m.cz.p, p.p,
+                       conductivity, m.nx, m.ny, nzl, m.px, m.py, n, b.p);
+  else
+    hipLaunchKernelGGL(k_darcy_rhs_simplex<3>, dim3(grid), dim3(256), 0, ctx->stream, m.cells.p, m.cx.p, m.cy.p, m.cz.p, p.p,
+                       conductivity, m.nx, m.ny, nzl, m.px, m.py, n, b.p);
+  PPH_HIP(ctx, hipGetLastError());
+  Csr M;
+  M.rowptr = m.rowptr.p; M.col = m.col.p; M.val = m.M.p; M.nrows = n; M.nnz = m.nnzb; M.max_row = m.max_row;
+  M.lanes = pph_pick_lanes(ctx, M.nnz, M.nrows);
+  la_extract_diag_inv(ctx, M, dinv.p);
+  std::vector<double> tmp((size_t)n);
+  for (int d = 0; d < dim; ++d) {
+    int its = 0;
+    PPH_TRY(pph_cg_jacobi(ctx, M, b.p + (size_t)d * n, u.p, dinv.p, 1e-13, 0.0, 1000, w1.p, w2.p, w3.p, w4.p, &its));
+    PPH_HIP(ctx, hipMemcpyAsync(tmp.data(), u.p, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int64_t i = 0; i < n; ++i) u_host[(size_t)i * dim + d] = tmp[(size_t)i];
+  }
+  p.release(); b.release(); u.release(); dinv.release(); w1.release(); w2.release(); w3.release(); w4.release();
+  return PPH_OK;
+}

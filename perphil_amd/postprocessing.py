@@ -1,12 +1,12 @@
 """
 Post-processing — mirror of reference ``src/perphil/utils/postprocessing.py``:
-``split_dpp_solution`` (:6-31), ``slice_along_x`` (:66-86), ``l2_error`` (:89-105), ``h1_seminorm_error``
+``split_dpp_solution`` (:6-31), ``calculate_darcy_velocity_from_pressure`` (:34-63), ``slice_along_x`` (:66-86), ``l2_error`` (:89-105), ``h1_seminorm_error``
 (:108-124).  The two error norms run on the device (``pph_error_norms_mms``): a Gauss rule per cell on
 the isoparametric map with the manufactured pressure evaluated in closed form at every quadrature point.
 """
 from __future__ import annotations
 
-from typing import Tuple
+from typing import Optional, Tuple
 
 import numpy as np
 
@@ -22,6 +22,25 @@ def split_dpp_solution(dpp_solution: fd.Function) -> Tuple[fd.Function, fd.Funct
     p1 = fd.Function(W.sub(0), dpp_solution.sub(0).vector().copy(), name="p1_h")
     p2 = fd.Function(W.sub(1), dpp_solution.sub(1).vector().copy(), name="p2_h")
     return p1, p2
+
+
+def calculate_darcy_velocity_from_pressure(pressure_field: fd.Function, conductivity,
+                                           velocity_space: Optional[fd.FunctionSpace] = None,
+                                           degree: int = 1) -> fd.Function:
+    """
+    u = -conductivity * grad(p_h), L2-projected onto the CG-1 vector space (``pph_darcy_velocity``:
+    node-centred right-hand side kernel + one mass-matrix CG solve per component on the device).
+    Coefficients are node-major: ``u.vector().reshape(-1, dim)[node]`` is the velocity at a vertex.
+    """
+    mesh = pressure_field.function_space().mesh()
+    if velocity_space is None:
+        velocity_space = fd.VectorFunctionSpace(mesh, "CG", degree)
+    if velocity_space.degree != 1 or velocity_space.mesh() is not mesh:
+        raise NotImplementedError("the velocity space must be the CG-1 vector space of the pressure's mesh")
+    if not isinstance(conductivity, (int, float, fd.Constant)):
+        raise NotImplementedError("conductivity must be a constant")
+    u = mesh.context().darcy_velocity(pressure_field.vector(), float(conductivity))
+    return fd.Function(velocity_space, u.reshape(-1), name="velocity")
 
 
 def slice_along_x(scalar_field: fd.Function, x_value: float) -> Tuple[np.ndarray, np.ndarray]:

@@ -547,3 +547,39 @@ def test_ragged_meshes_all_solvers(gpu_ctx_factory, dim, kind, nx, ny, nz):
         x, info, _ = ctx.solve(cfg)
         assert info.converged
         assert np.abs(x - ud).max() / scale < 1e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,kind,nx,ny,nz", [(2, o.CELL_QUAD, 7, 5, 0), (2, o.CELL_TRI, 6, 9, 0), (3, o.CELL_HEX, 5, 4, 6),
+                                               (3, o.CELL_TET, 4, 6, 3), (3, o.CELL_HEX, 1, 1, 1)])
+def test_darcy_velocity_projection_matches_oracle(gpu_ctx_factory, dim, kind, nx, ny, nz):
+    """calculate_darcy_velocity_from_pressure (reference postprocessing.py:34-63): device projection vs the
+    oracle's sparse-direct projection on a random nodal field, and exactness for a linear pressure."""
+    ctx = gpu_ctx_factory()
+    ctx.mesh_build(dim, kind, nx, ny, nz)
+    om = o.build_mesh(dim, kind, nx, ny, nz)
+    rng = np.random.default_rng(11)
+    p = rng.standard_normal(om.num_nodes)
+    u = ctx.darcy_velocity(p, 0.37)
+    ref = o.darcy_velocity(om, p, 0.37)
+    assert u.shape == ref.shape == (om.num_nodes, dim)
+    np.testing.assert_allclose(u, ref, rtol=0, atol=1e-10 * np.abs(ref).max())
+    a = np.array([0.5, -1.25, 2.0])[:dim]
+    u = ctx.darcy_velocity(om.coords[:, :dim] @ a + 3.0, 2.0)
+    np.testing.assert_allclose(u, np.tile(-2.0 * a, (om.num_nodes, 1)), rtol=0, atol=1e-10)
+
+
+@pytest.mark.gpu
+def test_darcy_velocity_public_api(gpu_ctx_factory):
+    import perphil_amd as pa
+    from perphil_amd import fd
+    from perphil_amd.postprocessing import calculate_darcy_velocity_from_pressure
+
+    mesh = pa.create_mesh(6, 4, quadrilateral=True)
+    U, V = pa.create_function_spaces(mesh)
+    ph = fd.Function(V).interpolate(lambda X: 2.0 * X[:, 0] - X[:, 1])
+    vel = calculate_darcy_velocity_from_pressure(ph, fd.Constant(0.5), velocity_space=U)
+    assert vel.function_space() is U
+    np.testing.assert_allclose(vel.vector().reshape(-1, 2), np.tile([-1.0, 0.5], (V.dim(), 1)), atol=1e-11)
+    vel2 = calculate_darcy_velocity_from_pressure(ph, 0.5)
+    np.testing.assert_array_equal(vel2.vector(), vel.vector())

@@ -178,3 +178,15 @@ def test_closed_form_element_matrices():
         assert abs(Kg @ np.ones(mm.num_nodes)).max() < 1e-13   # constants are in the kernel of K
         assert Mg.sum() == pytest.approx(1.0, rel=1e-13)          # volume of the unit square/cube
         assert abs(Kg - Kg.T).max() < 1e-14
+
+
+@pytest.mark.parametrize("dim,kind,nx,ny,nz", [(2, o.CELL_QUAD, 5, 4, 0), (2, o.CELL_TRI, 4, 5, 0), (3, o.CELL_HEX, 3, 4, 2),
+                                               (3, o.CELL_TET, 3, 2, 4)])
+def test_oracle_darcy_velocity_exact_for_linear_pressure(dim, kind, nx, ny, nz):
+    """The L2 projection of -k grad(p_h) reproduces constants: u = -k a for p = a.x + c
+    (reference postprocessing.py:34-63; the reference holds no stored velocity output - parity unpinned
+    beyond this property)."""
+    om = o.build_mesh(dim, kind, nx, ny, nz)
+    a = np.array([0.5, -1.25, 2.0])[:dim]
+    u = o.darcy_velocity(om, om.coords[:, :dim] @ a + 1.0, 3.0)
+    np.testing.assert_allclose(u, np.tile(-3.0 * a, (om.num_nodes, 1)), atol=1e-12)
