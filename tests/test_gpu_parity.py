@@ -583,3 +583,61 @@ def test_darcy_velocity_public_api(gpu_ctx_factory):
     np.testing.assert_allclose(vel.vector().reshape(-1, 2), np.tile([-1.0, 0.5], (V.dim(), 1)), atol=1e-11)
     vel2 = calculate_darcy_velocity_from_pressure(ph, 0.5)
     np.testing.assert_array_equal(vel2.vector(), vel.vector())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hexa,k2", [(True, 1e-2), (False, 1e-4)])
+def test_full_size_properties_256cubed(gpu_ctx_factory, hexa, k2):
+    """BASELINE configs 4 (256^3 Q1, k1/k2 = 1e2) and 5 (256^3 Kuhn tets, k1/k2 = 1e4) at full size, through
+    size-independent properties: closed-form sizes, kernel of K / volume from M, symmetry of the blocks,
+    A12 == A21, identity Dirichlet rows, an independently recomputed true residual of the converged Picard
+    solve, and O(h^2) agreement with the manufactured solution."""
+    f = _ffi()
+    N = 256
+    Pp = o.Params(k1=1.0, k2=k2)
+    ctx = gpu_ctx_factory()
+    ctx.mesh_build(3, f.CELL_HEX if hexa else f.CELL_TET, N, N, N)
+    n = ctx.n
+    assert n == (N + 1) ** 3
+    nnz_tet = n + 2 * (3 * N * (N + 1) ** 2 + 3 * N * N * (N + 1) + N ** 3)     # SURVEY.md section 8 size table
+    assert ctx.nnzb == ((3 * N + 1) ** 3 if hexa else nnz_tet)
+    assert ctx.ncell == (N ** 3 if hexa else 6 * N ** 3)
+    import perphil_amd.fd as fdm
+
+    mesh = fdm.UnitCubeMesh(N, N, N, hexahedral=hexa)
+    b = mesh.boundary_nodes()
+    assert b.size == 6 * N * N + 2
+    e1, e2 = o.exact_pressures(mesh.node_coordinates(b), Pp)
+    ctx.set_dirichlet(0, b, e1)
+    ctx.set_dirichlet(1, b, e2)
+    ctx.assemble(Pp.k1, Pp.k2, Pp.beta, Pp.mu, monolithic=False)
+    ones = np.ones(n)
+    assert np.abs(ctx.spmv(f.MAT_K, ones)).max() < 1e-11
+    assert ctx.spmv(f.MAT_M, ones).sum() == pytest.approx(1.0, rel=1e-11)
+    rng = np.random.default_rng(256)
+    x, y = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    for which in (f.MAT_A11, f.MAT_A22):
+        Ax, Ay = ctx.spmv(which, x), ctx.spmv(which, y)
+        assert abs(y @ Ax - x @ Ay) <= 1e-10 * abs(y @ Ax)
+        assert x @ Ax > 0
+        np.testing.assert_array_equal(Ax[b], x[b])
+    A12x = ctx.spmv(f.MAT_A12, x)
+    np.testing.assert_array_equal(A12x, ctx.spmv(f.MAT_A21, x))
+    assert not A12x[b].any()
+    # the bench's algorithm: inexact block-Picard with multigrid-CG block solves
+    xs, info, _ = ctx.solve(_cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_MG, inner_rtol=1e-10,
+                                 inner_reduction=1e-2, mg_smooth=1, picard_rtol=1e-8, picard_max_it=200))
+    assert info.converged
+    r, u0 = ctx.rhs()
+    d = xs - u0
+    res1 = r[:n] - ctx.spmv(f.MAT_A11, d[:n]) - ctx.spmv(f.MAT_A12, d[n:])
+    res2 = r[n:] - ctx.spmv(f.MAT_A21, d[:n]) - ctx.spmv(f.MAT_A22, d[n:])
+    true_res = np.sqrt(res1 @ res1 + res2 @ res2)
+    assert true_res <= 1.05e-8 * np.linalg.norm(r)
+    assert true_res == pytest.approx(info.resnorm, rel=1e-3)
+    np.testing.assert_array_equal(xs[b], e1)
+    np.testing.assert_array_equal(xs[n + b], e2)
+    ex1, ex2 = o.exact_pressures(mesh.node_coordinates(), Pp)
+    tol = 5e-4 if hexa else 2e-2      # config 5: boundary layer exp(100 y) resolved with eta*h = 0.39
+    assert np.abs(xs[:n] - ex1).max() / np.abs(ex1).max() < tol
+    assert np.abs(xs[n:] - ex2).max() / np.abs(ex2).max() < tol
