@@ -56,51 +56,98 @@ def mms_boundary(n_cells, k1, k2, beta, mu):
     return b, p1(X), p2(X)
 
 
-def cpu_baseline(sample_n, k1, k2, beta, mu, smooth=1, reduction=1e-2, inner_rtol=1e-10):
-    """The oracle (CPU port of the same algorithm: assembly + Picard with multigrid-CG block solves)
-    timed on one host core on a smaller cube; returns DoF/s."""
+def _mms_boundary_np(N, k1, k2, beta, mu):
     from oracle import dpp_oracle as o
-    from oracle import dpp_mg_oracle as mgo
 
+    px = N + 1
+    idx = np.arange(px ** 3)
+    i, j, k = idx % px, (idx // px) % px, idx // (px * px)
+    on = (i == 0) | (i == N) | (j == 0) | (j == N) | (k == 0) | (k == N)
+    X = np.stack([i[on] / N, j[on] / N, k[on] / N], 1)
+    g1, g2 = o.exact_pressures(X, o.Params(k1=k1, k2=k2, beta=beta, mu=mu))
+    return idx[on], g1, g2
+
+
+def _cpu_port_run(N, threads, k1, k2, beta, mu, smooth, reduction, inner_rtol):
+    """One step (assemble + multigrid setup + inexact Picard) of the C/OpenMP restatement; seconds, sweeps, its."""
+    from oracle import dpp_cpu as cpu
+
+    cpu.set_threads(threads)
+    S = cpu.CpuSystem(3, 2, N, N, N)          # mesh + pattern: outside the timed region, as on the GPU
+    b, g1, g2 = _mms_boundary_np(N, k1, k2, beta, mu)
+    S.set_dirichlet(0, b, g1)
+    S.set_dirichlet(1, b, g2)
     t0 = time.perf_counter()
-    P = o.Params(k1=k1, k2=k2, beta=beta, mu=mu)
-    om = o.build_mesh(3, o.CELL_HEX, sample_n, sample_n, sample_n)
-    t_mesh = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    osys = o.build_system(om, P)
-    n = osys.n
-    a, b, c = P.abc
-    mask = np.zeros(n, bool)
-    mask[o.boundary_nodes(om)] = True
-    L1 = mgo.build_hierarchy(3, o.CELL_HEX, sample_n, sample_n, sample_n, a, b, mask)
-    L2 = mgo.build_hierarchy(3, o.CELL_HEX, sample_n, sample_n, sample_n, c, b, mask)
-    A = osys.A.tocsr()
-    A11, A12, A21, A22 = A[:n, :n], A[:n, n:], A[n:, :n], A[n:, n:]
-    rhs = osys.rhs
-    du = np.zeros(2 * n)
-    r0 = np.linalg.norm(rhs)
-    res, its = r0, 0
-    while res > max(1e-8 * r0, 1e-12) and its < 100:
-        x0 = du[:n].copy() if its else None
-        du[:n] = o.pcg(A11, rhs[:n] - A12 @ du[n:], lambda v: mgo.vcycle(L1, v, smooth), rtol=inner_rtol, x0=x0,
-                       reduction=reduction).x
-        x0 = du[n:].copy() if its else None
-        du[n:] = o.pcg(A22, rhs[n:] - A21 @ du[:n], lambda v: mgo.vcycle(L2, v, smooth), rtol=inner_rtol, x0=x0,
-                       reduction=reduction).x
-        its += 1
-        res = np.linalg.norm(rhs - A @ du)
+    S.assemble(k1, k2, beta, mu)
+    S.mg_setup()
+    _, sweeps, inner, _ = S.picard(pc=cpu.PC_MG, inner_rtol=inner_rtol, reduction=reduction, smooth=smooth, rtol=1e-8,
+                                   atol=1e-12, max_it=100)
     t = time.perf_counter() - t0
-    # independent single-thread SpMV sanity point (SciPy CSR, same fine-level scalar block)
-    xr = np.random.default_rng(20260313).uniform(-1, 1, n)
-    A11c = A11.tocsr()
-    ts = time.perf_counter()
-    for _ in range(20):
-        A11c @ xr
-    spmv_gbs = 20 * (12.0 * A11c.nnz + 20.0 * n) / (time.perf_counter() - ts) / 1e9
-    return {"value": 2 * n / t, "unit": "DoF/s", "cores": 1, "kind": "port", "scipy_spmv_gbs": round(spmv_gbs, 2),
-            "sample": f"{sample_n}^3 Q1 unit cube ({2 * n} DoF), same algorithm (assemble + inexact Picard, {its} sweeps, "
-                      f"V({smooth},{smooth}) multigrid-CG block solves, reduction {reduction:g}) in NumPy/SciPy, {t:.1f} s "
-                      f"(mesh build {t_mesh:.1f} s excluded)"}
+    spmv_gbs = (12.0 * S.nnz + 20.0 * S.n) / S.spmv_seconds(cpu.MAT_A11, 10) / 1e9
+    dofs = 2 * S.n
+    scipy_gbs = None
+    if threads == 1:
+        # independent single-thread SpMV sanity point (SciPy CSR, same fine-level scalar block)
+        A = S.csr(cpu.MAT_A11)
+        xr = np.random.default_rng(20260313).uniform(-1, 1, S.n)
+        ts = time.perf_counter()
+        for _ in range(10):
+            A @ xr
+        scipy_gbs = 10 * (12.0 * A.nnz + 20.0 * S.n) / (time.perf_counter() - ts) / 1e9
+    S.close()
+    return t, sweeps, inner, dofs, spmv_gbs, scipy_gbs
+
+
+def host_cores(cap=16):
+    """Threads the CPU baseline may use: the affinity mask clipped by the cgroup CPU quota (a GPU box exposes
+    every core of the host in the mask but grants a share of them) and by `cap`."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                       # cgroup v2
+            quota, period = fh.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:
+                q, p = int(fq.read()), int(fp.read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, cap))
+
+
+def cpu_baseline(sample_n, k1, k2, beta, mu, smooth=1, reduction=1e-2, inner_rtol=1e-10, threads=0):
+    """The CPU port (oracle/dpp_cpu.c: C99 + OpenMP restatement of the same algorithm - assembly, multigrid
+    setup, inexact Picard with multigrid-CG block solves) timed on the host: all available cores on a
+    `sample_n`^3 cube (bounded sample of the 256^3 workload) and one core on 64^3; returns DoF/s."""
+    cores = threads if threads > 0 else host_cores()
+    small = min(64, sample_n)
+    t1, sw1, in1, dofs1, gbs1, scipy_gbs = _cpu_port_run(small, 1, k1, k2, beta, mu, smooth, reduction, inner_rtol)
+    t, sw, inner, dofs, gbs, _ = _cpu_port_run(small, cores, k1, k2, beta, mu, smooth, reduction, inner_rtol)
+    # largest cube up to sample_n whose predicted time stays within a minute and whose ~2.3 KB per node fit in memory
+    try:
+        import psutil
+        avail = psutil.virtual_memory().available
+    except Exception:
+        avail = 16 << 30
+    pick = small
+    cand = sample_n
+    while cand > small:
+        if t * (cand / small) ** 3 < 60.0 and 1.5 * 2300.0 * (cand + 1) ** 3 < avail:
+            pick = cand
+            break
+        cand //= 2
+    if pick > small:
+        t, sw, inner, dofs, gbs, _ = _cpu_port_run(pick, cores, k1, k2, beta, mu, smooth, reduction, inner_rtol)
+    sample_n = pick
+    return {"value": dofs / t, "unit": "DoF/s", "cores": cores, "kind": "port",
+            "single_core_value": dofs1 / t1, "spmv_gbs": round(gbs, 1), "single_core_spmv_gbs": round(gbs1, 1),
+            "scipy_spmv_gbs": round(scipy_gbs, 1),
+            "sample": f"{sample_n}^3 Q1 unit cube ({dofs} DoF), same algorithm as the GPU step (assemble + multigrid setup + "
+                      f"inexact Picard: {sw} sweeps, {inner} CG iterations, V({smooth},{smooth}), reduction {reduction:g}) in "
+                      f"C/OpenMP on {cores} threads, {t:.1f} s; single_core_value: {small}^3 on 1 thread, {t1:.1f} s"}
 
 
 def main():
@@ -109,8 +156,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--cells", type=int, default=256, help="cells per direction of the unit cube")
-    ap.add_argument("--cpu-sample-n", type=int, default=64)
+    ap.add_argument("--cpu-sample-n", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0: cgroup share, at most 16)")
     ap.add_argument("--inner-rtol", type=float, default=1e-10)
     ap.add_argument("--smooth", type=int, default=1)
     ap.add_argument("--inner-reduction", type=float, default=1e-2)
@@ -255,7 +303,7 @@ def main():
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, k1, k2, beta, mu, args.smooth, args.inner_reduction,
-                                           args.inner_rtol)
+                                           args.inner_rtol, args.cpu_threads)
     elif rank == 0:
         out["cpu_baseline"] = None
     if dist is not None:

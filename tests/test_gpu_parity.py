@@ -641,3 +641,44 @@ def test_full_size_properties_256cubed(gpu_ctx_factory, hexa, k2):
     tol = 5e-4 if hexa else 2e-2      # config 5: boundary layer exp(100 y) resolved with eta*h = 0.39
     assert np.abs(xs[:n] - ex1).max() / np.abs(ex1).max() < tol
     assert np.abs(xs[n:] - ex2).max() / np.abs(ex2).max() < tol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hexa,N", [(True, 96), (False, 48)])
+def test_hip_matches_cpu_port_mid_size(gpu_ctx_factory, hexa, N):
+    """HIP path vs the C/OpenMP restatement (oracle/dpp_cpu.c) at sizes the NumPy oracle cannot reach in seconds:
+    K/M/blocks entry for entry, right-hand side, and the bench's inexact-Picard solve (same sweeps, same number
+    of CG iterations, same solution)."""
+    from oracle import dpp_cpu as cpu
+
+    f = _ffi()
+    kind = f.CELL_HEX if hexa else f.CELL_TET
+    S = cpu.CpuSystem(3, kind, N, N, N)
+    ctx = gpu_ctx_factory()
+    ctx.mesh_build(3, kind, N, N, N)
+    import perphil_amd.fd as fdm
+
+    mesh = fdm.UnitCubeMesh(N, N, N, hexahedral=hexa)
+    b = mesh.boundary_nodes()
+    e1, e2 = o.exact_pressures(mesh.node_coordinates(b), P)
+    for tgt in (S, ctx):
+        tgt.set_dirichlet(0, b, e1)
+        tgt.set_dirichlet(1, b, e2)
+    S.assemble(P.k1, P.k2, P.beta, P.mu)
+    ctx.assemble(P.k1, P.k2, P.beta, P.mu, monolithic=False)
+    for wc, wg in ((cpu.MAT_K, f.MAT_K), (cpu.MAT_M, f.MAT_M), (cpu.MAT_A11, f.MAT_A11), (cpu.MAT_A22, f.MAT_A22),
+                   (cpu.MAT_A12, f.MAT_A12)):
+        ref, got = S.csr(wc), ctx.csr(wg)
+        np.testing.assert_array_equal(got.indptr, ref.indptr)
+        np.testing.assert_array_equal(got.indices, ref.indices)
+        np.testing.assert_allclose(got.data, ref.data, rtol=0, atol=1e-12 * np.abs(ref.data).max())
+    r_ref, _ = S.rhs()
+    r, _ = ctx.rhs()
+    np.testing.assert_allclose(r, r_ref, rtol=0, atol=1e-12 * np.abs(r_ref).max())
+    S.mg_setup()
+    x_ref, sweeps, inner, res = S.picard()
+    xs, info, _ = ctx.solve(_cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_MG, inner_rtol=1e-10,
+                                 inner_reduction=1e-2, mg_smooth=1, picard_rtol=1e-8, picard_max_it=100))
+    assert info.converged and info.iterations == sweeps and info.inner_iterations == inner
+    assert np.abs(xs - x_ref).max() <= 1e-9 * np.abs(x_ref).max()
+    assert info.resnorm == pytest.approx(res, rel=1e-3)
