@@ -31,7 +31,7 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def picard_cfg(_ffi, inner_rtol=1e-10, smooth=2, reduction=0.0):
+def picard_cfg(_ffi, inner_rtol=1e-10, smooth=2, reduction=0.0, inner_norm=0):
     cfg = _ffi.SolverCfg()
     cfg.ksp_type, cfg.pc_type, cfg.restart, cfg.max_it = _ffi.KSP_GMRES, _ffi.PC_FIELDSPLIT, 30, 50000
     cfg.rtol, cfg.atol = 1e-8, 1e-12
@@ -40,6 +40,7 @@ def picard_cfg(_ffi, inner_rtol=1e-10, smooth=2, reduction=0.0):
     cfg.picard, cfg.picard_rtol, cfg.picard_atol, cfg.picard_max_it = 1, 1e-8, 1e-12, 100
     cfg.mg_smooth = smooth
     cfg.inner_reduction = reduction
+    cfg.inner_norm = inner_norm
     return cfg
 
 
@@ -68,7 +69,7 @@ def _mms_boundary_np(N, k1, k2, beta, mu):
     return idx[on], g1, g2
 
 
-def _cpu_port_run(N, threads, k1, k2, beta, mu, smooth, reduction, inner_rtol):
+def _cpu_port_run(N, threads, k1, k2, beta, mu, smooth, reduction, inner_rtol, inner_norm):
     """One step (assemble + multigrid setup + inexact Picard) of the C/OpenMP restatement; seconds, sweeps, its."""
     from oracle import dpp_cpu as cpu
 
@@ -81,7 +82,7 @@ def _cpu_port_run(N, threads, k1, k2, beta, mu, smooth, reduction, inner_rtol):
     S.assemble(k1, k2, beta, mu)
     S.mg_setup()
     _, sweeps, inner, _ = S.picard(pc=cpu.PC_MG, inner_rtol=inner_rtol, reduction=reduction, smooth=smooth, rtol=1e-8,
-                                   atol=1e-12, max_it=100)
+                                   atol=1e-12, max_it=100, inner_norm=inner_norm)
     t = time.perf_counter() - t0
     spmv_gbs = (12.0 * S.nnz + 20.0 * S.n) / S.spmv_seconds(cpu.MAT_A11, 10) / 1e9
     dofs = 2 * S.n
@@ -118,14 +119,14 @@ def host_cores(cap=16):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(sample_n, k1, k2, beta, mu, smooth=1, reduction=1e-2, inner_rtol=1e-10, threads=0):
+def cpu_baseline(sample_n, k1, k2, beta, mu, smooth=1, reduction=1e-1, inner_rtol=1e-10, threads=0, inner_norm=1):
     """The CPU port (oracle/dpp_cpu.c: C99 + OpenMP restatement of the same algorithm - assembly, multigrid
     setup, inexact Picard with multigrid-CG block solves) timed on the host: all available cores on a
     `sample_n`^3 cube (bounded sample of the 256^3 workload) and one core on 64^3; returns DoF/s."""
     cores = threads if threads > 0 else host_cores()
     small = min(64, sample_n)
-    t1, sw1, in1, dofs1, gbs1, scipy_gbs = _cpu_port_run(small, 1, k1, k2, beta, mu, smooth, reduction, inner_rtol)
-    t, sw, inner, dofs, gbs, _ = _cpu_port_run(small, cores, k1, k2, beta, mu, smooth, reduction, inner_rtol)
+    t1, sw1, in1, dofs1, gbs1, scipy_gbs = _cpu_port_run(small, 1, k1, k2, beta, mu, smooth, reduction, inner_rtol, inner_norm)
+    t, sw, inner, dofs, gbs, _ = _cpu_port_run(small, cores, k1, k2, beta, mu, smooth, reduction, inner_rtol, inner_norm)
     # largest cube up to sample_n whose predicted time stays within a minute and whose ~2.3 KB per node fit in memory
     try:
         import psutil
@@ -140,13 +141,14 @@ def cpu_baseline(sample_n, k1, k2, beta, mu, smooth=1, reduction=1e-2, inner_rto
             break
         cand //= 2
     if pick > small:
-        t, sw, inner, dofs, gbs, _ = _cpu_port_run(pick, cores, k1, k2, beta, mu, smooth, reduction, inner_rtol)
+        t, sw, inner, dofs, gbs, _ = _cpu_port_run(pick, cores, k1, k2, beta, mu, smooth, reduction, inner_rtol, inner_norm)
     sample_n = pick
     return {"value": dofs / t, "unit": "DoF/s", "cores": cores, "kind": "port",
             "single_core_value": dofs1 / t1, "spmv_gbs": round(gbs, 1), "single_core_spmv_gbs": round(gbs1, 1),
             "scipy_spmv_gbs": round(scipy_gbs, 1),
             "sample": f"{sample_n}^3 Q1 unit cube ({dofs} DoF), same algorithm as the GPU step (assemble + multigrid setup + "
-                      f"inexact Picard: {sw} sweeps, {inner} CG iterations, V({smooth},{smooth}), reduction {reduction:g}) in "
+                      f"inexact Picard: {sw} sweeps, {inner} CG iterations, V({smooth},{smooth}), reduction {reduction:g} of the "
+                      f"{'unpreconditioned' if inner_norm else 'preconditioned'} residual) in "
                       f"C/OpenMP on {cores} threads, {t:.1f} s; single_core_value: {small}^3 on 1 thread, {t1:.1f} s"}
 
 
@@ -161,8 +163,12 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0: cgroup share, at most 16)")
     ap.add_argument("--inner-rtol", type=float, default=1e-10)
     ap.add_argument("--smooth", type=int, default=1)
-    ap.add_argument("--inner-reduction", type=float, default=1e-2)
+    ap.add_argument("--inner-reduction", type=float, default=1e-1)
+    ap.add_argument("--inner-norm", type=int, default=1, choices=(0, 1),
+                    help="norm tested by the block solves: 0 preconditioned, 1 unpreconditioned")
     ap.add_argument("--asm-kernel", type=int, default=2)
+    ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
+                    help="extra pph_set_option settings for A/B runs (e.g. spmv_kernel=8)")
     ap.add_argument("--skip-fine-bench", action="store_true", help="omit the isolated fine-level SpMV loop (PMC passes)")
     args = ap.parse_args()
 
@@ -196,8 +202,10 @@ def main():
         from perphil_amd.distributed import SlabSolver
 
         solver = SlabSolver(N, world, rank, device, k1, k2, beta, mu, inner_rtol=args.inner_rtol, smooth=args.smooth,
-                            inner_reduction=args.inner_reduction)
+                            inner_reduction=args.inner_reduction, inner_norm=args.inner_norm)
         solver.ctx.set_option("asm_kernel", args.asm_kernel)
+        for kv in args.set:
+            solver.ctx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
         dofs_global = solver.global_dofs
         step = solver.step
         ctx = solver.ctx
@@ -207,8 +215,10 @@ def main():
         b, g1, g2 = mms_boundary(N, k1, k2, beta, mu)
         ctx.set_dirichlet(0, b, g1)
         ctx.set_dirichlet(1, b, g2)
-        cfg = picard_cfg(_ffi, args.inner_rtol, args.smooth, args.inner_reduction)
+        cfg = picard_cfg(_ffi, args.inner_rtol, args.smooth, args.inner_reduction, args.inner_norm)
         ctx.set_option("asm_kernel", args.asm_kernel)
+        for kv in args.set:
+            ctx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
         dofs_global = 2 * ctx.n
         last = {}
 
@@ -273,6 +283,12 @@ def main():
                        "achieved": round(fine_bytes / 1e9 / (fine_ms / 1e3), 1) if fine_ms == fine_ms else None,
                        "frac": round(fine_bytes / 1e9 / (fine_ms / 1e3) / HBM_PEAK_GBS, 4) if fine_ms == fine_ms else None},
     }
+    if tr["spmv_fine_launches"] and tr["spmv_fine_ms"] > 0:
+        # the fine-level launches of the instrumented step itself (cold x, operators alternating), beside the isolated loop
+        fa = tr["spmv_fine_bytes"] / 1e9 / (tr["spmv_fine_ms"] / 1e3)
+        roofline["fine_level_in_solver"] = {"launches_per_step": tr["spmv_fine_launches"],
+                                            "avg_launch_ms": round(tr["spmv_fine_ms"] / tr["spmv_fine_launches"], 4),
+                                            "achieved": round(fa, 1), "frac": round(fa / HBM_PEAK_GBS, 4)}
 
     out = {
         "metric": "DoF/s (assemble+solve), 3D UnitCube Q1 DPP, Picard-split",
@@ -291,7 +307,8 @@ def main():
             "workload": f"3D UnitCube {N}^3 Q1, two-pressure DPP (k1=1, k2=1e-2, beta=mu=1), manufactured Dirichlet data, "
                         f"assemble + block Picard (fixed-stress) to snes_rtol 1e-8 (true residual), warm-started block solves = "
                         f"CG + geometric multigrid (Chebyshev-Jacobi V({args.smooth},{args.smooth})) on CSR blocks, each to a "
-                        f"residual reduction of {args.inner_reduction:g} (or rtol {args.inner_rtol:g})",
+                        f"reduction of the {'unpreconditioned' if args.inner_norm else 'preconditioned'} residual by "
+                        f"{args.inner_reduction:g} (or rtol {args.inner_rtol:g})",
             "cells": N ** 3, "dofs": int(dofs_global), "parallelism": f"slab{world}" if world > 1 else "single",
             "picard_sweeps": int(info.iterations), "inner_cg_iterations": int(info.inner_iterations),
             "picard_ms_per_sweep": round(tm["solve_ms"] / max(int(info.iterations), 1), 3),
@@ -303,7 +320,7 @@ def main():
     }
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, k1, k2, beta, mu, args.smooth, args.inner_reduction,
-                                           args.inner_rtol, args.cpu_threads)
+                                           args.inner_rtol, args.cpu_threads, args.inner_norm)
     elif rank == 0:
         out["cpu_baseline"] = None
     if dist is not None:

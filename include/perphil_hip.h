@@ -82,6 +82,12 @@ typedef struct {
                           * factor from its value at the start of the solve (inexact Picard sweeps; warm
                           * starts make the sequence converge to the exact fixed point), or at inner_rtol,
                           * whichever comes first.  0: inner_rtol only.                       */
+  int32_t inner_norm;    /* norm the block solves test (ksp_norm_type of the fieldsplit_i_ solvers): 0 =
+                          * preconditioned ||P^-1 r|| (PETSc's default for left-preconditioned CG), 1 =
+                          * unpreconditioned ||r||_2 (KSP_NORM_UNPRECONDITIONED): the recurrence residual is
+                          * known before the preconditioner runs, so a block solve of k iterations costs k
+                          * preconditioner applications instead of k + 1                          */
+  int32_t reserved0;
 } pph_solver_cfg;
 
 typedef struct {
@@ -204,7 +210,9 @@ int pph_comm_selftest(pph_ctx* ctx);
  * out[0] mesh+pattern ms, [1] K/M integration+scatter ms, [2] BC elimination/blocks ms, [3] last solve ms;
  * SpMV accounting of the last solve per kernel variant v (0: plain, 1: fused with the p.Ap dot):
  * out[4+3v] sum of per-launch durations in ms (0 unless option "time_spmv" is on), out[5+3v] launches,
- * out[6+3v] algorithmic bytes (12 nnz + 20 nrows per launch); out[10] halo exchanges of the last solve. */
+ * out[6+3v] algorithmic bytes (12 nnz + 20 nrows per launch); out[10] halo exchanges of the last solve;
+ * out[11..13] the same three figures (ms, launches, bytes; both variants together) for the launches on
+ * fine-level operators only (rows >= nodes of the mesh), i.e. without the coarser multigrid levels. */
 int pph_get_timers(pph_ctx* ctx, double* out, int n);
 /* tuning / profiling switches (no reference counterpart): "spmv_lanes" (0 = automatic, 4..64 lanes per
  * CSR row), "time_spmv" (1: bracket every SpMV launch of a solve with a HIP event pair on the context

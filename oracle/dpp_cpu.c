@@ -543,16 +543,44 @@ static void apply_pc(csys* S, int which, int pc, int smooth, const double* dinv,
   } else vcopy(n, r, z);
 }
 
-/* PETSc-style PCG on block `which` (0: A11, 1: A22): preconditioned-residual norm, tolerance
- * max(rtol*||P^-1 b||, atol, reduction * ||P^-1 r_0||) (cf. oracle/dpp_oracle.py pcg) */
+/* PETSc-style PCG on block `which` (0: A11, 1: A22).  norm 0: preconditioned-residual norm, tolerance
+ * max(rtol*||P^-1 b||, atol, reduction * ||P^-1 r_0||); norm 1 (KSP_NORM_UNPRECONDITIONED): ||r||_2 with
+ * max(rtol*||b||, atol, reduction * ||r_0||), tested before the preconditioner is applied
+ * (cf. oracle/dpp_oracle.py pcg) */
 static ksp_out pcg(csys* S, int which, int pc, int smooth, const double* b, double* x, int warm, double rtol, double atol,
-                   int max_it, double reduction, double* w /* 4n work */) {
+                   int max_it, double reduction, int norm, double* w /* 4n work */) {
   const cmesh* M = &S->mesh;
   const int64_t n = M->n;
   const double* A = which ? S->A22 : S->A11;
   const double* dinv = S->H[which].nlev ? S->H[which].lv[0].dinv : NULL;
   double *r = w, *z = w + n, *p = w + 2 * n, *q = w + 3 * n;
   ksp_out out = {0, 0.0, 0};
+  if (norm == 1) {
+    const double bnorm = sqrt(dot(n, b, b));
+    if (warm) resid(M, A, x, b, r);
+    else { vzero(n, x); vcopy(n, b, r); }
+    double res = sqrt(dot(n, r, r));
+    const double tol = fmax(fmax(rtol * bnorm, atol), reduction * res);
+    out.res = res;
+    if (res <= tol) { out.converged = 1; return out; }
+    apply_pc(S, which, pc, smooth, dinv, r, z);
+    vcopy(n, z, p);
+    double rz = dot(n, r, z);
+    while (out.its < max_it) {
+      spmv(M, A, p, q);
+      const double alpha = rz / dot(n, p, q);
+      axpy(n, alpha, p, x);
+      axpy(n, -alpha, q, r);
+      out.its++;
+      out.res = sqrt(dot(n, r, r));
+      if (out.res <= tol) { out.converged = 1; return out; }
+      apply_pc(S, which, pc, smooth, dinv, r, z);
+      const double rzn = dot(n, r, z);
+      xpby(n, z, rzn / rz, p);
+      rz = rzn;
+    }
+    return out;
+  }
   double bnorm;
   if (warm) {
     apply_pc(S, which, pc, smooth, dinv, b, z);
@@ -732,12 +760,12 @@ void dppc_vcycle(void* h, int which, const double* r, double* z, int smooth) {
 }
 
 int dppc_pcg(void* h, int which, int pc, const double* b, double* x, int warm, double rtol, double atol, int max_it,
-             double reduction, int smooth, double* resnorm) {
+             double reduction, int smooth, int norm, double* resnorm) {
   csys* S = (csys*)h;
   const int64_t n = S->mesh.n;
   if (!S->H[which].nlev) return -1;         /* the Jacobi diagonal lives on level 0 of the hierarchy */
   double* w = (double*)malloc(sizeof(double) * (size_t)(4 * n));
-  ksp_out o = pcg(S, which, pc, smooth, b, x, warm, rtol, atol, max_it, reduction, w);
+  ksp_out o = pcg(S, which, pc, smooth, b, x, warm, rtol, atol, max_it, reduction, norm, w);
   free(w);
   if (resnorm) *resnorm = o.res;
   return o.converged ? o.its : -2 - o.its;
@@ -746,7 +774,7 @@ int dppc_pcg(void* h, int which, int pc, const double* b, double* x, int warm, d
 /* Block Picard per dpp_delayed_form (Gauss-Seidel order, warm-started inexact block solves) until the true
  * residual of the monolithic system drops below max(rtol*||F(u0)||, atol).  x_out = u0 + correction. */
 int dppc_picard(void* h, int pc, double inner_rtol, double inner_atol, int inner_max_it, double reduction, int smooth,
-                double rtol, double atol, int max_it, double* x_out, int* inner_its, double* resnorm) {
+                int inner_norm, double rtol, double atol, int max_it, double* x_out, int* inner_its, double* resnorm) {
   csys* S = (csys*)h;
   const cmesh* M = &S->mesh;
   const int64_t n = M->n;
@@ -762,11 +790,12 @@ int dppc_picard(void* h, int pc, double inner_rtol, double inner_atol, int inner
     spmv(M, S->A12, du + n, t);
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) b[i] = S->rhs[i] - t[i];
-    ksp_out o1 = pcg(S, 0, pc, smooth, b, du, sweeps > 0, inner_rtol, inner_atol, inner_max_it, reduction, w);
+    ksp_out o1 = pcg(S, 0, pc, smooth, b, du, sweeps > 0, inner_rtol, inner_atol, inner_max_it, reduction, inner_norm, w);
     spmv(M, S->A21, du, t);
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < n; ++i) b[i] = S->rhs[n + i] - t[i];
-    ksp_out o2 = pcg(S, 1, pc, smooth, b, du + n, sweeps > 0, inner_rtol, inner_atol, inner_max_it, reduction, w);
+    ksp_out o2 = pcg(S, 1, pc, smooth, b, du + n, sweeps > 0, inner_rtol, inner_atol, inner_max_it, reduction, inner_norm,
+                     w);
     tot += o1.its + o2.its;
     sweeps++;
     /* true residual of the monolithic system */

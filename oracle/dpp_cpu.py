@@ -49,8 +49,8 @@ def _load():
     lib.dppc_spmv_bench.restype = f64
     lib.dppc_vcycle.argtypes = [p, i32, p, p, i32]
     lib.dppc_vcycle.restype = None
-    lib.dppc_pcg.argtypes = [p, i32, i32, p, p, i32, f64, f64, i32, f64, i32, p]
-    lib.dppc_picard.argtypes = [p, i32, f64, f64, i32, f64, i32, f64, f64, i32, p, p, p]
+    lib.dppc_pcg.argtypes = [p, i32, i32, p, p, i32, f64, f64, i32, f64, i32, i32, p]
+    lib.dppc_picard.argtypes = [p, i32, f64, f64, i32, f64, i32, i32, f64, f64, i32, p, p, p]
     lib.dppc_num_threads.restype = i32
     lib.dppc_set_threads.argtypes = [i32]
     lib.dppc_set_threads.restype = None
@@ -136,20 +136,20 @@ class CpuSystem:
         lib.dppc_vcycle(self._h, which, _ptr(r), _ptr(z), smooth)
         return z
 
-    def pcg(self, which, pc, b, x0=None, rtol=1e-8, atol=1e-12, max_it=50000, reduction=0.0, smooth=2):
+    def pcg(self, which, pc, b, x0=None, rtol=1e-8, atol=1e-12, max_it=50000, reduction=0.0, smooth=2, norm=0):
         b = np.ascontiguousarray(b, np.float64)
         x = np.zeros_like(b) if x0 is None else np.array(x0, np.float64)
         res = C.c_double()
         its = lib.dppc_pcg(self._h, which, pc, _ptr(b), _ptr(x), int(x0 is not None), rtol, atol, max_it, reduction, smooth,
-                           C.byref(res))
+                           norm, C.byref(res))
         return x, its, res.value
 
     def picard(self, pc=PC_MG, inner_rtol=1e-10, inner_atol=1e-300, inner_max_it=50000, reduction=1e-2, smooth=1,
-               rtol=1e-8, atol=1e-12, max_it=100):
+               rtol=1e-8, atol=1e-12, max_it=100, inner_norm=0):
         x = np.empty(2 * self.n)
         inner, res = C.c_int(), C.c_double()
-        sweeps = lib.dppc_picard(self._h, pc, inner_rtol, inner_atol, inner_max_it, reduction, smooth, rtol, atol, max_it,
-                                 _ptr(x), C.byref(inner), C.byref(res))
+        sweeps = lib.dppc_picard(self._h, pc, inner_rtol, inner_atol, inner_max_it, reduction, smooth, inner_norm, rtol, atol,
+                                 max_it, _ptr(x), C.byref(inner), C.byref(res))
         return x, sweeps, inner.value, res.value
 
 

@@ -353,12 +353,39 @@ def gmres(A, b, M_apply: Optional[Callable] = None, rtol=1e-8, atol=1e-12, max_i
 
 
 def pcg(A, b, M_apply: Optional[Callable] = None, rtol=1e-8, atol=1e-12, max_it=50000,
-        x0: Optional[np.ndarray] = None, reduction: float = 0.0) -> KspResult:
-    """Preconditioned CG, PETSc default norm: preconditioned residual ||z||_2.  ``reduction`` > 0 also accepts a
-    drop of the residual by that factor from its value at the start of this solve (inexact Picard sweeps)."""
+        x0: Optional[np.ndarray] = None, reduction: float = 0.0, norm: str = "preconditioned") -> KspResult:
+    """Preconditioned CG.  ``norm="preconditioned"`` (PETSc default): tests ||z||_2, z = P^-1 r;
+    ``norm="unpreconditioned"`` (KSP_NORM_UNPRECONDITIONED): tests ||r||_2, known before the preconditioner is
+    applied.  ``reduction`` > 0 also accepts a drop of that norm by that factor from its value at the start of this
+    solve (inexact Picard sweeps)."""
     prec = (lambda v: v) if M_apply is None else M_apply
     x = np.zeros_like(b) if x0 is None else x0.copy()
     r = b - A @ x if x0 is not None else b.copy()
+    if norm == "unpreconditioned":
+        res = float(np.linalg.norm(r))
+        tol = max(rtol * float(np.linalg.norm(b)), atol, reduction * res)
+        hist = [res]
+        if res <= tol:
+            return KspResult(x, 0, res, hist, True)
+        z = prec(r)
+        p = z.copy()
+        rz = float(np.dot(r, z))
+        its = 0
+        while its < max_it:
+            Ap = A @ p
+            alpha = rz / float(np.dot(p, Ap))
+            x += alpha * p
+            r -= alpha * Ap
+            its += 1
+            res = float(np.linalg.norm(r))
+            hist.append(res)
+            if res <= tol:
+                return KspResult(x, its, res, hist, True)
+            z = prec(r)
+            rz_new = float(np.dot(r, z))
+            p = z + (rz_new / rz) * p
+            rz = rz_new
+        return KspResult(x, its, hist[-1], hist, False)
     z = prec(r)
     z0 = prec(b) if x0 is not None else z
     res = float(np.linalg.norm(z))

@@ -52,6 +52,7 @@ class SolverCfg(C.Structure):
         ("picard_rtol", C.c_double), ("picard_atol", C.c_double),
         ("picard_max_it", C.c_int32), ("mg_smooth", C.c_int32),
         ("inner_reduction", C.c_double),
+        ("inner_norm", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -294,9 +295,10 @@ class Context:
         return out
 
     def timers(self) -> dict:
-        t = np.zeros(11, dtype=np.float64)
-        self._check(lib.pph_get_timers(self._h, _ptr(t), 11))
+        t = np.zeros(14, dtype=np.float64)
+        self._check(lib.pph_get_timers(self._h, _ptr(t), 14))
         return {"mesh_ms": t[0], "assemble_ms": t[1], "bc_blocks_ms": t[2], "solve_ms": t[3],
                 "spmv_ms": t[4], "spmv_launches": int(t[5]), "spmv_bytes": t[6],
                 "spmv_dot_ms": t[7], "spmv_dot_launches": int(t[8]), "spmv_dot_bytes": t[9],
-                "halo_exchanges": int(t[10])}
+                "halo_exchanges": int(t[10]),
+                "spmv_fine_ms": t[11], "spmv_fine_launches": int(t[12]), "spmv_fine_bytes": t[13]}

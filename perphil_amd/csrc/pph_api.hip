@@ -379,6 +379,36 @@ int pph_spmv_bench(pph_ctx* ctx, int which, int reps, double* avg_ms) {
   PPH_TRY(x.alloc(ctx, (size_t)A.nrows));
   PPH_TRY(y.alloc(ctx, (size_t)A.nrows));
   hipLaunchKernelGGL(k_fill_pattern, dim3(2048), dim3(256), 0, ctx->stream, x.p, A.nrows);
+  if (ctx->spmv_bench_mode != 0) {
+    // interleaved protocols (what does a launch cost when something else ran in between?): every SpMV is timed
+    // with its own event pair; 1: a streaming axpy on two other vectors between products, 2: a one-block
+    // kernel between products, 3: products alternate between this matrix and A22 (or A11)
+    DevBuf<double> u, v;
+    PPH_TRY(u.alloc(ctx, (size_t)A.nrows));
+    PPH_TRY(v.alloc(ctx, (size_t)A.nrows));
+    la_set(ctx, u.p, 1.0, A.nrows);
+    la_set(ctx, v.p, 2.0, A.nrows);
+    Csr B = A;
+    if (ctx->spmv_bench_mode == 3) {
+      PPH_TRY(select_csr(ctx, which == 4 ? 3 : 4, &B));
+      B.lanes = A.lanes;
+    }
+    const bool was = ctx->time_spmv;
+    for (int i = 0; i < 5; ++i) la_spmv(ctx, (i & 1) ? B : A, x.p, y.p);
+    la_reset_spmv_stats(ctx);
+    ctx->time_spmv = true;
+    for (int i = 0; i < reps; ++i) {
+      la_spmv(ctx, (ctx->spmv_bench_mode == 3 && (i & 1)) ? B : A, x.p, y.p);
+      if (ctx->spmv_bench_mode == 1) la_axpy(ctx, u.p, 0.5, v.p, A.nrows);
+      if (ctx->spmv_bench_mode == 2) la_set(ctx, u.p, 1.0, 64);
+    }
+    la_harvest_spmv_times(ctx);
+    ctx->time_spmv = was;
+    *avg_ms = ctx->t_spmv[0] / reps;
+    la_reset_spmv_stats(ctx);
+    u.release(); v.release(); x.release(); y.release();
+    return PPH_OK;
+  }
   for (int i = 0; i < 20; ++i) la_spmv(ctx, A, x.p, y.p);  // warm-up (SURVEY.md §8d protocol: 20 + 200)
   PPH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   for (int i = 0; i < reps; ++i) la_spmv(ctx, A, x.p, y.p);
@@ -403,7 +433,7 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
   }
   if (!strcmp(name, "spmv_kernel")) {
     const int v = (int)value;
-    PPH_REQUIRE(ctx, (v >= 0 && v <= 16), "spmv_kernel: 0 vector, 1 vector+preload, 2 LDS stream, 3 aligned-wide (default), 4 LDS-transposed, 5-7 multi-row, 8 aligned-wide XCD-contiguous, 10 no-gather probe");
+    PPH_REQUIRE(ctx, (v >= 0 && v <= 17), "spmv_kernel: 0 vector, 1 vector+preload, 2 LDS stream, 3 aligned-wide (default), 4 LDS-transposed, 5-7 multi-row, 8 aligned-wide XCD-contiguous, 10 no-gather probe");
     ctx->spmv_kernel = v;
     return PPH_OK;
   }
@@ -427,6 +457,7 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
     return PPH_OK;
   }
   if (!strcmp(name, "spmv_blocks")) { ctx->spmv_blocks = (int)value; return PPH_OK; }
+  if (!strcmp(name, "spmv_bench_mode")) { ctx->spmv_bench_mode = (int)value; return PPH_OK; }
   if (!strcmp(name, "time_spmv")) { ctx->time_spmv = value != 0.0; return PPH_OK; }
   if (!strcmp(name, "invalidate_KM")) {
     // forget the integrated K and M (all multigrid levels) so that the next assemble + solve integrates
@@ -459,10 +490,11 @@ int pph_comm_set_callbacks(pph_ctx* ctx, int rank, int world, pph_halo_fn halo, 
 int pph_get_timers(pph_ctx* ctx, double* out, int n) {
   if (!ctx || !out) return PPH_ERR_INVALID;
   la_harvest_spmv_times(ctx);
-  const double v[11] = {ctx->t_mesh, ctx->t_asm, ctx->t_bc, ctx->t_solve,
+  const double v[14] = {ctx->t_mesh, ctx->t_asm, ctx->t_bc, ctx->t_solve,
                         ctx->t_spmv[0], (double)ctx->n_spmv[0], ctx->spmv_bytes[0],
-                        ctx->t_spmv[1], (double)ctx->n_spmv[1], ctx->spmv_bytes[1], (double)ctx->n_halo};
-  for (int i = 0; i < n && i < 11; ++i) out[i] = v[i];
+                        ctx->t_spmv[1], (double)ctx->n_spmv[1], ctx->spmv_bytes[1], (double)ctx->n_halo,
+                        ctx->t_spmv_fine, (double)ctx->n_spmv_fine, ctx->spmv_bytes_fine};
+  for (int i = 0; i < n && i < 14; ++i) out[i] = v[i];
   return PPH_OK;
 }
 

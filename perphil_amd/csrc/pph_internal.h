@@ -161,11 +161,14 @@ struct pph_ctx {
   double spmv_bytes[2] = {0, 0};
   int64_t n_spmv[2] = {0, 0};
   bool time_spmv = false;
-  struct EvPair { hipEvent_t e0, e1; int variant; };
+  struct EvPair { hipEvent_t e0, e1; int variant; bool fine; };
+  double t_spmv_fine = 0, spmv_bytes_fine = 0;   // the fine-level launches among t_spmv / spmv_bytes
+  int64_t n_spmv_fine = 0;
   std::vector<EvPair> ev_pool;          // reusable event pairs
   size_t ev_used = 0;                   // pairs recorded since the last harvest
   int spmv_lanes_override = 0;          // 0: pick from the mean row length
   int spmv_blocks = 0;                  // 0: default persistent grid (1024 workgroups)
+  int spmv_bench_mode = 0;              // pph_spmv_bench protocol: 0 back-to-back, 1-3 interleaved (see pph_api.hip)
   int64_t mg_replicate_below = 40000;   // slabs: multigrid levels with at most this many global nodes are replicated
   int mg_fp32 = 0;                      // 1: V-cycle SpMVs read fp32 copies of the operator values (8 instead of 12 B per non-zero)
   int asm_kernel = 2;                   // multilinear cells: 2 two-pass (element rows + node gather, default), 1 one-pass node gather, 0 cell-centred atomic scatter-add

@@ -136,11 +136,27 @@ __global__ __launch_bounds__(256) void k_spmv_wide(const int64_t* __restrict__ r
   const int64_t c_first = LINEAR ? blockIdx.x : c_begin + bx;
   const int64_t c_step = LINEAR ? gridDim.x : bpx;
   double acc = 0.0;
+  // row pointers are fetched one chunk ahead, so that a row's matrix loads do not wait for them
+  int64_t s = 0, e = 0;
+  if (c_first < c_end && c_first * RPB + grp < nrows) {
+    s = rowptr[c_first * RPB + grp];
+    e = rowptr[c_first * RPB + grp + 1];
+  }
   for (int64_t ch = c_first; ch < c_end; ch += c_step) {
     const int64_t row = ch * RPB + grp;
+    const int64_t nrow = (ch + c_step) * RPB + grp;
+    int64_t ns = 0, ne = 0;
+    if (ch + c_step < c_end && nrow < nrows) {
+      ns = rowptr[nrow];
+      ne = rowptr[nrow + 1];
+    }
     double sum = 0.0;
+    // operands of the epilogue (b[row] of the residual form, x[row] of the fused p.Ap) are requested together with
+    // the row pointers: loading them after the reduction put one more memory latency on every row's critical path
+    double bv = 0.0, xr = 0.0;
     if (row < nrows) {
-      const int64_t s = rowptr[row], e = rowptr[row + 1];
+      if (bvec) bv = bvec[row];
+      if (DOT) xr = x[row];
       const int32_t safe = 0;  // column used by masked lanes (x[0] is always valid)
       for (int64_t base = (s & ~(int64_t)3) + 4 * sub; base < e; base += 4 * G) {
         int4 c;
@@ -188,9 +204,104 @@ __global__ __launch_bounds__(256) void k_spmv_wide(const int64_t* __restrict__ r
       for (int o = G / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, G);
     }
     if (sub == 0 && row < nrows) {
-      y[row] = bvec ? bvec[row] - sum : sum;
-      if (DOT) acc += sum * x[row];
+      y[row] = bvec ? bv - sum : sum;
+      if (DOT) acc += sum * xr;
     }
+    s = ns;
+    e = ne;
+  }
+  if (DOT) {
+    acc = block_sum(acc, lds);
+    if (threadIdx.x == 0) part[blockIdx.x] = acc;
+  }
+}
+
+// Software-pipelined aligned-wide variant.  A row's critical path in k_spmv_wide is three dependent memory
+// latencies (row pointers -> matrix entries -> x gather) that only occupancy hides.  Here every lane group
+// keeps two stages in flight: the row pointers of chunk i+2 and the first 4 G matrix entries of chunk i+1 are
+// requested before chunk i's gather starts, so the gather of one row overlaps the matrix stream of the next
+// and the only exposed latency per row is the gather itself.  Rows longer than one 4 G-entry step finish
+// with unpipelined steps (none for the 27- / 15-entry stencil rows of this path).
+template <int G, bool DOT, typename VT = double>
+__global__ __launch_bounds__(256) void k_spmv_pipe(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                   const VT* __restrict__ val, const double* __restrict__ x,
+                                                   const double* __restrict__ bvec, double* __restrict__ y,
+                                                   int64_t nrows, double* __restrict__ part) {
+  constexpr int RPB = 256 / G;
+  __shared__ double lds[4];
+  const int sub = threadIdx.x % G;
+  const int grp = threadIdx.x / G;
+  const int64_t nchunks = (nrows + RPB - 1) / RPB;
+  const int64_t step = gridDim.x;
+  auto load_ptr = [&](int64_t chunk, int64_t& ps, int64_t& pe) {
+    const int64_t r = chunk * RPB + grp;
+    ps = pe = 0;
+    if (chunk < nchunks && r < nrows) {
+      ps = rowptr[r];
+      pe = rowptr[r + 1];
+    }
+  };
+  auto load_mat = [&](int64_t base, int64_t pe, int4& c, double2& a01, double2& a23) {
+    c = make_int4(0, 0, 0, 0);
+    a01 = a23 = make_double2(0.0, 0.0);
+    if (base < pe) {
+      c = *reinterpret_cast<const int4*>(col + base);
+      if constexpr (sizeof(VT) == 4) {
+        const float4 vf = *reinterpret_cast<const float4*>(val + base);
+        a01 = make_double2((double)vf.x, (double)vf.y);
+        a23 = make_double2((double)vf.z, (double)vf.w);
+      } else {
+        a01 = *reinterpret_cast<const double2*>(reinterpret_cast<const double*>(val) + base);
+        a23 = *reinterpret_cast<const double2*>(reinterpret_cast<const double*>(val) + base + 2);
+      }
+    }
+  };
+  auto consume = [&](int64_t base, int64_t s, int64_t e, const int4& c, const double2& a01, const double2& a23) -> double {
+    const bool k0 = base >= s && base < e, k1 = base + 1 >= s && base + 1 < e, k2 = base + 2 >= s && base + 2 < e,
+               k3 = base + 3 >= s && base + 3 < e;
+    const double x0 = x[k0 ? c.x : 0], x1 = x[k1 ? c.y : 0], x2 = x[k2 ? c.z : 0], x3 = x[k3 ? c.w : 0];
+    return (k0 ? a01.x : 0.0) * x0 + (k1 ? a01.y : 0.0) * x1 + (k2 ? a23.x : 0.0) * x2 + (k3 ? a23.y : 0.0) * x3;
+  };
+  double acc = 0.0;
+  int64_t ch = blockIdx.x;
+  int64_t s, e, ns, ne;
+  int4 c;
+  double2 v01, v23;
+  load_ptr(ch, s, e);
+  load_mat((s & ~(int64_t)3) + 4 * sub, e, c, v01, v23);
+  load_ptr(ch + step, ns, ne);
+  for (; ch < nchunks; ch += step) {
+    const int64_t row = ch * RPB + grp;
+    int4 nc;
+    double2 nv01, nv23;
+    load_mat((ns & ~(int64_t)3) + 4 * sub, ne, nc, nv01, nv23);   // chunk i+1: matrix entries
+    int64_t nns, nne;
+    load_ptr(ch + 2 * step, nns, nne);                            // chunk i+2: row pointers
+    double bv = 0.0, xr = 0.0;
+    if (row < nrows) {
+      if (bvec) bv = bvec[row];
+      if (DOT) xr = x[row];
+    }
+    int64_t base = (s & ~(int64_t)3) + 4 * sub;
+    double sum = 0.0;
+    if (base < e) sum = consume(base, s, e, c, v01, v23);
+    for (base += 4 * G; base < e; base += 4 * G) {                // long rows: remaining steps, unpipelined
+      int4 c2;
+      double2 a01, a23;
+      load_mat(base, e, c2, a01, a23);
+      sum += consume(base, s, e, c2, a01, a23);
+    }
+    if constexpr (G == 8) {
+      sum = group8_sum(sum);
+    } else {
+#pragma unroll
+      for (int o = G / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, G);
+    }
+    if (sub == 0 && row < nrows) {
+      y[row] = bvec ? bv - sum : sum;
+      if (DOT) acc += sum * xr;
+    }
+    s = ns; e = ne; c = nc; v01 = nv01; v23 = nv23; ns = nns; ne = nne;
   }
   if (DOT) {
     acc = block_sum(acc, lds);
@@ -642,6 +753,7 @@ static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const doub
     if (ctx->ev_used < ctx->ev_pool.size()) {
       ev = &ctx->ev_pool[ctx->ev_used++];
       ev->variant = variant;
+      ev->fine = A.nrows >= ctx->mesh.n;
       (void)hipEventRecord(ev->e0, ctx->stream);
     }
   }
@@ -661,6 +773,7 @@ static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const doub
     if (ev) (void)hipEventRecord(ev->e1, ctx->stream);
     ctx->n_spmv[variant]++;
     ctx->spmv_bytes[variant] += bytes_per_nnz * (double)A.nnz + 20.0 * (double)A.nrows;
+    if (A.nrows >= ctx->mesh.n) { ctx->n_spmv_fine++; ctx->spmv_bytes_fine += bytes_per_nnz * (double)A.nnz + 20.0 * (double)A.nrows; }
     return grid;
   }
   const bool can_stream = A.max_row > 0 && A.max_row <= 8 * 64;
@@ -709,6 +822,14 @@ static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const doub
       hipLaunchKernelGGL((k_spmv_block<32, DOT>), dim3(grid), dim3(64), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
     else
       hipLaunchKernelGGL((k_spmv_block<16, DOT>), dim3(grid), dim3(64), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
+  } else if (ctx->spmv_kernel == 17) {
+    if (A.max_row > 0 && A.max_row + 3 <= 16) {
+      grid = spmv_grid(ctx, A.nrows, 256 / 4);
+      hipLaunchKernelGGL((k_spmv_pipe<4, DOT>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
+    } else {
+      grid = spmv_grid(ctx, A.nrows, 256 / 8);
+      hipLaunchKernelGGL((k_spmv_pipe<8, DOT>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
+    }
   } else if (ctx->spmv_kernel == 15) {
     grid = spmv_grid(ctx, A.nrows, 256 / 8);
     hipLaunchKernelGGL((k_spmv_wide2<DOT>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
@@ -771,6 +892,7 @@ static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const doub
   if (ev) (void)hipEventRecord(ev->e1, ctx->stream);
   ctx->n_spmv[variant]++;
   ctx->spmv_bytes[variant] += 12.0 * (double)A.nnz + 20.0 * (double)A.nrows;
+  if (A.nrows >= ctx->mesh.n) { ctx->n_spmv_fine++; ctx->spmv_bytes_fine += 12.0 * (double)A.nnz + 20.0 * (double)A.nrows; }
   return grid;
 }
 
@@ -779,8 +901,10 @@ void la_harvest_spmv_times(pph_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   for (size_t i = 0; i < ctx->ev_used; ++i) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, ctx->ev_pool[i].e0, ctx->ev_pool[i].e1) == hipSuccess)
+    if (hipEventElapsedTime(&ms, ctx->ev_pool[i].e0, ctx->ev_pool[i].e1) == hipSuccess) {
       ctx->t_spmv[ctx->ev_pool[i].variant] += ms;
+      if (ctx->ev_pool[i].fine) ctx->t_spmv_fine += ms;
+    }
   }
   ctx->ev_used = 0;
 }
@@ -788,6 +912,7 @@ void la_harvest_spmv_times(pph_ctx* ctx) {
 void la_reset_spmv_stats(pph_ctx* ctx) {
   la_harvest_spmv_times(ctx);
   for (int v = 0; v < 2; ++v) { ctx->t_spmv[v] = 0; ctx->spmv_bytes[v] = 0; ctx->n_spmv[v] = 0; }
+  ctx->t_spmv_fine = 0; ctx->spmv_bytes_fine = 0; ctx->n_spmv_fine = 0;
 }
 
 

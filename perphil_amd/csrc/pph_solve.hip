@@ -64,6 +64,81 @@ static Csr mono_csr(pph_ctx* ctx) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// preconditioned CG that tests the UNPRECONDITIONED residual ||r||_2 (KSP_NORM_UNPRECONDITIONED): the
+// recurrence residual is known before the preconditioner is applied, so a solve of k iterations costs k
+// preconditioner applications instead of k + 1 and a warm start that already meets the tolerance costs
+// none.  Tolerance: max(rtol * ||b||_2, atol, reduction * ||r_0||_2).  `bnorm_hint` is ||b||_2 of an
+// earlier, nearby system (see cg_solve).
+// ------------------------------------------------------------------------------------------------
+static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double* x, const double* dinv, const ApplyFn& pc,
+                            double rtol, double atol, int max_it, bool warm, double* r, double* z, double* p, double* q,
+                            int slot, KspOut* out, double* hist, int hist_cap, double bnorm_hint, double reduction,
+                            const double* r_init) {
+  const int64_t n = A.nrows;
+  const Seg sg = pph_owned_seg(A.geom, n);
+  auto apply_pc = [&](const double* in, double* o) {
+    if (dinv) la_pointwise_mult(ctx, o, dinv, in, n);
+    else if (pc) pc(in, o);
+    else la_copy(ctx, o, in, n);
+  };
+  double bnorm = -1.0;
+  if (warm) {
+    if (bnorm_hint > 0.0) {
+      bnorm = bnorm_hint;
+    } else {
+      la_mdot_seg(ctx, b, 0, 1, b, sg, slot);
+      PPH_TRY(la_fetch(ctx, slot, 1));
+      bnorm = std::sqrt(ctx->h_scal[slot]);
+    }
+    if (r_init) la_copy(ctx, r, r_init, n);
+    else la_spmv_resid(ctx, A, x, b, r);
+  } else {
+    la_set(ctx, x, 0.0, n);
+    la_copy(ctx, r, b, n);
+  }
+  la_mdot_seg(ctx, r, 0, 1, r, sg, slot);
+  PPH_TRY(la_fetch(ctx, slot, 1));
+  double res = std::sqrt(ctx->h_scal[slot]);
+  if (bnorm < 0.0) bnorm = res;
+  const double tol = std::fmax(std::fmax(rtol * bnorm, atol), reduction > 0.0 ? reduction * res : 0.0);
+  out->its = 0; out->res = res; out->converged = false; out->breakdown = false; out->bnorm = bnorm;
+  if (hist && hist_cap > 0) hist[0] = res;
+  if (!(res == res)) { out->breakdown = true; return PPH_OK; }
+  if (res <= tol) { out->converged = true; return PPH_OK; }
+  apply_pc(r, z);
+  la_mdot_seg(ctx, r, 0, 1, z, sg, slot);
+  PPH_TRY(la_fetch(ctx, slot, 1));
+  double rz = ctx->h_scal[slot];
+  la_copy(ctx, p, z, n);
+  int its = 0;
+  while (its < max_it) {
+    la_spmv_dot(ctx, A, p, q, slot);
+    PPH_TRY(la_fetch(ctx, slot, 1));
+    const double pq = ctx->h_scal[slot];
+    if (!(pq > 0.0) || !(rz == rz)) { out->breakdown = true; break; }
+    const double alpha = rz / pq;
+    la_axpy(ctx, x, alpha, p, n);
+    la_axpy(ctx, r, -alpha, q, n);
+    la_mdot_seg(ctx, r, 0, 1, r, sg, slot);
+    PPH_TRY(la_fetch(ctx, slot, 1));
+    res = std::sqrt(ctx->h_scal[slot]);
+    ++its;
+    if (hist && its < hist_cap) hist[its] = res;
+    if (!(res == res)) { out->breakdown = true; break; }
+    if (res <= tol) { out->converged = true; break; }
+    apply_pc(r, z);
+    la_mdot_seg(ctx, r, 0, 1, z, sg, slot);
+    PPH_TRY(la_fetch(ctx, slot, 1));
+    const double rz_new = ctx->h_scal[slot];
+    la_axpby(ctx, p, 1.0, z, rz_new / rz, n);
+    rz = rz_new;
+  }
+  out->its = its;
+  out->res = res;
+  return PPH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // preconditioned CG.  `dinv` != null selects the fused Jacobi path; otherwise `pc` (may be empty =
 // identity) is called.  x holds the initial guess when warm != 0, else it is zeroed here.
 // work vectors r,z,p,q are supplied by the caller (inner and outer solves use disjoint sets).
@@ -71,8 +146,11 @@ static Csr mono_csr(pph_ctx* ctx) {
 static int cg_solve(pph_ctx* ctx, const Csr& A, const double* b, double* x, const double* dinv, const ApplyFn& pc,
                     double rtol, double atol, int max_it, bool warm, double* r, double* z, double* p, double* q,
                     int slot, KspOut* out, double* hist, int hist_cap, double bnorm_hint = -1.0,
-                    double reduction = 0.0, const double* r_init = nullptr) {
+                    double reduction = 0.0, const double* r_init = nullptr, int norm_type = 0) {
   const int64_t n = A.nrows;
+  if (norm_type == 1)
+    return cg_solve_natural(ctx, A, b, x, dinv, pc, rtol, atol, max_it, warm, r, z, p, q, slot, out, hist, hist_cap,
+                            bnorm_hint, reduction, r_init);
   // reductions run over the owned entries of a slab (whole vector on a single GPU)
   const Seg sg = pph_owned_seg(A.geom, n);
   const bool fused = (dinv != nullptr) || !pc;
@@ -330,7 +408,7 @@ struct BlockSolver {
     }
     PPH_TRY(cg_solve(ctx, A[which], rhs, z, dinv[which], pc, cfg->inner_rtol, cfg->inner_atol, cfg->inner_max_it,
                      warm, r, zz, p, q, S_INNER, &ko, nullptr, 0, warm ? bnorm_cache[which] : -1.0,
-                     cfg->inner_reduction, warm ? r_init : nullptr));
+                     cfg->inner_reduction, warm ? r_init : nullptr, cfg->inner_norm));
     if (!warm) bnorm_cache[which] = ko.bnorm;
     last_resid = r;
     total_its += ko.its;
@@ -357,6 +435,7 @@ static int validate_cfg(pph_ctx* ctx, const pph_solver_cfg* cfg) {
   PPH_REQUIRE(ctx, cfg->max_it >= 0 && cfg->inner_max_it >= 0 && cfg->picard_max_it >= 0, "negative max_it");
   PPH_REQUIRE(ctx, cfg->rtol >= 0 && cfg->atol >= 0 && cfg->inner_rtol >= 0 && cfg->inner_atol >= 0, "negative tolerance");
   PPH_REQUIRE(ctx, cfg->inner_reduction >= 0 && cfg->inner_reduction < 1, "inner_reduction must be in [0,1)");
+  PPH_REQUIRE(ctx, cfg->inner_norm == 0 || cfg->inner_norm == 1, "inner_norm must be 0 (preconditioned) or 1 (unpreconditioned)");
   PPH_REQUIRE(ctx, cfg->inner_ksp_type == PPH_KSP_PREONLY || cfg->inner_ksp_type == PPH_KSP_CG,
               "inner ksp_type %d not supported (preonly, cg)", cfg->inner_ksp_type);
   if (!cfg->picard) {

@@ -138,7 +138,8 @@ class SlabSolver:
 
     def __init__(self, n_cells: int, world: int, rank: int, device: int, k1: float, k2: float, beta: float, mu: float,
                  inner_rtol: float = 1e-10, smooth: int = 2, kind: int = _ffi.CELL_HEX, group=None,
-                 inner_pc: int = _ffi.PC_MG, transport: str = "auto", inner_reduction: float = 0.0):
+                 inner_pc: int = _ffi.PC_MG, transport: str = "auto", inner_reduction: float = 0.0,
+                 inner_norm: int = 0):
         from .manufactured_solutions import exact_expressions_3d
         from .parameters import DPPParameters
         from . import fd
@@ -180,6 +181,7 @@ class SlabSolver:
         cfg.picard, cfg.picard_rtol, cfg.picard_atol, cfg.picard_max_it = 1, 1e-8, 1e-12, 100
         cfg.mg_smooth = smooth
         cfg.inner_reduction = inner_reduction
+        cfg.inner_norm = inner_norm
         self.cfg = cfg
         self.info = None
         self.monolithic = False  # True: also materialise the monolithic CSR (monolithic Krylov solves)

@@ -33,8 +33,9 @@ def test_struct_layouts_match_header():
     from perphil_amd import _ffi
 
     # pph_solver_cfg: 4 int32, 2 double, 4 int32, 4 double, 2 int32, 1 double ; pph_solve_info: 4 int32, 2 double
-    assert ctypes.sizeof(_ffi.SolverCfg) == 4 * 4 + 2 * 8 + 4 * 4 + 4 * 8 + 2 * 4 + 8
+    assert ctypes.sizeof(_ffi.SolverCfg) == 4 * 4 + 2 * 8 + 4 * 4 + 4 * 8 + 2 * 4 + 8 + 2 * 4
     assert _ffi.SolverCfg.inner_reduction.offset == 88
+    assert _ffi.SolverCfg.inner_norm.offset == 96
     assert ctypes.sizeof(_ffi.SolveInfo) == 4 * 4 + 2 * 8
     assert _ffi.SolverCfg.rtol.offset == 16 and _ffi.SolverCfg.inner_rtol.offset == 48
     assert _ffi.SolverCfg.picard_max_it.offset == 80

@@ -88,12 +88,22 @@ def test_vcycle_and_mg_pcg_match_mg_oracle(dim, kind, nx, ny, nz):
         resj = o.pcg(A, r, o.jacobi_apply(A), rtol=1e-8)
         xj, itsj, _ = S.pcg(which, cpu.PC_JACOBI, r, rtol=1e-8)
         assert itsj == resj.its
+        # unpreconditioned-norm test (KSP_NORM_UNPRECONDITIONED), cold and warm-started with a reduction target
+        resu = o.pcg(A, r, lambda v: mgo.vcycle(L, v, 1), rtol=1e-9, norm="unpreconditioned")
+        xu, itsu, rnu = S.pcg(which, cpu.PC_MG, r, rtol=1e-9, smooth=1, norm=1)
+        assert itsu == resu.its and rnu == pytest.approx(resu.resnorm, rel=1e-6)
+        x0 = 0.9 * resu.x
+        resw = o.pcg(A, r, lambda v: mgo.vcycle(L, v, 1), rtol=1e-12, x0=x0, reduction=0.1, norm="unpreconditioned")
+        xw, itsw, _ = S.pcg(which, cpu.PC_MG, r, x0=x0, rtol=1e-12, reduction=0.1, smooth=1, norm=1)
+        assert itsw == resw.its
+        np.testing.assert_allclose(xw, resw.x, rtol=0, atol=1e-9 * np.abs(resw.x).max())
 
 
-def test_picard_matches_direct_solution_3d():
+@pytest.mark.parametrize("norm,red", [(0, 1e-2), (1, 1e-1)])
+def test_picard_matches_direct_solution_3d(norm, red):
     om, S, b = _system(3, o.CELL_HEX, 8, 8, 8)
     S.mg_setup()
-    x, sweeps, inner, res = S.picard()          # the bench's settings: V(1,1), reduction 1e-2
+    x, sweeps, inner, res = S.picard(inner_norm=norm, reduction=red)   # (1, 0.1): the bench's settings, V(1,1)
     assert 0 < sweeps <= 12
     osys = o.build_system(om, P)
     ud = o.solve_direct(osys)

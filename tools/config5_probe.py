@@ -18,7 +18,8 @@ for name, picard, mono in (("picard", 1, False), ("gmres_fieldsplit", 0, True)):
     cfg.ksp_type, cfg.pc_type, cfg.restart, cfg.max_it, cfg.rtol, cfg.atol = _ffi.KSP_GMRES, _ffi.PC_FIELDSPLIT, 30, 200, 1e-8, 1e-12
     cfg.inner_ksp_type, cfg.inner_pc_type, cfg.inner_max_it, cfg.inner_rtol, cfg.inner_atol = _ffi.KSP_CG, _ffi.PC_MG, 500, 1e-10, 1e-300
     cfg.picard, cfg.picard_rtol, cfg.picard_atol, cfg.picard_max_it, cfg.mg_smooth = picard, 1e-8, 1e-12, 100, 1
-    cfg.inner_reduction = 1e-2 if picard else 0.0
+    cfg.inner_reduction = 1e-1 if picard else 0.0
+    cfg.inner_norm = 1 if picard else 0
     for rep in range(2):
         ctx.set_option("invalidate_KM", 1)
         t0 = time.perf_counter()
