@@ -460,9 +460,19 @@ __global__ __launch_bounds__(256) void k_elem_rows(const int32_t* __restrict__ c
   constexpr int CPB = 256 / NB;
   __shared__ double sN[NB][NB];
   __shared__ double sdN[NB][NB][DIM];
-  __shared__ double sX[CPB][NB][DIM];
-  __shared__ double sG[CPB][NB][NB][DIM];  // [cell][q][b][d] physical gradients
-  __shared__ double sW[CPB][NB];           // [cell][q] |det J| (Gauss weights are 1)
+  // per-cell strides are padded off the bank period: the 8 cells of a wavefront read the same (q, b, d)
+  // of DIFFERENT cells in the contraction, and an unpadded stride (192 doubles = a multiple of all 64 banks)
+  // serialises those reads 8-fold
+  constexpr int SXC = NB * DIM + 1;        // sX cell stride
+  constexpr int SGQ = NB * DIM + 1;        // sG Gauss-point stride
+  constexpr int SGC = NB * SGQ + 2;        // sG cell stride
+  constexpr int SWC = NB + 1;              // sW cell stride
+  __shared__ double sXf[CPB * SXC];
+  __shared__ double sGf[CPB * SGC];        // [cell][q][b][d] physical gradients
+  __shared__ double sWf[CPB * SWC];        // [cell][q] |det J| (Gauss weights are 1)
+#define sX(c_, b_, d_) sXf[(c_) * SXC + (b_) * DIM + (d_)]
+#define sG(c_, q_, b_, d_) sGf[(c_) * SGC + (q_) * SGQ + (b_) * DIM + (d_)]
+#define sW(c_, q_) sWf[(c_) * SWC + (q_)]
   const int tid = threadIdx.x;
   const int lc = tid / NB, a = tid % NB;
   if (tid < NB * NB) {
@@ -493,9 +503,9 @@ __global__ __launch_bounds__(256) void k_elem_rows(const int32_t* __restrict__ c
     const bool valid = cell < ncell;
     if (valid) {
       const int32_t node = cells[cell * NB + a];
-      sX[lc][a][0] = cx[node];
-      sX[lc][a][1] = cy[node];
-      if constexpr (DIM == 3) sX[lc][a][2] = cz[node];
+      sX(lc, a, 0) = cx[node];
+      sX(lc, a, 1) = cy[node];
+      if constexpr (DIM == 3) sX(lc, a, 2) = cz[node];
     }
     __syncthreads();
     if (valid) {
@@ -510,7 +520,7 @@ __global__ __launch_bounds__(256) void k_elem_rows(const int32_t* __restrict__ c
 #pragma unroll
         for (int e = 0; e < DIM; ++e)
 #pragma unroll
-          for (int d = 0; d < DIM; ++d) J[e][d] += sdN[q][b][e] * sX[lc][b][d];
+          for (int d = 0; d < DIM; ++d) J[e][d] += sdN[q][b][e] * sX(lc, b, d);
       double det, I[DIM][DIM];
       if constexpr (DIM == 2) {
         det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
@@ -533,7 +543,7 @@ __global__ __launch_bounds__(256) void k_elem_rows(const int32_t* __restrict__ c
         I[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
         I[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
       }
-      sW[lc][q] = fabs(det);
+      sW(lc, q) = fabs(det);
 #pragma unroll
       for (int b = 0; b < NB; ++b)
 #pragma unroll
@@ -541,7 +551,7 @@ __global__ __launch_bounds__(256) void k_elem_rows(const int32_t* __restrict__ c
           double g = 0.0;
 #pragma unroll
           for (int e = 0; e < DIM; ++e) g += I[d][e] * sdN[q][b][e];
-          sG[lc][q][b][d] = g;
+          sG(lc, q, b, d) = g;
         }
     }
     __syncthreads();
@@ -551,16 +561,16 @@ __global__ __launch_bounds__(256) void k_elem_rows(const int32_t* __restrict__ c
       for (int b = 0; b < NB; ++b) { Kr[b] = 0.0; Mr[b] = 0.0; }
 #pragma unroll 2
       for (int q = 0; q < NB; ++q) {
-        const double w = sW[lc][q];
+        const double w = sW(lc, q);
         double ga[DIM];
 #pragma unroll
-        for (int d = 0; d < DIM; ++d) ga[d] = w * sG[lc][q][a][d];
+        for (int d = 0; d < DIM; ++d) ga[d] = w * sG(lc, q, a, d);
         const double na = w * sN[q][a];
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
           double dotg = 0.0;
 #pragma unroll
-          for (int d = 0; d < DIM; ++d) dotg += ga[d] * sG[lc][q][b][d];
+          for (int d = 0; d < DIM; ++d) dotg += ga[d] * sG(lc, q, b, d);
           Kr[b] += dotg;
           Mr[b] += na * sN[q][b];
         }
@@ -574,6 +584,9 @@ __global__ __launch_bounds__(256) void k_elem_rows(const int32_t* __restrict__ c
     }
   }
 }
+#undef sX
+#undef sG
+#undef sW
 
 template <int DIM>
 __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__ cells,
@@ -925,6 +938,7 @@ __global__ __launch_bounds__(256) void k_blocks(const int64_t* __restrict__ rowp
                                                 double* __restrict__ A22, double* __restrict__ A12,
                                                 double* __restrict__ A21) {
   const int sub = threadIdx.x % BC_LANES;
+  const bool same = (A21 == nullptr);   // both fields carry the same Dirichlet set: one mask gather per entry
   for (int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / BC_LANES; row < n;
        row += ((int64_t)gridDim.x * blockDim.x) / BC_LANES) {
     const uint8_t r1 = m1[row], r2 = m2[row];
@@ -944,7 +958,7 @@ __global__ __launch_bounds__(256) void k_blocks(const int64_t* __restrict__ rowp
         const int32_t j = in[t] ? jj[t] : 0;
         const double kk = kk4[t], mm = mm4[t];
         const bool diag = (j == (int32_t)row);
-        const bool c1 = (m1[j] & 1) != 0, c2 = (m2[j] & 1) != 0;
+        const bool c1 = (m1[j] & 1) != 0, c2 = same ? c1 : (m2[j] & 1) != 0;
         // ghost rows (bit 1) belong to the neighbouring slab: empty here; Dirichlet rows: identity
         o11[t] = (r1 & 2) ? 0.0 : (r1 & 1) ? (diag ? 1.0 : 0.0) : (c1 ? 0.0 : a * kk + b * mm);
         o22[t] = (r2 & 2) ? 0.0 : (r2 & 1) ? (diag ? 1.0 : 0.0) : (c2 ? 0.0 : c * kk + b * mm);

@@ -147,22 +147,40 @@ __global__ __launch_bounds__(256) void k_prolong_add(double* __restrict__ xf, co
   }
 }
 
-// max over rows of sum_j |a_ij| / a_ii (8 lanes per row), accumulated with an integer atomic max on the
-// bit pattern of the non-negative double
-__global__ __launch_bounds__(256) void k_lam_bound(const int64_t* __restrict__ rowptr, const double* __restrict__ val,
-                                                   const double* __restrict__ dinv, int64_t n,
-                                                   unsigned long long* __restrict__ out) {
+// one pass over an operator for the smoother's two ingredients: dinv_i = 1 / a_ii (1 for an empty diagonal) and the
+// bound max_i sum_j |a_ij| / |a_ii| of the spectrum of D^-1 A (integer atomic max on the bit pattern of the
+// non-negative double).  8 lanes per row, 16-byte aligned loads from the row
+// start rounded down to a multiple of 4 (the layout of the SpMV kernel; buffers carry slack for the over-read).
+__global__ __launch_bounds__(256) void k_diag_lam(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                  const double* __restrict__ val, int64_t n, double* __restrict__ dinv,
+                                                  unsigned long long* __restrict__ out) {
   const int sub = threadIdx.x & 7;
   double best = 0.0;
   for (int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 3; row < n;
        row += ((int64_t)gridDim.x * blockDim.x) >> 3) {
-    double s = 0.0;
-    for (int64_t k = rowptr[row] + sub; k < rowptr[row + 1]; k += 8) s += fabs(val[k]);
-    s += __shfl_down(s, 4, 8);
-    s += __shfl_down(s, 2, 8);
-    s += __shfl_down(s, 1, 8);
-    s *= fabs(dinv[row]);
-    best = (sub == 0 && s > best) ? s : best;
+    const int64_t s0 = rowptr[row], e0 = rowptr[row + 1];
+    double s = 0.0, d = 0.0;
+    for (int64_t base = (s0 & ~(int64_t)3) + 4 * sub; base < e0; base += 32) {
+      const int4 c = *reinterpret_cast<const int4*>(col + base);
+      const double2 v01 = *reinterpret_cast<const double2*>(val + base), v23 = *reinterpret_cast<const double2*>(val + base + 2);
+      const int32_t cj[4] = {c.x, c.y, c.z, c.w};
+      const double vv[4] = {v01.x, v01.y, v23.x, v23.y};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const bool in = base + t >= s0 && base + t < e0;
+        s += in ? fabs(vv[t]) : 0.0;
+        d += (in && (int64_t)cj[t] == row) ? vv[t] : 0.0;
+      }
+    }
+    s += __shfl_down(s, 4, 8); d += __shfl_down(d, 4, 8);
+    s += __shfl_down(s, 2, 8); d += __shfl_down(d, 2, 8);
+    s += __shfl_down(s, 1, 8); d += __shfl_down(d, 1, 8);
+    if (sub == 0) {
+      const double di = (d != 0.0) ? 1.0 / d : 1.0;
+      dinv[row] = di;
+      s *= fabs(di);
+      best = s > best ? s : best;
+    }
   }
   for (int o = 32; o > 0; o >>= 1) {
     const double t = __shfl_down(best, o, 64);
@@ -346,7 +364,6 @@ int mg_setup(pph_ctx* ctx) {
     }
     for (int f = 0; f < 2; ++f) {
       PPH_TRY(L.dinv[f].alloc(ctx, (size_t)L.n));
-      la_extract_diag_inv(ctx, level_csr(ctx, L, f), L.dinv[f].p);
       if (ctx->mg_fp32) {
         PPH_TRY(L.val32[f].alloc(ctx, (size_t)L.nnz));
         hipLaunchKernelGGL(k_to_float, dim3(mg_grid(L.nnz)), dim3(256), 0, ctx->stream, L.val32[f].p, L.val[f], L.nnz);
@@ -354,8 +371,8 @@ int mg_setup(pph_ctx* ctx) {
     }
     PPH_HIP(ctx, hipMemsetAsync(lamdev.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
     for (int f = 0; f < 2; ++f)
-      hipLaunchKernelGGL(k_lam_bound, dim3(mg_grid(L.n * 8)), dim3(256), 0, ctx->stream, L.rowptr, L.val[f], L.dinv[f].p,
-                         L.n, lamdev.p + f);
+      hipLaunchKernelGGL(k_diag_lam, dim3(mg_grid(L.n * 8)), dim3(256), 0, ctx->stream, L.rowptr, L.col, L.val[f], L.n,
+                         L.dinv[f].p, lamdev.p + f);
     unsigned long long bits[2];
     PPH_HIP(ctx, hipMemcpyAsync(bits, lamdev.p, sizeof(bits), hipMemcpyDeviceToHost, ctx->stream));
     PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
