@@ -168,6 +168,7 @@ struct pph_ctx {
   size_t ev_used = 0;                   // pairs recorded since the last harvest
   int spmv_lanes_override = 0;          // 0: pick from the mean row length
   int spmv_blocks = 0;                  // 0: default persistent grid (1024 workgroups)
+  int coarse_on_device = 1;             // coarsest multigrid level (<= 4096 rows): CG inside one workgroup, no host round trips
   int spmv_bench_mode = 0;              // pph_spmv_bench protocol: 0 back-to-back, 1-3 interleaved (see pph_api.hip)
   int64_t mg_replicate_below = 40000;   // slabs: multigrid levels with at most this many global nodes are replicated
   int mg_fp32 = 0;                      // 1: V-cycle SpMVs read fp32 copies of the operator values (8 instead of 12 B per non-zero)

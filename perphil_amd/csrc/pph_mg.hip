@@ -424,6 +424,66 @@ static void chebyshev(pph_ctx* ctx, MgLevel& L, int which, const double* b, doub
   }
 }
 
+// Coarsest-level solve without the host: one workgroup runs the whole Jacobi-preconditioned CG (same recurrence,
+// same test on ||D^-1 r|| <= rtol ||D^-1 b||, at most max_it iterations as pph_cg_jacobi) on a system of a few
+// thousand rows at most.  The host-driven CG costs two stream synchronisations per iteration, which is what a
+// V-cycle on a small or distributed problem mostly waits for.  Block reductions are fixed-order (deterministic).
+__device__ __forceinline__ double coarse_block_sum(double v, double* lds) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  __syncthreads();                       // lds reuse across calls
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += lds[w];
+  return t;
+}
+
+__global__ __launch_bounds__(1024) void k_coarse_cg(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                    const double* __restrict__ val, const double* __restrict__ dinv,
+                                                    const double* __restrict__ b, double* __restrict__ x,
+                                                    double* __restrict__ r, double* __restrict__ p, double* __restrict__ q,
+                                                    int n, double rtol, int max_it) {
+  __shared__ double lds[16];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  double zz = 0.0, rz = 0.0;
+  for (int i = tid; i < n; i += nt) {
+    const double ri = b[i], zi = dinv[i] * ri;
+    x[i] = 0.0; r[i] = ri; p[i] = zi;
+    zz += zi * zi; rz += ri * zi;
+  }
+  zz = coarse_block_sum(zz, lds);
+  rz = coarse_block_sum(rz, lds);
+  const double tol = rtol * sqrt(zz);
+  if (!(sqrt(zz) > tol)) return;         // zero (or NaN) right-hand side: x = 0
+  for (int it = 0; it < max_it; ++it) {
+    __syncthreads();                     // p complete
+    double pq = 0.0;
+    for (int i = tid; i < n; i += nt) {
+      double s = 0.0;
+      for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) s += val[k] * p[col[k]];
+      q[i] = s;
+      pq += p[i] * s;
+    }
+    pq = coarse_block_sum(pq, lds);
+    if (!(pq > 0.0)) return;
+    const double alpha = rz / pq;
+    double zz2 = 0.0, rz2 = 0.0;
+    for (int i = tid; i < n; i += nt) {
+      x[i] += alpha * p[i];
+      const double ri = r[i] - alpha * q[i], zi = dinv[i] * ri;
+      r[i] = ri;
+      zz2 += zi * zi; rz2 += ri * zi;
+    }
+    zz2 = coarse_block_sum(zz2, lds);
+    rz2 = coarse_block_sum(rz2, lds);
+    if (sqrt(zz2) <= tol) return;
+    const double beta = rz2 / rz;
+    __syncthreads();                     // every thread has read p[col] of this iteration's product
+    for (int i = tid; i < n; i += nt) p[i] = dinv[i] * r[i] + beta * p[i];
+    rz = rz2;
+  }
+}
+
 void mg_vcycle(pph_ctx* ctx, int which, const double* rin, double* zout, int nsmooth) {
   std::vector<MgLevel>& mg = ctx->mg;
   const int nlev = (int)mg.size();
@@ -453,8 +513,12 @@ void mg_vcycle(pph_ctx* ctx, int which, const double* rin, double* zout, int nsm
     MgLevel& C = mg[nlev - 1];
     int its = 0;
     ctx->comm_suspended = C.replicated;
-    pph_cg_jacobi(ctx, level_csr(ctx, C, which), C.b.p, C.x.p, C.dinv[which].p, 1e-12, 0.0, 500, C.r.p, C.d.p, C.t.p,
-                  C.w.p, &its);
+    if ((!dist || C.replicated) && C.n <= 4096 && ctx->coarse_on_device)
+      hipLaunchKernelGGL(k_coarse_cg, dim3(1), dim3(C.n <= 256 ? 256 : 1024), 0, ctx->stream, C.rowptr, C.col, C.val[which],
+                         C.dinv[which].p, C.b.p, C.x.p, C.r.p, C.d.p, C.t.p, (int)C.n, 1e-12, 500);
+    else
+      pph_cg_jacobi(ctx, level_csr(ctx, C, which), C.b.p, C.x.p, C.dinv[which].p, 1e-12, 0.0, 500, C.r.p, C.d.p, C.t.p,
+                    C.w.p, &its);
   }
   // upward leg
   for (int l = nlev - 2; l >= 0; --l) {
