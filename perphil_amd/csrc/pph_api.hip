@@ -114,6 +114,7 @@ int pph_ctx_destroy(pph_ctx* ctx) {
   free_system(ctx);
   ctx->mesh.release_all();
   for (int f = 0; f < 2; ++f) { ctx->bcmask[f].release(); ctx->g[f].release(); }
+  ctx->rownear.release();
   comm_release(ctx);
   for (auto& w : ctx->work) w.release();
   for (auto& p : ctx->ev_pool) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
@@ -174,6 +175,7 @@ int pph_mesh_build(pph_ctx* ctx, int dim, int cell_kind, int nx, int ny, int nz,
     PPH_TRY(ctx->bcmask[f].alloc(ctx, (size_t)m.n));
     PPH_TRY(ctx->g[f].alloc(ctx, (size_t)m.n));
     PPH_HIP(ctx, hipMemsetAsync(ctx->bcmask[f].p, 0, (size_t)m.n, ctx->stream));
+    ctx->bc_dirty = true;
     PPH_HIP(ctx, hipMemsetAsync(ctx->g[f].p, 0, sizeof(double) * (size_t)m.n, ctx->stream));
     const int64_t plane = (int64_t)m.px * m.py;
     if (ctx->ghost_lo)
@@ -248,6 +250,7 @@ int pph_set_dirichlet(pph_ctx* ctx, int field, const int64_t* nodes, const doubl
     hg[(size_t)nodes[i]] = vals[i];
   }
   PPH_HIP(ctx, hipMemcpyAsync(ctx->bcmask[field].p, hmask.data(), (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  ctx->bc_dirty = true;
   PPH_HIP(ctx, hipMemcpyAsync(ctx->g[field].p, hg.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice,
                               ctx->stream));
   PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -896,15 +896,41 @@ int pph_launch_assemble_KM(pph_ctx* ctx_, MeshData& mesh) {
 // ------------------------------------------------------------------------------------------------
 #define BC_LANES 8
 
+// rownear[row] = 1 when the row is constrained / ghost in either field or one of its columns is constrained:
+// only those rows need the masks in k_blocks and have a non-zero lifting term.  Depends on the pattern and the
+// Dirichlet sets only, so it is rebuilt when they change, not per assembly.
+__global__ __launch_bounds__(256) void k_row_near(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                  const uint8_t* __restrict__ m1, const uint8_t* __restrict__ m2, int64_t n,
+                                                  uint8_t* __restrict__ rownear) {
+  const int sub = threadIdx.x % 8;
+  for (int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / 8; row < n;
+       row += ((int64_t)gridDim.x * blockDim.x) / 8) {
+    int f = (m1[row] | m2[row]) != 0;
+    for (int64_t k = rowptr[row] + sub; k < rowptr[row + 1]; k += 8) {
+      const int32_t j = col[k];
+      f |= ((m1[j] | m2[j]) & 1) != 0;
+    }
+    f |= __shfl_down(f, 4, 8);
+    f |= __shfl_down(f, 2, 8);
+    f |= __shfl_down(f, 1, 8);
+    if (sub == 0) rownear[row] = (uint8_t)f;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_lift_rhs(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                   const double* __restrict__ K, const double* __restrict__ M,
                                                   const uint8_t* __restrict__ m1, const uint8_t* __restrict__ m2,
                                                   const double* __restrict__ g1, const double* __restrict__ g2,
                                                   double a, double b, double c, int64_t n,
+                                                  const uint8_t* __restrict__ rownear,
                                                   double* __restrict__ rhs, double* __restrict__ u0) {
   const int sub = threadIdx.x % BC_LANES;
   for (int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / BC_LANES; row < n;
        row += ((int64_t)gridDim.x * blockDim.x) / BC_LANES) {
+    if (!rownear[row]) {   // no constrained column: u0 vanishes on the whole row, nothing to lift
+      if (sub == 0) { rhs[row] = 0.0; rhs[n + row] = 0.0; u0[row] = 0.0; u0[n + row] = 0.0; }
+      continue;
+    }
     double sK1 = 0, sK2 = 0, sM = 0;
     for (int64_t k = rowptr[row] + sub; k < rowptr[row + 1]; k += BC_LANES) {
       const int32_t j = col[k];
@@ -934,15 +960,47 @@ __global__ __launch_bounds__(256) void k_lift_rhs(const int64_t* __restrict__ ro
 __global__ __launch_bounds__(256) void k_blocks(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                 const double* __restrict__ K, const double* __restrict__ M,
                                                 const uint8_t* __restrict__ m1, const uint8_t* __restrict__ m2,
-                                                double a, double b, double c, int64_t n, double* __restrict__ A11,
+                                                double a, double b, double c, int64_t n,
+                                                const uint8_t* __restrict__ rownear, double* __restrict__ A11,
                                                 double* __restrict__ A22, double* __restrict__ A12,
                                                 double* __restrict__ A21) {
   const int sub = threadIdx.x % BC_LANES;
   const bool same = (A21 == nullptr);   // both fields carry the same Dirichlet set: one mask gather per entry
   for (int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / BC_LANES; row < n;
        row += ((int64_t)gridDim.x * blockDim.x) / BC_LANES) {
-    const uint8_t r1 = m1[row], r2 = m2[row];
     const int64_t s = rowptr[row], e = rowptr[row + 1];
+    if (!rownear[row]) {
+      // interior row without a constrained column (almost all rows): pure streaming, no column or mask reads
+      for (int64_t base = (s & ~(int64_t)3) + 4 * sub; base < e; base += 4 * BC_LANES) {
+        const double2 k01 = *reinterpret_cast<const double2*>(K + base), k23 = *reinterpret_cast<const double2*>(K + base + 2);
+        const double2 q01 = *reinterpret_cast<const double2*>(M + base), q23 = *reinterpret_cast<const double2*>(M + base + 2);
+        const double kk4[4] = {k01.x, k01.y, k23.x, k23.y};
+        const double mm4[4] = {q01.x, q01.y, q23.x, q23.y};
+        if (base >= s && base + 3 < e) {
+          *reinterpret_cast<double2*>(A11 + base) = make_double2(a * kk4[0] + b * mm4[0], a * kk4[1] + b * mm4[1]);
+          *reinterpret_cast<double2*>(A11 + base + 2) = make_double2(a * kk4[2] + b * mm4[2], a * kk4[3] + b * mm4[3]);
+          *reinterpret_cast<double2*>(A22 + base) = make_double2(c * kk4[0] + b * mm4[0], c * kk4[1] + b * mm4[1]);
+          *reinterpret_cast<double2*>(A22 + base + 2) = make_double2(c * kk4[2] + b * mm4[2], c * kk4[3] + b * mm4[3]);
+          *reinterpret_cast<double2*>(A12 + base) = make_double2(-b * mm4[0], -b * mm4[1]);
+          *reinterpret_cast<double2*>(A12 + base + 2) = make_double2(-b * mm4[2], -b * mm4[3]);
+          if (A21) {
+            *reinterpret_cast<double2*>(A21 + base) = make_double2(-b * mm4[0], -b * mm4[1]);
+            *reinterpret_cast<double2*>(A21 + base + 2) = make_double2(-b * mm4[2], -b * mm4[3]);
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+            if (base + t >= s && base + t < e) {
+              A11[base + t] = a * kk4[t] + b * mm4[t];
+              A22[base + t] = c * kk4[t] + b * mm4[t];
+              A12[base + t] = -b * mm4[t];
+              if (A21) A21[base + t] = -b * mm4[t];
+            }
+        }
+      }
+      continue;
+    }
+    const uint8_t r1 = m1[row], r2 = m2[row];
     for (int64_t base = (s & ~(int64_t)3) + 4 * sub; base < e; base += 4 * BC_LANES) {
       const int4 cj = *reinterpret_cast<const int4*>(col + base);
       const double2 k01 = *reinterpret_cast<const double2*>(K + base), k23 = *reinterpret_cast<const double2*>(K + base + 2);
@@ -1035,7 +1093,7 @@ int pph_launch_blocks(pph_ctx* ctx, int monolithic) {
   PPH_TRY(ctx->A22.alloc(ctx, (size_t)nnzb));
   PPH_TRY(ctx->A12.alloc(ctx, (size_t)nnzb));
   // same Dirichlet set on both fields (every reference configuration): A21 == A12, stored once
-  {
+  if (ctx->bc_dirty) {
     int* flag = reinterpret_cast<int*>(ctx->scal.p + (PPH_MAX_SCAL - 200));
     int h = 0;
     PPH_HIP(ctx, hipMemsetAsync(flag, 0, sizeof(int), ctx->stream));
@@ -1043,6 +1101,11 @@ int pph_launch_blocks(pph_ctx* ctx, int monolithic) {
     PPH_HIP(ctx, hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->a21_alias = (h == 0);
+    PPH_TRY(ctx->rownear.alloc(ctx, (size_t)n));
+    int64_t nbn = ceil_div64(n * 8, 256);
+    hipLaunchKernelGGL(k_row_near, dim3((int)(nbn < 4096 ? nbn : 4096)), dim3(256), 0, ctx->stream, ctx->mesh.rowptr.p,
+                       ctx->mesh.col.p, ctx->bcmask[0].p, ctx->bcmask[1].p, n, ctx->rownear.p);
+    ctx->bc_dirty = false;
   }
   if (ctx->a21_alias) ctx->A21.release();
   else PPH_TRY(ctx->A21.alloc(ctx, (size_t)nnzb));
@@ -1053,9 +1116,9 @@ int pph_launch_blocks(pph_ctx* ctx, int monolithic) {
   int grid = (int)(nb < 256 * 16 ? nb : 256 * 16);
   hipLaunchKernelGGL(k_lift_rhs, dim3(grid), dim3(256), 0, ctx->stream, ctx->mesh.rowptr.p, ctx->mesh.col.p, ctx->mesh.K.p,
                      ctx->mesh.M.p, ctx->bcmask[0].p, ctx->bcmask[1].p, ctx->g[0].p, ctx->g[1].p, ctx->a, ctx->b, ctx->c,
-                     n, ctx->rhs.p, ctx->u0.p);
+                     n, ctx->rownear.p, ctx->rhs.p, ctx->u0.p);
   hipLaunchKernelGGL(k_blocks, dim3(grid), dim3(256), 0, ctx->stream, ctx->mesh.rowptr.p, ctx->mesh.col.p, ctx->mesh.K.p, ctx->mesh.M.p,
-                     ctx->bcmask[0].p, ctx->bcmask[1].p, ctx->a, ctx->b, ctx->c, n, ctx->A11.p, ctx->A22.p,
+                     ctx->bcmask[0].p, ctx->bcmask[1].p, ctx->a, ctx->b, ctx->c, n, ctx->rownear.p, ctx->A11.p, ctx->A22.p,
                      ctx->A12.p, ctx->a21_alias ? nullptr : ctx->A21.p);
   PPH_HIP(ctx, hipGetLastError());
   ctx->mono_ok = false;

@@ -123,6 +123,8 @@ struct pph_ctx {
   int64_t n = 0, nnzb = 0;              // copies of mesh.n / mesh.nnzb
   bool mesh_ok = false, asm_ok = false, mono_ok = false;
   DevBuf<uint8_t> bcmask[2];            // per field: 1 Dirichlet, 2 ghost, 0 free
+  DevBuf<uint8_t> rownear;              // 1: the row is constrained / ghost or has a constrained column (needs the masks)
+  bool bc_dirty = true;                 // masks changed since rownear / a21_alias were derived from them
   DevBuf<double> g[2];                  // per field Dirichlet values (dense, 0 elsewhere)
   DevBuf<double> A11, A22, A12, A21;    // eliminated blocks on the scalar pattern
   bool a21_alias = false;               // both fields share one Dirichlet set: A21 == A12, A21 not stored
