@@ -987,6 +987,21 @@ void la_scale(pph_ctx* ctx, double* y, double alpha, int64_t n) {
 void la_pointwise_mult(pph_ctx* ctx, double* z, const double* d, const double* r, int64_t n) {
   hipLaunchKernelGGL(k_pmult, dim3(ew_grid(n)), dim3(256), 0, ctx->stream, z, d, r, n);
 }
+// R += sign * (tnew - told) ; told = tnew   (residual bookkeeping of the Picard sweeps: one pass instead of
+// two axpys and a copy)
+__global__ void k_shift(double* __restrict__ R, double* __restrict__ told, const double* __restrict__ tnew, double sign,
+                        int64_t n) {
+  EW_LOOP(i, n) {
+    const double tn = tnew[i];
+    R[i] += sign * (tn - told[i]);
+    told[i] = tn;
+  }
+}
+
+void la_shift(pph_ctx* ctx, double* R, double* told, const double* tnew, double sign, int64_t n) {
+  hipLaunchKernelGGL(k_shift, dim3(ew_grid(n)), dim3(256), 0, ctx->stream, R, told, tnew, sign, n);
+}
+
 void la_sub(pph_ctx* ctx, double* z, const double* a, const double* b, int64_t n) {
   hipLaunchKernelGGL(k_sub, dim3(ew_grid(n)), dim3(256), 0, ctx->stream, z, a, b, n);
 }

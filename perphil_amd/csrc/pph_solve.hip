@@ -90,7 +90,7 @@ static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double*
       PPH_TRY(la_fetch(ctx, slot, 1));
       bnorm = std::sqrt(ctx->h_scal[slot]);
     }
-    if (r_init) la_copy(ctx, r, r_init, n);
+    if (r_init) { if (r_init != r) la_copy(ctx, r, r_init, n); }
     else la_spmv_resid(ctx, A, x, b, r);
   } else {
     la_set(ctx, x, 0.0, n);
@@ -173,7 +173,7 @@ static int cg_solve(pph_ctx* ctx, const Csr& A, const double* b, double* x, cons
       bnorm = std::sqrt(ctx->h_scal[slot]);
     }
     // r_init: the caller already knows b - A x (residual bookkeeping of the Picard sweeps)
-    if (r_init) la_copy(ctx, r, r_init, n);
+    if (r_init) { if (r_init != r) la_copy(ctx, r, r_init, n); }
     else la_spmv_resid(ctx, A, x, b, r);
   } else {
     la_set(ctx, x, 0.0, n);
@@ -388,10 +388,13 @@ struct BlockSolver {
     return PPH_OK;
   }
 
-  int solve(int which, const double* rhs, double* z, bool warm, const double* r_init = nullptr) {
+  // r_io (optional): vector the CG uses as its residual - on entry b - A z when warm and r_known, on return the
+  // recurrence residual of the solve (the Picard loop keeps its block residuals there: no copies in or out)
+  int solve(int which, const double* rhs, double* z, bool warm, const double* r_init = nullptr, double* r_io = nullptr) {
     const int64_t n = ctx->n;
     double *r, *zz, *p, *q;
     PPH_TRY(work(ctx, W_IR, (size_t)n, &r));
+    if (r_io) r = r_io;
     PPH_TRY(work(ctx, W_IZ, (size_t)n, &zz));
     PPH_TRY(work(ctx, W_IP, (size_t)n, &p));
     PPH_TRY(work(ctx, W_IQ, (size_t)n, &q));
@@ -499,12 +502,12 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
     la_set(ctx, t12, 0.0, n);
     const bool recur = (cfg->inner_ksp_type == PPH_KSP_CG);
     const int64_t pob = ctx->mesh.own_begin(), pon = ctx->mesh.own_end() - ctx->mesh.own_begin();
+    // true residual from direct products only: t12 = A12 du2 and rhs1 = b2 - A21 du1 were formed by SpMVs with
+    // the current iterates in this sweep, so two more products (A11 du1, A22 du2) complete it
     auto true_residual = [&]() -> int {
-      la_spmv_resid(ctx, bs.A[0], du1, b1, R0);
-      la_axpy(ctx, R0, -1.0, t12, n);
-      la_spmv_resid(ctx, A21, du1, b2, R1);
-      la_spmv(ctx, bs.A[1], du2, t);
-      la_axpy(ctx, R1, -1.0, t, n);
+      la_sub(ctx, pb, b1, t12, n);
+      la_spmv_resid(ctx, bs.A[0], du1, pb, R0);
+      la_spmv_resid(ctx, bs.A[1], du2, rhs1, R1);
       la_dot(ctx, R0 + pob, R0 + pob, pon, S_A);
       la_dot(ctx, R1 + pob, R1 + pob, pon, S_A + 1);
       PPH_TRY(la_fetch(ctx, S_A, 2));
@@ -514,24 +517,18 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
     while (res > tol && its < cfg->picard_max_it) {
       const bool warm = its > 0;
       la_sub(ctx, pb, b1, t12, n);                                   // rhs of the macro block
-      PPH_TRY(bs.solve(0, pb, du1, warm, (warm && recur) ? R0 : nullptr));
-      if (recur) la_copy(ctx, R0, bs.last_resid, n);
+      PPH_TRY(bs.solve(0, pb, du1, warm, (warm && recur) ? R0 : nullptr, recur ? R0 : nullptr));
       if (warm && recur) {
         la_spmv_resid(ctx, A21, du1, b2, tn);                        // new rhs of the micro block
-        la_axpy(ctx, R1, 1.0, tn, n);                                // R1 += rhs1_new - rhs1_old
-        la_axpy(ctx, R1, -1.0, rhs1, n);
-        la_copy(ctx, rhs1, tn, n);
+        la_shift(ctx, R1, rhs1, tn, 1.0, n);                         // R1 += rhs1_new - rhs1_old ; rhs1 = rhs1_new
       } else {
         la_spmv_resid(ctx, A21, du1, b2, rhs1);
       }
-      PPH_TRY(bs.solve(1, rhs1, du2, warm, (warm && recur) ? R1 : nullptr));
-      if (recur) la_copy(ctx, R1, bs.last_resid, n);
+      PPH_TRY(bs.solve(1, rhs1, du2, warm, (warm && recur) ? R1 : nullptr, recur ? R1 : nullptr));
       ++its;
       la_spmv(ctx, A12, du2, tn);                                    // new coupling term
       if (recur) {
-        la_axpy(ctx, R0, 1.0, t12, n);                               // R0 += A12 du2_old - A12 du2_new
-        la_axpy(ctx, R0, -1.0, tn, n);
-        la_copy(ctx, t12, tn, n);
+        la_shift(ctx, R0, t12, tn, -1.0, n);                         // R0 += A12 du2_old - A12 du2_new ; t12 = new
         la_dot(ctx, R0 + pob, R0 + pob, pon, S_A);
         la_dot(ctx, R1 + pob, R1 + pob, pon, S_A + 1);
         PPH_TRY(la_fetch(ctx, S_A, 2));
