@@ -115,6 +115,7 @@ int pph_ctx_destroy(pph_ctx* ctx) {
   ctx->mesh.release_all();
   for (int f = 0; f < 2; ++f) { ctx->bcmask[f].release(); ctx->g[f].release(); }
   ctx->rownear.release();
+  ctx->dinv0[0].release(); ctx->dinv0[1].release(); ctx->lam0.release();
   comm_release(ctx);
   for (auto& w : ctx->work) w.release();
   for (auto& p : ctx->ev_pool) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
@@ -266,6 +267,19 @@ int pph_assemble_dpp(pph_ctx* ctx, double k1, double k2, double beta, double mu,
   release_system(ctx);
   ctx->a = k1 / mu; ctx->b = beta / mu; ctx->c = k2 / mu;
   float ms = 0.f;
+  if (!ctx->mesh.km_valid && pph_can_fuse_assembly(ctx)) {
+    // integration needed anyway: element rows, then one node-centred pass straight to the eliminated blocks
+    PPH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    PPH_TRY(pph_launch_assemble_fused(ctx, monolithic));
+    PPH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    PPH_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    PPH_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->t_asm = ms;
+    ctx->t_bc = 0.0;
+    PPH_HIP(ctx, hipGetLastError());
+    ctx->asm_ok = true;
+    return PPH_OK;
+  }
   // K and M depend only on the mesh: integrate once per mesh
   if (!ctx->mesh.km_valid) {
     PPH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
@@ -301,8 +315,14 @@ static int select_csr(pph_ctx* ctx, int which, Csr* A) {
       A->lanes = pph_pick_lanes(ctx, A->nnz, A->nrows);
       A->max_row = 2 * m.max_row;
       return PPH_OK;
-    case 1: PPH_REQUIRE(ctx, m.K.p && m.km_valid, "K not assembled"); A->val = m.K.p; return PPH_OK;
-    case 2: PPH_REQUIRE(ctx, m.M.p && m.km_valid, "M not assembled"); A->val = m.M.p; return PPH_OK;
+    case 1:
+    case 2:
+      if (!m.km_valid) {   // not kept by the fused assembly (or never assembled): integrate now
+        PPH_TRY(pph_launch_assemble_KM(ctx, ctx->mesh));
+        ctx->mesh.km_valid = true;
+      }
+      A->val = (which == 1) ? m.K.p : m.M.p;
+      return PPH_OK;
     case 3: PPH_REQUIRE(ctx, ctx->asm_ok, "blocks not assembled"); A->val = ctx->A11.p; return PPH_OK;
     case 4: PPH_REQUIRE(ctx, ctx->asm_ok, "blocks not assembled"); A->val = ctx->A22.p; return PPH_OK;
     case 5: PPH_REQUIRE(ctx, ctx->asm_ok, "blocks not assembled"); A->val = ctx->A12.p; return PPH_OK;
@@ -460,6 +480,8 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
     return PPH_OK;
   }
   if (!strcmp(name, "spmv_blocks")) { ctx->spmv_blocks = (int)value; return PPH_OK; }
+  if (!strcmp(name, "asm_fused")) { ctx->asm_fused = value != 0.0 ? 1 : 0; return PPH_OK; }
+  if (!strcmp(name, "asm_keep_km")) { ctx->asm_keep_km = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "coarse_on_device")) { ctx->coarse_on_device = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "spmv_bench_mode")) { ctx->spmv_bench_mode = (int)value; return PPH_OK; }
   if (!strcmp(name, "time_spmv")) { ctx->time_spmv = value != 0.0; return PPH_OK; }

@@ -588,14 +588,30 @@ __global__ __launch_bounds__(256) void k_elem_rows(const int32_t* __restrict__ c
 #undef sG
 #undef sW
 
-template <int DIM>
+// Operands of the fused epilogue of k_gather_rows<DIM, true>: at the point where a CSR entry (K_ij, M_ij) of a
+// complete row is known, the Dirichlet-eliminated DPP blocks, the lifted right-hand side and the smoother's
+// diagonal / spectral bound of both diagonal blocks are formed from it directly, instead of writing K and M and
+// streaming them again through k_lift_rhs, k_blocks and k_diag_lam.
+struct FuseArgs {
+  const uint8_t *m1, *m2, *near;
+  const double *g1, *g2;
+  double a, b, c;
+  double *A11, *A22, *A12, *A21;   // A21 null: aliased to A12 (same Dirichlet set on both fields)
+  double *rhs, *u0;                // [2n]
+  double *dinv1, *dinv2;           // [n] each
+  unsigned long long* lam;         // [2] max_i sum_j |a_ij| / |a_ii| as the bit pattern of a non-negative double
+  int keep_km;                     // also store K and M
+};
+
+template <int DIM, bool FUSED = false>
 __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__ cells,
                                                      const double* __restrict__ erows,
                                                      const int64_t* __restrict__ rowptr,
                                                      const int32_t* __restrict__ col, double* __restrict__ K,
                                                      double* __restrict__ M, int nx, int ny, int nzl, int px, int py,
-                                                     int64_t n) {
+                                                     int64_t n, FuseArgs fa) {
   constexpr int NB = 1 << DIM;
+  double best1 = 0.0, best2 = 0.0;
   constexpr int NPB = 256 / NB;
   __shared__ double sK[NPB][NB][NB + 1];  // +1: rows of different incident cells land in different banks
   __shared__ double sM[NPB][NB][NB + 1];
@@ -639,6 +655,14 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__
       const int64_t s = rowptr[node], e = rowptr[node + 1];
       // closed-form matching needs an unambiguous decode of the column offset (>= 2 cells per direction)
       const bool closed = px >= 3 && py >= 3 && (DIM == 2 || nzl >= 2);
+      // fused epilogue state of this lane's share of the row
+      bool near = false;
+      uint8_t r1 = 0, r2 = 0;
+      double s11 = 0.0, s22 = 0.0, d11 = 0.0, d22 = 0.0, lK1 = 0.0, lK2 = 0.0, lM = 0.0;
+      if constexpr (FUSED) {
+        near = fa.near[node] != 0;
+        if (near) { r1 = fa.m1[node]; r2 = fa.m2[node]; }
+      }
       for (int64_t k = s + c; k < e; k += NB) {
         const int32_t j = col[k];
         double kv = 0.0, mv = 0.0;
@@ -679,9 +703,63 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__
               mv += hit ? sM[ln][cc][b] : 0.0;
             }
         }
-        K[k] = kv;
-        M[k] = mv;
+        if constexpr (!FUSED) {
+          K[k] = kv;
+          M[k] = mv;
+        } else {
+          if (fa.keep_km) { K[k] = kv; M[k] = mv; }
+          const bool diag = (j == (int32_t)node);
+          double o11 = fa.a * kv + fa.b * mv, o22 = fa.c * kv + fa.b * mv, o12 = -fa.b * mv, o21 = o12;
+          if (near) {
+            // same arithmetic as k_lift_rhs / k_blocks: ghost rows empty, Dirichlet rows identity, constrained columns zero
+            const bool c1 = (fa.m1[j] & 1) != 0, c2 = fa.A21 ? (fa.m2[j] & 1) != 0 : c1;
+            const double v1 = fa.g1[j], v2 = fa.g2[j];
+            lK1 += kv * v1; lK2 += kv * v2; lM += mv * (v1 - v2);
+            o11 = (r1 & 2) ? 0.0 : (r1 & 1) ? (diag ? 1.0 : 0.0) : (c1 ? 0.0 : o11);
+            o22 = (r2 & 2) ? 0.0 : (r2 & 1) ? (diag ? 1.0 : 0.0) : (c2 ? 0.0 : o22);
+            o12 = (r1 != 0 || c2) ? 0.0 : -fa.b * mv;
+            o21 = (r2 != 0 || c1) ? 0.0 : -fa.b * mv;
+          }
+          fa.A11[k] = o11;
+          fa.A22[k] = o22;
+          fa.A12[k] = o12;
+          if (fa.A21) fa.A21[k] = o21;
+          s11 += fabs(o11); s22 += fabs(o22);
+          if (diag) { d11 = o11; d22 = o22; }
+        }
       }
+      if constexpr (FUSED) {
+        // row sums over the NB lanes of the node
+#pragma unroll
+        for (int o = NB / 2; o > 0; o >>= 1) {
+          s11 += __shfl_down(s11, o, NB); s22 += __shfl_down(s22, o, NB);
+          d11 += __shfl_down(d11, o, NB); d22 += __shfl_down(d22, o, NB);
+          lK1 += __shfl_down(lK1, o, NB); lK2 += __shfl_down(lK2, o, NB); lM += __shfl_down(lM, o, NB);
+        }
+        if (c == 0) {
+          const double i1 = (d11 != 0.0) ? 1.0 / d11 : 1.0, i2 = (d22 != 0.0) ? 1.0 / d22 : 1.0;
+          fa.dinv1[node] = i1;
+          fa.dinv2[node] = i2;
+          const double q1 = s11 * fabs(i1), q2 = s22 * fabs(i2);
+          best1 = q1 > best1 ? q1 : best1;
+          best2 = q2 > best2 ? q2 : best2;
+          fa.rhs[node] = (!near || r1 != 0) ? 0.0 : -(fa.a * lK1 + fa.b * lM);
+          fa.rhs[n + node] = (!near || r2 != 0) ? 0.0 : -(fa.c * lK2 - fa.b * lM);
+          fa.u0[node] = near ? fa.g1[node] : 0.0;
+          fa.u0[n + node] = near ? fa.g2[node] : 0.0;
+        }
+      }
+    }
+  }
+  if constexpr (FUSED) {
+    for (int o = 32; o > 0; o >>= 1) {
+      const double t1 = __shfl_down(best1, o, 64), t2 = __shfl_down(best2, o, 64);
+      best1 = t1 > best1 ? t1 : best1;
+      best2 = t2 > best2 ? t2 : best2;
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMax(fa.lam, (unsigned long long)__double_as_longlong(best1));
+      atomicMax(fa.lam + 1, (unsigned long long)__double_as_longlong(best2));
     }
   }
 }
@@ -821,13 +899,13 @@ int pph_launch_assemble_KM(pph_ctx* ctx_, MeshData& mesh) {
       hipLaunchKernelGGL(k_elem_rows<2>, dim3(g1), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p, mesh.cy.p,
                          mesh.cz.p, mesh.erows.p, ncell);
       hipLaunchKernelGGL(k_gather_rows<2>, dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
-                         mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, mesh.nx, mesh.ny, 0, mesh.px, mesh.py, mesh.n);
+                         mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, mesh.nx, mesh.ny, 0, mesh.px, mesh.py, mesh.n, FuseArgs{});
     } else {
       hipLaunchKernelGGL(k_elem_rows<3>, dim3(g1), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p, mesh.cy.p,
                          mesh.cz.p, mesh.erows.p, ncell);
       hipLaunchKernelGGL(k_gather_rows<3>, dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
                          mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, mesh.nx, mesh.ny, mesh.nzl, mesh.px, mesh.py,
-                         mesh.n);
+                         mesh.n, FuseArgs{});
     }
     PPH_HIP(ctx, hipGetLastError());
     return PPH_OK;
@@ -1087,7 +1165,8 @@ __global__ __launch_bounds__(256) void k_mono_fill(const int64_t* __restrict__ r
   }
 }
 
-int pph_launch_blocks(pph_ctx* ctx, int monolithic) {
+// buffers of the eliminated system and everything that depends on the Dirichlet sets only
+static int blocks_prepare(pph_ctx* ctx) {
   const int64_t n = ctx->n, nnzb = ctx->nnzb;
   PPH_TRY(ctx->A11.alloc(ctx, (size_t)nnzb));
   PPH_TRY(ctx->A22.alloc(ctx, (size_t)nnzb));
@@ -1112,15 +1191,13 @@ int pph_launch_blocks(pph_ctx* ctx, int monolithic) {
   PPH_TRY(ctx->rhs.alloc(ctx, (size_t)(2 * n)));
   PPH_TRY(ctx->u0.alloc(ctx, (size_t)(2 * n)));
   PPH_TRY(ctx->sol.alloc(ctx, (size_t)(2 * n)));
+  return PPH_OK;
+}
+
+static int blocks_mono(pph_ctx* ctx, int monolithic) {
+  const int64_t n = ctx->n, nnzb = ctx->nnzb;
   int64_t nb = ceil_div64(n * BC_LANES, 256);
   int grid = (int)(nb < 256 * 16 ? nb : 256 * 16);
-  hipLaunchKernelGGL(k_lift_rhs, dim3(grid), dim3(256), 0, ctx->stream, ctx->mesh.rowptr.p, ctx->mesh.col.p, ctx->mesh.K.p,
-                     ctx->mesh.M.p, ctx->bcmask[0].p, ctx->bcmask[1].p, ctx->g[0].p, ctx->g[1].p, ctx->a, ctx->b, ctx->c,
-                     n, ctx->rownear.p, ctx->rhs.p, ctx->u0.p);
-  hipLaunchKernelGGL(k_blocks, dim3(grid), dim3(256), 0, ctx->stream, ctx->mesh.rowptr.p, ctx->mesh.col.p, ctx->mesh.K.p, ctx->mesh.M.p,
-                     ctx->bcmask[0].p, ctx->bcmask[1].p, ctx->a, ctx->b, ctx->c, n, ctx->rownear.p, ctx->A11.p, ctx->A22.p,
-                     ctx->A12.p, ctx->a21_alias ? nullptr : ctx->A21.p);
-  PPH_HIP(ctx, hipGetLastError());
   ctx->mono_ok = false;
   if (monolithic) {
     PPH_REQUIRE(ctx, 4 * nnzb < (int64_t)2147483647 * 4 && 2 * n < (int64_t)2147483647,
@@ -1136,6 +1213,74 @@ int pph_launch_blocks(pph_ctx* ctx, int monolithic) {
     ctx->mono_ok = true;
   }
   return PPH_OK;
+}
+
+int pph_launch_blocks(pph_ctx* ctx, int monolithic) {
+  const int64_t n = ctx->n;
+  PPH_TRY(blocks_prepare(ctx));
+  int64_t nb = ceil_div64(n * BC_LANES, 256);
+  int grid = (int)(nb < 256 * 16 ? nb : 256 * 16);
+  hipLaunchKernelGGL(k_lift_rhs, dim3(grid), dim3(256), 0, ctx->stream, ctx->mesh.rowptr.p, ctx->mesh.col.p, ctx->mesh.K.p,
+                     ctx->mesh.M.p, ctx->bcmask[0].p, ctx->bcmask[1].p, ctx->g[0].p, ctx->g[1].p, ctx->a, ctx->b, ctx->c,
+                     n, ctx->rownear.p, ctx->rhs.p, ctx->u0.p);
+  hipLaunchKernelGGL(k_blocks, dim3(grid), dim3(256), 0, ctx->stream, ctx->mesh.rowptr.p, ctx->mesh.col.p, ctx->mesh.K.p, ctx->mesh.M.p,
+                     ctx->bcmask[0].p, ctx->bcmask[1].p, ctx->a, ctx->b, ctx->c, n, ctx->rownear.p, ctx->A11.p, ctx->A22.p,
+                     ctx->A12.p, ctx->a21_alias ? nullptr : ctx->A21.p);
+  PPH_HIP(ctx, hipGetLastError());
+  ctx->diag0_valid = false;
+  return blocks_mono(ctx, monolithic);
+}
+
+// Fused assembly of the fine level for multilinear cells (two-pass kernels): element rows, then ONE node-centred
+// pass that writes the eliminated blocks, the lifted right-hand side and the smoother's diagonal / spectral bound
+// (and K, M as well when `asm_keep_km` is set, so that later assemblies with other coefficients reuse them).
+bool pph_can_fuse_assembly(const pph_ctx* ctx) {
+  const MeshData& m = ctx->mesh;
+  return ctx->asm_fused && ctx->asm_kernel == 2 && (m.kind == PPH_CELL_QUAD || m.kind == PPH_CELL_HEX);
+}
+
+int pph_launch_assemble_fused(pph_ctx* ctx, int monolithic) {
+  MeshData& mesh = ctx->mesh;
+  const int64_t n = ctx->n;
+  PPH_TRY(blocks_prepare(ctx));
+  if (ctx->asm_keep_km) {
+    PPH_TRY(mesh.K.alloc(ctx, (size_t)mesh.nnzb));
+    PPH_TRY(mesh.M.alloc(ctx, (size_t)mesh.nnzb));
+  }
+  PPH_TRY(ctx->dinv0[0].alloc(ctx, (size_t)n));
+  PPH_TRY(ctx->dinv0[1].alloc(ctx, (size_t)n));
+  PPH_TRY(ctx->lam0.alloc(ctx, 2));
+  PPH_HIP(ctx, hipMemsetAsync(ctx->lam0.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+  PPH_TRY(mesh.erows.alloc(ctx, (size_t)mesh.ncell * mesh.m * 2 * mesh.m));
+  const int cpb = 256 / mesh.m;
+  int64_t nb1 = ceil_div64(mesh.ncell, cpb), nb2 = ceil_div64(mesh.n, cpb);
+  int g1 = (int)(nb1 < 256 * 16 ? nb1 : 256 * 16), g2 = (int)(nb2 < 256 * 16 ? nb2 : 256 * 16);
+  FuseArgs fa;
+  fa.m1 = ctx->bcmask[0].p; fa.m2 = ctx->bcmask[1].p; fa.near = ctx->rownear.p;
+  fa.g1 = ctx->g[0].p; fa.g2 = ctx->g[1].p;
+  fa.a = ctx->a; fa.b = ctx->b; fa.c = ctx->c;
+  fa.A11 = ctx->A11.p; fa.A22 = ctx->A22.p; fa.A12 = ctx->A12.p; fa.A21 = ctx->a21_alias ? nullptr : ctx->A21.p;
+  fa.rhs = ctx->rhs.p; fa.u0 = ctx->u0.p;
+  fa.dinv1 = ctx->dinv0[0].p; fa.dinv2 = ctx->dinv0[1].p;
+  fa.lam = ctx->lam0.p;
+  fa.keep_km = ctx->asm_keep_km;
+  double* Kp = ctx->asm_keep_km ? mesh.K.p : nullptr;
+  double* Mp = ctx->asm_keep_km ? mesh.M.p : nullptr;
+  if (mesh.kind == PPH_CELL_QUAD) {
+    hipLaunchKernelGGL(k_elem_rows<2>, dim3(g1), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p, mesh.cy.p, mesh.cz.p,
+                       mesh.erows.p, mesh.ncell);
+    hipLaunchKernelGGL((k_gather_rows<2, true>), dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
+                       mesh.rowptr.p, mesh.col.p, Kp, Mp, mesh.nx, mesh.ny, 0, mesh.px, mesh.py, mesh.n, fa);
+  } else {
+    hipLaunchKernelGGL(k_elem_rows<3>, dim3(g1), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p, mesh.cy.p, mesh.cz.p,
+                       mesh.erows.p, mesh.ncell);
+    hipLaunchKernelGGL((k_gather_rows<3, true>), dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
+                       mesh.rowptr.p, mesh.col.p, Kp, Mp, mesh.nx, mesh.ny, mesh.nzl, mesh.px, mesh.py, mesh.n, fa);
+  }
+  PPH_HIP(ctx, hipGetLastError());
+  mesh.km_valid = ctx->asm_keep_km != 0;
+  ctx->diag0_valid = true;
+  return blocks_mono(ctx, monolithic);
 }
 
 // one Dirichlet-eliminated scalar operator coefK*K + coefM*M on any level (multigrid coarse operators)

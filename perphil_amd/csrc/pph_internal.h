@@ -123,6 +123,11 @@ struct pph_ctx {
   int64_t n = 0, nnzb = 0;              // copies of mesh.n / mesh.nnzb
   bool mesh_ok = false, asm_ok = false, mono_ok = false;
   DevBuf<uint8_t> bcmask[2];            // per field: 1 Dirichlet, 2 ghost, 0 free
+  DevBuf<double> dinv0[2];              // fused assembly: 1 / diag of A11, A22 ...
+  DevBuf<unsigned long long> lam0;      // ... and their spectral bounds (bit patterns), valid when diag0_valid
+  bool diag0_valid = false;
+  int asm_fused = 1;                    // multilinear two-pass assembly writes the blocks directly (see pph_launch_assemble_fused)
+  int asm_keep_km = 0;                  // 1: the fused pass also stores K and M (two more 8 B/nnz streams); 0: they are integrated on demand (pph_get_csr K/M, Darcy projection)
   DevBuf<uint8_t> rownear;              // 1: the row is constrained / ghost or has a constrained column (needs the masks)
   bool bc_dirty = true;                 // masks changed since rownear / a21_alias were derived from them
   DevBuf<double> g[2];                  // per field Dirichlet values (dense, 0 elsewhere)
@@ -193,6 +198,8 @@ int pph_launch_pattern(pph_ctx* ctx, int dim, int kind, int px, int py, int pz, 
                        DevBuf<int32_t>& col, int64_t* nnz_out);
 int pph_launch_assemble_KM(pph_ctx* ctx, MeshData& mesh);
 int pph_launch_blocks(pph_ctx* ctx, int monolithic);
+bool pph_can_fuse_assembly(const pph_ctx* ctx);
+int pph_launch_assemble_fused(pph_ctx* ctx, int monolithic);
 
 // linear algebra on the context stream; all results that feed control flow go through ctx->scal
 void la_spmv(pph_ctx* ctx, const Csr& A, const double* x, double* y);

@@ -370,6 +370,14 @@ int mg_setup(pph_ctx* ctx) {
       }
     }
     PPH_HIP(ctx, hipMemsetAsync(lamdev.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+    if (l == 0 && ctx->diag0_valid) {
+      // the fused assembly already produced the fine-level diagonal inverses and bounds
+      for (int f = 0; f < 2; ++f)
+        PPH_HIP(ctx, hipMemcpyAsync(L.dinv[f].p, ctx->dinv0[f].p, sizeof(double) * (size_t)L.n, hipMemcpyDeviceToDevice,
+                                    ctx->stream));
+      PPH_HIP(ctx, hipMemcpyAsync(lamdev.p, ctx->lam0.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToDevice,
+                                  ctx->stream));
+    } else
     for (int f = 0; f < 2; ++f)
       hipLaunchKernelGGL(k_diag_lam, dim3(mg_grid(L.n * 8)), dim3(256), 0, ctx->stream, L.rowptr, L.col, L.val[f], L.n,
                          L.dinv[f].p, lamdev.p + f);

@@ -702,3 +702,45 @@ def test_spmv_long_rows_and_residual_forms(gpu_ctx_factory, kern):
     res = o.pcg(osys.A, osys.rhs, o.jacobi_apply(osys.A), rtol=1e-10)
     assert info.converged and abs(info.iterations - res.its) <= 1
     assert np.abs(xs - (osys.u0 + res.x)).max() <= 1e-8 * np.abs(xs).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,kind,nx,ny,nz", [(2, o.CELL_QUAD, 9, 6, 0), (3, o.CELL_HEX, 6, 5, 4), (3, o.CELL_HEX, 16, 16, 16)])
+def test_fused_assembly_equals_two_step(gpu_ctx_factory, dim, kind, nx, ny, nz):
+    """The fused node-centred pass (blocks, lifted right-hand side, smoother diagonal / bound straight from the
+    element rows) against the two-step path (K, M, then k_lift_rhs / k_blocks / k_diag_lam): same entries, and the
+    multigrid-preconditioned solve takes the same iterations; with asm_keep_km = 0 K and M are integrated on demand."""
+    f = _ffi()
+    om = o.build_mesh(dim, kind, nx, ny, nz)
+    b = o.boundary_nodes(om)
+    g1, g2 = o.exact_pressures(om.coords[b], P)
+    out = {}
+    for mode, (fused, keep) in {"two-step": (0, 1), "fused": (1, 1), "fused-nokeep": (1, 0)}.items():
+        ctx = gpu_ctx_factory()
+        ctx.set_option("asm_fused", fused)
+        ctx.set_option("asm_keep_km", keep)
+        ctx.mesh_build(dim, kind, nx, ny, nz)
+        ctx.set_dirichlet(0, b, g1)
+        ctx.set_dirichlet(1, b, g2)
+        ctx.assemble(P.k1, P.k2, P.beta, P.mu, monolithic=True)
+        mats = {w: ctx.csr(w) for w in (f.MAT_A11, f.MAT_A22, f.MAT_A12, f.MAT_A21, f.MAT_MONO)}
+        rhs, u0 = ctx.rhs()
+        xs, info, _ = ctx.solve(_cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_MG, inner_rtol=1e-10,
+                                     inner_reduction=1e-1, inner_norm=1, mg_smooth=1, picard_rtol=1e-8))
+        K, M = ctx.csr(f.MAT_K), ctx.csr(f.MAT_M)       # after the solve: on-demand integration when not kept
+        out[mode] = (mats, rhs, u0, xs, (info.iterations, info.inner_iterations), K, M)
+    ref = out["two-step"]
+    for mode in ("fused", "fused-nokeep"):
+        got = out[mode]
+        for w in ref[0]:
+            np.testing.assert_array_equal(got[0][w].indices, ref[0][w].indices)
+            np.testing.assert_array_equal(got[0][w].data, ref[0][w].data)
+        # the lifting sums are reduced in a different lane order: last-bit differences only
+        np.testing.assert_allclose(got[1], ref[1], rtol=0, atol=1e-14 * np.abs(ref[1]).max())
+        np.testing.assert_array_equal(got[2], ref[2])
+        assert got[4] == ref[4]
+        np.testing.assert_allclose(got[3], ref[3], rtol=0, atol=1e-12 * np.abs(ref[3]).max())
+        np.testing.assert_array_equal(got[5].data, ref[5].data)
+        np.testing.assert_array_equal(got[6].data, ref[6].data)
+    osys = o.build_system(om, P)
+    assert abs(ref[0][f.MAT_MONO] - osys.A).max() <= 1e-12 * abs(osys.A).max()
