@@ -467,6 +467,8 @@ __global__ __launch_bounds__(256) void k_elem_rows(const int32_t* __restrict__ c
   constexpr int SGQ = NB * DIM + 1;        // sG Gauss-point stride
   constexpr int SGC = NB * SGQ + 2;        // sG cell stride
   constexpr int SWC = NB + 1;              // sW cell stride
+  constexpr int SOR = 2 * NB + 1;          // output staging: row stride (2 NB values + 1 pad), reuses sGf
+  static_assert(CPB * NB * SOR <= CPB * SGC, "output staging must fit in the gradient buffer");
   __shared__ double sXf[CPB * SXC];
   __shared__ double sGf[CPB * SGC];        // [cell][q][b][d] physical gradients
   __shared__ double sWf[CPB * SWC];        // [cell][q] |det J| (Gauss weights are 1)
@@ -497,16 +499,29 @@ __global__ __launch_bounds__(256) void k_elem_rows(const int32_t* __restrict__ c
     }
   }
   const int64_t nbatch = (ncell + CPB - 1) / CPB;
+  // vertex coordinates of the NEXT batch (two dependent loads: cell->dof entry, then the coordinates) are requested
+  // before the current batch is integrated
+  double pxyz[3] = {0.0, 0.0, 0.0};
+  auto fetch = [&](int64_t bt) {
+    const int64_t cl = bt * CPB + lc;
+    if (bt < nbatch && cl < ncell) {
+      const int32_t node = cells[cl * NB + a];
+      pxyz[0] = cx[node];
+      pxyz[1] = cy[node];
+      if constexpr (DIM == 3) pxyz[2] = cz[node];
+    }
+  };
+  fetch(blockIdx.x);
   for (int64_t batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
     __syncthreads();
     const int64_t cell = batch * CPB + lc;
     const bool valid = cell < ncell;
     if (valid) {
-      const int32_t node = cells[cell * NB + a];
-      sX(lc, a, 0) = cx[node];
-      sX(lc, a, 1) = cy[node];
-      if constexpr (DIM == 3) sX(lc, a, 2) = cz[node];
+      sX(lc, a, 0) = pxyz[0];
+      sX(lc, a, 1) = pxyz[1];
+      if constexpr (DIM == 3) sX(lc, a, 2) = pxyz[2];
     }
+    fetch(batch + gridDim.x);
     __syncthreads();
     if (valid) {
       const int q = a;  // this lane's Gauss point
@@ -555,31 +570,61 @@ __global__ __launch_bounds__(256) void k_elem_rows(const int32_t* __restrict__ c
         }
     }
     __syncthreads();
-    if (valid) {
-      double Kr[NB], Mr[NB];
+    // Contraction K_e = sum_{q,d} (w_q G[q][a][d]) G[q][b][d], M_e = sum_q (w_q N_q[a]) N_q[b] on the matrix cores:
+    // v_mfma_f64_16x16x4_f64 tiles of 16/NB cells (block-diagonal part used), A/B operand of lane l = row/column
+    // l & 15, k = 4 step + (l >> 4); result register r of lane l = D[(l >> 4) + 4 r][l & 15].  One LDS read per
+    // operand pair instead of one per multiply-add: the scalar version of this loop was LDS-bandwidth bound.
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    constexpr int CT = 16 / NB;                 // cells per tile
+    constexpr int TPW = (64 / NB) / CT;         // tiles per wavefront (4)
+    const int lane = tid & 63, wcell0 = (tid >> 6) * (64 / NB);
+    const int ti = lane & 15, tk = lane >> 4;   // operand row/column and k offset of this lane
+    v4d accK[TPW], accM[TPW];
 #pragma unroll
-      for (int b = 0; b < NB; ++b) { Kr[b] = 0.0; Mr[b] = 0.0; }
-#pragma unroll 2
-      for (int q = 0; q < NB; ++q) {
-        const double w = sW(lc, q);
-        double ga[DIM];
+    for (int t = 0; t < TPW; ++t) {
+      const int oc = wcell0 + t * CT + ti / NB, on = ti % NB;   // operand cell (in the batch) and vertex
+      v4d ck = {0.0, 0.0, 0.0, 0.0}, cm = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int d = 0; d < DIM; ++d) ga[d] = w * sG(lc, q, a, d);
-        const double na = w * sN[q][a];
+      for (int st = 0; st < NB * DIM / 4; ++st) {
+        const int kk = 4 * st + tk, q = kk / DIM, d = kk % DIM;
+        const double g = sG(oc, q, on, d);
+        ck = __builtin_amdgcn_mfma_f64_16x16x4f64(g * sW(oc, q), g, ck, 0, 0, 0);
+      }
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-          double dotg = 0.0;
+      for (int st = 0; st < NB / 4; ++st) {
+        const int q = 4 * st + tk;
+        const double nv = sN[q][on];
+        cm = __builtin_amdgcn_mfma_f64_16x16x4f64(nv * sW(oc, q), nv, cm, 0, 0, 0);
+      }
+      accK[t] = ck;
+      accM[t] = cm;
+    }
+    // park the rows in LDS (the gradients are dead after this barrier): the workgroup then streams its CPB x NB
+    // rows - one contiguous range of the element-row buffer - with coalesced 16-byte stores
+    __syncthreads();
 #pragma unroll
-          for (int d = 0; d < DIM; ++d) dotg += ga[d] * sG(lc, q, b, d);
-          Kr[b] += dotg;
-          Mr[b] += na * sN[q][b];
+    for (int t = 0; t < TPW; ++t) {
+      const int cj = ti / NB, b = ti % NB;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = tk + 4 * r;
+        if (i / NB == cj) {
+          double* so = sGf + ((wcell0 + t * CT + cj) * NB + i % NB) * SOR;
+          so[b] = accK[t][r];
+          so[NB + b] = accM[t][r];
         }
       }
-      double* out = erows + (cell * NB + a) * (2 * NB);
-#pragma unroll
-      for (int b = 0; b < NB; b += 2) {
-        *reinterpret_cast<double2*>(out + b) = make_double2(Kr[b], Kr[b + 1]);
-        *reinterpret_cast<double2*>(out + NB + b) = make_double2(Mr[b], Mr[b + 1]);
+    }
+    __syncthreads();
+    {
+      const int64_t cell0 = batch * CPB;
+      const int64_t left = ncell - cell0;
+      const int rows = (int)(left < CPB ? left : CPB) * NB;
+      double* out = erows + cell0 * NB * (2 * NB);
+      for (int e2 = tid; e2 < rows * NB; e2 += 256) {     // one double2 per thread and pass
+        const int row = e2 / NB, colp = 2 * (e2 % NB);
+        const double* si = sGf + row * SOR + colp;
+        *reinterpret_cast<double2*>(out + (int64_t)row * (2 * NB) + colp) = make_double2(si[0], si[1]);
       }
     }
   }
@@ -619,37 +664,57 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__
   const int tid = threadIdx.x;
   const int ln = tid / NB, c = tid % NB;
   const int64_t nbatch = (n + NPB - 1) / NPB;
+  // the element row and the cell->dof entries of the NEXT batch are requested before the current batch is matched
+  // and stored (register double buffer): the two phases of a batch are separated by barriers, and with a dozen
+  // waves per CU the loads of one phase were not overlapping the stores of the other
+  double2 pk[NB / 2], pm[NB / 2];
+  int32_t pc[NB];
+  int64_t pcell = -1;
+  bool pok = false;
+  auto fetch = [&](int64_t bt) {
+    pcell = -1;
+    pok = false;
+    const int64_t nd = bt * NPB + ln;
+    if (bt < nbatch && nd < n) {
+      const int i = (int)(nd % px);
+      const int64_t t = nd / px;
+      const int j = (int)(t % py), k = (int)(t / py);
+      const int ci = i - (c & 1), cj = j - ((c >> 1) & 1), ck = (DIM == 3) ? k - ((c >> 2) & 1) : 0;
+      const bool inb = ci >= 0 && ci < nx && cj >= 0 && cj < ny && (DIM == 2 || (ck >= 0 && ck < nzl));
+      if (inb) pcell = ci + (int64_t)nx * (cj + (int64_t)ny * ck);
+    }
+    if (pcell >= 0) {
+      // the node is local vertex c of this cell (checked against the cell->dof map)
+      const double* in = erows + (pcell * NB + c) * (2 * NB);
+      const int32_t* cn = cells + pcell * NB;
+#pragma unroll
+      for (int b = 0; b < NB; b += 2) {
+        pk[b / 2] = *reinterpret_cast<const double2*>(in + b);
+        pm[b / 2] = *reinterpret_cast<const double2*>(in + NB + b);
+      }
+#pragma unroll
+      for (int b = 0; b < NB; ++b) pc[b] = cn[b];
+      pok = pc[c] == (int32_t)nd;
+    }
+  };
+  fetch(blockIdx.x);
   for (int64_t batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
     __syncthreads();
     const int64_t node = batch * NPB + ln;
     const bool valid = node < n;
-    int64_t cell = -1;
-    if (valid) {
-      const int i = (int)(node % px);
-      const int64_t t = node / px;
-      const int j = (int)(t % py), k = (int)(t / py);
-      const int ci = i - (c & 1), cj = j - ((c >> 1) & 1), ck = (DIM == 3) ? k - ((c >> 2) & 1) : 0;
-      const bool inb = ci >= 0 && ci < nx && cj >= 0 && cj < ny && (DIM == 2 || (ck >= 0 && ck < nzl));
-      if (inb) cell = ci + (int64_t)nx * (cj + (int64_t)ny * ck);
-    }
-    if (cell >= 0) {
-      // the node is local vertex c of this cell (checked against the cell->dof map below)
-      const double* in = erows + (cell * NB + c) * (2 * NB);
-      const int32_t* cn = cells + cell * NB;
-      const bool ok = cn[c] == (int32_t)node;
+    if (pcell >= 0) {
 #pragma unroll
       for (int b = 0; b < NB; b += 2) {
-        const double2 kk = *reinterpret_cast<const double2*>(in + b);
-        const double2 mm = *reinterpret_cast<const double2*>(in + NB + b);
-        sK[ln][c][b] = kk.x; sK[ln][c][b + 1] = kk.y;
-        sM[ln][c][b] = mm.x; sM[ln][c][b + 1] = mm.y;
+        sK[ln][c][b] = pk[b / 2].x; sK[ln][c][b + 1] = pk[b / 2].y;
+        sM[ln][c][b] = pm[b / 2].x; sM[ln][c][b + 1] = pm[b / 2].y;
       }
 #pragma unroll
-      for (int b = 0; b < NB; ++b) sC[ln][c][b] = ok ? cn[b] : -1;
+      for (int b = 0; b < NB; ++b) sC[ln][c][b] = pok ? pc[b] : -1;
     } else {
 #pragma unroll
       for (int b = 0; b < NB; ++b) sC[ln][c][b] = -1;
     }
+    fetch(batch + gridDim.x);
     __syncthreads();
     if (valid) {
       const int64_t s = rowptr[node], e = rowptr[node + 1];
