@@ -110,6 +110,53 @@ __global__ void k_restrict(double* __restrict__ bc, const double* __restrict__ r
   }
 }
 
+// Q1 (quad / hex) restriction with the 3^DIM stencil unrolled and every load unconditional (out-of-range and
+// constrained neighbours get weight 0 and a clamped address): all loads of a coarse node are in flight together,
+// where the generic loop above waits for each conditional load before issuing the next.
+template <int DIM>
+__global__ __launch_bounds__(256) void k_restrict_q1(double* __restrict__ bc, const double* __restrict__ rf,
+                                                     const uint8_t* __restrict__ mc, const uint8_t* __restrict__ mf,
+                                                     TGeom g) {
+  const int64_t nc = (int64_t)g.pxc * g.pyc * g.pzc;
+  NODE_LOOP(id, nc) {
+    const int I = (int)(id % g.pxc);
+    const int64_t t = id / g.pxc;
+    const int J = (int)(t % g.pyc), K = (int)(t / g.pyc) + g.gzc;
+    double s = 0.0;
+    if (mc[id] == 0 && 2 * K >= g.own_lo_f && 2 * K < g.own_hi_f) {
+      constexpr int NZ = (DIM == 3) ? 3 : 1;
+      double v[NZ][3][3];
+      uint8_t m[NZ][3][3];
+      bool in[NZ][3][3];
+#pragma unroll
+      for (int dz = 0; dz < NZ; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const int i = 2 * I + dx - 1, j = 2 * J + dy - 1, k = (DIM == 3) ? 2 * K + dz - 1 - g.gzf : 0;
+            const bool ok = i >= 0 && i < g.pxf && j >= 0 && j < g.pyf && k >= 0 && k < g.pzf;
+            const int64_t f = ok ? i + (int64_t)g.pxf * (j + (int64_t)g.pyf * k) : 0;
+            in[dz][dy][dx] = ok;
+            v[dz][dy][dx] = rf[f];
+            m[dz][dy][dx] = mf[f];
+          }
+#pragma unroll
+      for (int dz = 0; dz < NZ; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const int nzc = (dx != 1) + (dy != 1) + ((DIM == 3) ? (dz != 1) : 0);
+            const double w = (nzc == 0) ? 1.0 : (nzc == 1) ? 0.5 : (nzc == 2) ? 0.25 : 0.125;
+            // same order of accumulation as the generic kernel's stencil (dz, dy, dx ascending)
+            if (in[dz][dy][dx] && (m[dz][dy][dx] & 1) == 0) s += w * v[dz][dy][dx];
+          }
+    }
+    bc[id] = s;
+  }
+}
+
 // x_f[f] += (P x_c)[f]   (constrained fine dofs untouched).  Closed form of the transpose of k_restrict:
 // a fine node f = 2c + o (o = parity vector of the GLOBAL index) interpolates
 //   Q1 (TK 0)         : the 2^|o| coarse nodes c + s, s <= o component-wise, weight 2^-|o|
@@ -129,12 +176,13 @@ __global__ __launch_bounds__(256) void k_prolong_add(double* __restrict__ xf, co
     const int64_t c = (i >> 1) + sy * (j >> 1) + sz * ((kg >> 1) - g.gzc);
     double s;
     if (TK == 0) {
-      double a0 = xc[c], a1 = ox ? xc[c + sx] : a0;
-      const double v00 = 0.5 * (a0 + a1);
-      double v10 = v00, v01 = v00, v11 = v00;
-      if (oy) { a0 = xc[c + sy]; a1 = ox ? xc[c + sy + sx] : a0; v10 = 0.5 * (a0 + a1); }
-      if (oz) { a0 = xc[c + sz]; a1 = ox ? xc[c + sz + sx] : a0; v01 = 0.5 * (a0 + a1); }
-      if (oy && oz) { a0 = xc[c + sy + sz]; a1 = ox ? xc[c + sy + sz + sx] : a0; v11 = 0.5 * (a0 + a1); }
+      // the 8 candidate coarse values are requested unconditionally (even parities repeat an address), then combined
+      // exactly as before: no load waits behind a branch
+      const int64_t ex = ox ? sx : 0, ey = oy ? sy : 0, ez = oz ? sz : 0;
+      const double c000 = xc[c], c100 = xc[c + ex], c010 = xc[c + ey], c110 = xc[c + ey + ex];
+      const double c001 = xc[c + ez], c101 = xc[c + ez + ex], c011 = xc[c + ez + ey], c111 = xc[c + ez + ey + ex];
+      const double v00 = 0.5 * (c000 + c100), v10 = 0.5 * (c010 + c110), v01 = 0.5 * (c001 + c101),
+                   v11 = 0.5 * (c011 + c111);
       if (oy && oz) s = 0.25 * (v00 + v10 + v01 + v11);
       else if (oy | oz) s = 0.5 * (v00 + (oy ? v10 : v01));
       else s = v00;
@@ -512,8 +560,15 @@ void mg_vcycle(pph_ctx* ctx, int which, const double* rin, double* zout, int nsm
     chebyshev(ctx, L, which, b, x, nsmooth, true);
     la_spmv_resid(ctx, level_csr(ctx, L, which, true), x, b, L.r.p);
     if (dist && !L.replicated) (void)la_halo(ctx, *L.geom, L.r.p);  // restriction reads one fine plane beyond the owned ones
-    hipLaunchKernelGGL(k_restrict, dim3(mg_grid(C.n)), dim3(256), 0, ctx->stream, C.b.p, L.r.p, st, C.maskp[which],
-                       L.maskp[which], tgeom(L, C));
+    if (ctx->mesh.kind == PPH_CELL_HEX)
+      hipLaunchKernelGGL(k_restrict_q1<3>, dim3(mg_grid(C.n)), dim3(256), 0, ctx->stream, C.b.p, L.r.p, C.maskp[which],
+                         L.maskp[which], tgeom(L, C));
+    else if (ctx->mesh.kind == PPH_CELL_QUAD)
+      hipLaunchKernelGGL(k_restrict_q1<2>, dim3(mg_grid(C.n)), dim3(256), 0, ctx->stream, C.b.p, L.r.p, C.maskp[which],
+                         L.maskp[which], tgeom(L, C));
+    else
+      hipLaunchKernelGGL(k_restrict, dim3(mg_grid(C.n)), dim3(256), 0, ctx->stream, C.b.p, L.r.p, st, C.maskp[which],
+                         L.maskp[which], tgeom(L, C));
     if (dist && C.replicated && !L.replicated) (void)la_allreduce_vec(ctx, C.b.p, C.n);
   }
   // coarsest level: Jacobi-CG to 1e-12 (a handful of unknowns)
