@@ -835,15 +835,16 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__
 // (membership and local index from the cell->dof map), evaluates the constant gradients and adds the node's
 // row of K_e / M_e into the CSR row held in registers; fixed order, no atomics, every entry written once.
 // ------------------------------------------------------------------------------------------------
-template <int DIM>
+template <int DIM, bool FUSED = false>
 __global__ __launch_bounds__(256) void k_asm_simplex_gather(const int32_t* __restrict__ cells,
                                                             const double* __restrict__ cx, const double* __restrict__ cy,
                                                             const double* __restrict__ cz,
                                                             const int64_t* __restrict__ rowptr,
                                                             const int32_t* __restrict__ col, double* __restrict__ K,
                                                             double* __restrict__ M, int nx, int ny, int nzl, int px, int py,
-                                                            int64_t n) {
+                                                            int64_t n, FuseArgs fa) {
   constexpr int NB = DIM + 1;
+  double best1 = 0.0, best2 = 0.0;
   constexpr int NSUB = (DIM == 2) ? 2 : 6;
   constexpr int MAXROW = (DIM == 2) ? 7 : 15;
   for (int64_t node = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; node < n;
@@ -939,12 +940,65 @@ __global__ __launch_bounds__(256) void k_asm_simplex_gather(const int32_t* __res
         }
       }
     }
+    if constexpr (!FUSED) {
 #pragma unroll
-    for (int q = 0; q < MAXROW; ++q)
-      if (q < len) {
-        K[s + q] = aK[q];
-        M[s + q] = aM[q];
-      }
+      for (int q = 0; q < MAXROW; ++q)
+        if (q < len) {
+          K[s + q] = aK[q];
+          M[s + q] = aM[q];
+        }
+    } else {
+      // fused epilogue (see FuseArgs): the row is complete in registers
+      const bool near = fa.near[node] != 0;
+      uint8_t r1 = 0, r2 = 0;
+      if (near) { r1 = fa.m1[node]; r2 = fa.m2[node]; }
+      double s11 = 0.0, s22 = 0.0, d11 = 0.0, d22 = 0.0, lK1 = 0.0, lK2 = 0.0, lM = 0.0;
+#pragma unroll
+      for (int q = 0; q < MAXROW; ++q)
+        if (q < len) {
+          const double kv = aK[q], mv = aM[q];
+          const int32_t jc = cl[q];
+          if (fa.keep_km) { K[s + q] = kv; M[s + q] = mv; }
+          const bool diag = (jc == (int32_t)node);
+          double o11 = fa.a * kv + fa.b * mv, o22 = fa.c * kv + fa.b * mv, o12 = -fa.b * mv, o21 = o12;
+          if (near) {
+            const bool c1 = (fa.m1[jc] & 1) != 0, c2 = fa.A21 ? (fa.m2[jc] & 1) != 0 : c1;
+            const double v1 = fa.g1[jc], v2 = fa.g2[jc];
+            lK1 += kv * v1; lK2 += kv * v2; lM += mv * (v1 - v2);
+            o11 = (r1 & 2) ? 0.0 : (r1 & 1) ? (diag ? 1.0 : 0.0) : (c1 ? 0.0 : o11);
+            o22 = (r2 & 2) ? 0.0 : (r2 & 1) ? (diag ? 1.0 : 0.0) : (c2 ? 0.0 : o22);
+            o12 = (r1 != 0 || c2) ? 0.0 : -fa.b * mv;
+            o21 = (r2 != 0 || c1) ? 0.0 : -fa.b * mv;
+          }
+          fa.A11[s + q] = o11;
+          fa.A22[s + q] = o22;
+          fa.A12[s + q] = o12;
+          if (fa.A21) fa.A21[s + q] = o21;
+          s11 += fabs(o11); s22 += fabs(o22);
+          if (diag) { d11 = o11; d22 = o22; }
+        }
+      const double i1 = (d11 != 0.0) ? 1.0 / d11 : 1.0, i2 = (d22 != 0.0) ? 1.0 / d22 : 1.0;
+      fa.dinv1[node] = i1;
+      fa.dinv2[node] = i2;
+      const double q1 = s11 * fabs(i1), q2 = s22 * fabs(i2);
+      best1 = q1 > best1 ? q1 : best1;
+      best2 = q2 > best2 ? q2 : best2;
+      fa.rhs[node] = (!near || r1 != 0) ? 0.0 : -(fa.a * lK1 + fa.b * lM);
+      fa.rhs[n + node] = (!near || r2 != 0) ? 0.0 : -(fa.c * lK2 - fa.b * lM);
+      fa.u0[node] = near ? fa.g1[node] : 0.0;
+      fa.u0[n + node] = near ? fa.g2[node] : 0.0;
+    }
+  }
+  if constexpr (FUSED) {
+    for (int o = 32; o > 0; o >>= 1) {
+      const double t1 = __shfl_down(best1, o, 64), t2 = __shfl_down(best2, o, 64);
+      best1 = t1 > best1 ? t1 : best1;
+      best2 = t2 > best2 ? t2 : best2;
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicMax(fa.lam, (unsigned long long)__double_as_longlong(best1));
+      atomicMax(fa.lam + 1, (unsigned long long)__double_as_longlong(best2));
+    }
   }
 }
 
@@ -998,11 +1052,11 @@ int pph_launch_assemble_KM(pph_ctx* ctx_, MeshData& mesh) {
     if (mesh.kind == PPH_CELL_TRI)
       hipLaunchKernelGGL(k_asm_simplex_gather<2>, dim3(grid), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p,
                          mesh.cy.p, mesh.cz.p, mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, mesh.nx, mesh.ny, 0, mesh.px,
-                         mesh.py, mesh.n);
+                         mesh.py, mesh.n, FuseArgs{});
     else
       hipLaunchKernelGGL(k_asm_simplex_gather<3>, dim3(grid), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p,
                          mesh.cy.p, mesh.cz.p, mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, mesh.nx, mesh.ny, mesh.nzl,
-                         mesh.px, mesh.py, mesh.n);
+                         mesh.px, mesh.py, mesh.n, FuseArgs{});
     PPH_HIP(ctx, hipGetLastError());
     return PPH_OK;
   }
@@ -1301,7 +1355,9 @@ int pph_launch_blocks(pph_ctx* ctx, int monolithic) {
 // (and K, M as well when `asm_keep_km` is set, so that later assemblies with other coefficients reuse them).
 bool pph_can_fuse_assembly(const pph_ctx* ctx) {
   const MeshData& m = ctx->mesh;
-  return ctx->asm_fused && ctx->asm_kernel == 2 && (m.kind == PPH_CELL_QUAD || m.kind == PPH_CELL_HEX);
+  if (!ctx->asm_fused) return false;
+  if (m.kind == PPH_CELL_QUAD || m.kind == PPH_CELL_HEX) return ctx->asm_kernel == 2;
+  return ctx->asm_kernel != 0;   // simplices: the node-centred gather kernel
 }
 
 int pph_launch_assemble_fused(pph_ctx* ctx, int monolithic) {
@@ -1316,7 +1372,8 @@ int pph_launch_assemble_fused(pph_ctx* ctx, int monolithic) {
   PPH_TRY(ctx->dinv0[1].alloc(ctx, (size_t)n));
   PPH_TRY(ctx->lam0.alloc(ctx, 2));
   PPH_HIP(ctx, hipMemsetAsync(ctx->lam0.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
-  PPH_TRY(mesh.erows.alloc(ctx, (size_t)mesh.ncell * mesh.m * 2 * mesh.m));
+  const bool multilinear = (mesh.kind == PPH_CELL_QUAD || mesh.kind == PPH_CELL_HEX);
+  if (multilinear) PPH_TRY(mesh.erows.alloc(ctx, (size_t)mesh.ncell * mesh.m * 2 * mesh.m));
   const int cpb = 256 / mesh.m;
   int64_t nb1 = ceil_div64(mesh.ncell, cpb), nb2 = ceil_div64(mesh.n, cpb);
   int g1 = (int)(nb1 < 256 * 16 ? nb1 : 256 * 16), g2 = (int)(nb2 < 256 * 16 ? nb2 : 256 * 16);
@@ -1331,7 +1388,18 @@ int pph_launch_assemble_fused(pph_ctx* ctx, int monolithic) {
   fa.keep_km = ctx->asm_keep_km;
   double* Kp = ctx->asm_keep_km ? mesh.K.p : nullptr;
   double* Mp = ctx->asm_keep_km ? mesh.M.p : nullptr;
-  if (mesh.kind == PPH_CELL_QUAD) {
+  if (!multilinear) {
+    int64_t nbs = ceil_div64(mesh.n, 256);
+    const int gs = (int)(nbs < 256 * 32 ? nbs : 256 * 32);
+    if (mesh.kind == PPH_CELL_TRI)
+      hipLaunchKernelGGL((k_asm_simplex_gather<2, true>), dim3(gs), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p,
+                         mesh.cy.p, mesh.cz.p, mesh.rowptr.p, mesh.col.p, Kp, Mp, mesh.nx, mesh.ny, 0, mesh.px, mesh.py,
+                         mesh.n, fa);
+    else
+      hipLaunchKernelGGL((k_asm_simplex_gather<3, true>), dim3(gs), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p,
+                         mesh.cy.p, mesh.cz.p, mesh.rowptr.p, mesh.col.p, Kp, Mp, mesh.nx, mesh.ny, mesh.nzl, mesh.px,
+                         mesh.py, mesh.n, fa);
+  } else if (mesh.kind == PPH_CELL_QUAD) {
     hipLaunchKernelGGL(k_elem_rows<2>, dim3(g1), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p, mesh.cy.p, mesh.cz.p,
                        mesh.erows.p, mesh.ncell);
     hipLaunchKernelGGL((k_gather_rows<2, true>), dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,

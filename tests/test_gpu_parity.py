@@ -705,7 +705,8 @@ def test_spmv_long_rows_and_residual_forms(gpu_ctx_factory, kern):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dim,kind,nx,ny,nz", [(2, o.CELL_QUAD, 9, 6, 0), (3, o.CELL_HEX, 6, 5, 4), (3, o.CELL_HEX, 16, 16, 16)])
+@pytest.mark.parametrize("dim,kind,nx,ny,nz", [(2, o.CELL_QUAD, 9, 6, 0), (3, o.CELL_HEX, 6, 5, 4), (3, o.CELL_HEX, 16, 16, 16),
+                                               (2, o.CELL_TRI, 8, 6, 0), (3, o.CELL_TET, 6, 4, 8)])
 def test_fused_assembly_equals_two_step(gpu_ctx_factory, dim, kind, nx, ny, nz):
     """The fused node-centred pass (blocks, lifted right-hand side, smoother diagonal / bound straight from the
     element rows) against the two-step path (K, M, then k_lift_rhs / k_blocks / k_diag_lam): same entries, and the
