@@ -207,16 +207,25 @@ int pph_comm_selftest(pph_ctx* ctx);
 
 /* ---- stats ---------------------------------------------------------------------------------
  * replaces: PETSc -log_view event times scraped by reference src/perphil/experiments/petsc_profiling.py:302-447.
- * out[0] mesh+pattern ms, [1] K/M integration+scatter ms, [2] BC elimination/blocks ms, [3] last solve ms;
+ * out[0] mesh+pattern ms, [1] integration ms (fused assembly: the whole assembly), [2] elimination/blocks ms of
+ * the two-step path (0 when fused), [3] last solve ms;
  * SpMV accounting of the last solve per kernel variant v (0: plain, 1: fused with the p.Ap dot):
  * out[4+3v] sum of per-launch durations in ms (0 unless option "time_spmv" is on), out[5+3v] launches,
  * out[6+3v] algorithmic bytes (12 nnz + 20 nrows per launch); out[10] halo exchanges of the last solve;
  * out[11..13] the same three figures (ms, launches, bytes; both variants together) for the launches on
  * fine-level operators only (rows >= nodes of the mesh), i.e. without the coarser multigrid levels. */
 int pph_get_timers(pph_ctx* ctx, double* out, int n);
-/* tuning / profiling switches (no reference counterpart): "spmv_lanes" (0 = automatic, 4..64 lanes per
- * CSR row), "time_spmv" (1: bracket every SpMV launch of a solve with a HIP event pair on the context
- * stream), "invalidate_KM" (drop the integrated K and M so the next assemble integrates again) */
+/* tuning / profiling switches (no reference counterpart; defaults in brackets):
+ *   "spmv_kernel" [3]    SpMV variant kept for A/B measurement, "spmv_lanes" [0 = automatic,
+ *                        4..64 lanes per CSR row], "spmv_blocks" [0 = 1024 workgroups], "spmv_bench_mode" [0]
+ *   "time_spmv" [0]      1: bracket every SpMV launch of a solve with a HIP event pair on the context stream
+ *   "asm_kernel" [2]     multilinear assembly: 0 cell-centred scatter-add (atomics), 1 node-centred gather, 2 two-pass
+ *   "asm_fused" [1]      the node-centred pass writes the eliminated blocks, lifted right-hand side and smoother
+ *                        diagonal directly; 0: K and M first, then separate elimination kernels
+ *   "asm_keep_km" [0]    1: the fused pass also stores K and M (otherwise they are integrated on demand)
+ *   "invalidate_KM"      drop the integrated K and M so that the next assemble integrates again
+ *   "mg_fp32" [0], "mg_replicate_below" [40000 nodes], "coarse_on_device" [1]   multigrid: fp32 copies of the V-cycle
+ *                        operators, replication threshold of coarse levels on slabs, coarsest solve in one workgroup */
 int pph_set_option(pph_ctx* ctx, const char* name, double value);
 
 #ifdef __cplusplus
