@@ -648,7 +648,7 @@ struct FuseArgs {
   int keep_km;                     // also store K and M
 };
 
-template <int DIM, bool FUSED = false>
+template <int DIM, bool FUSED = false, bool CLOSED = false>
 __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__ cells,
                                                      const double* __restrict__ erows,
                                                      const int64_t* __restrict__ rowptr,
@@ -660,7 +660,10 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__
   constexpr int NPB = 256 / NB;
   __shared__ double sK[NPB][NB][NB + 1];  // +1: rows of different incident cells land in different banks
   __shared__ double sM[NPB][NB][NB + 1];
-  __shared__ int32_t sC[NPB][NB][NB];
+  // CLOSED (at least two cells per direction): columns are matched by corner arithmetic and only a validity flag
+  // per incident cell is kept; otherwise the cell->dof entries are parked for a search (tiny meshes)
+  __shared__ int32_t sC[CLOSED ? 1 : NPB][NB][NB];
+  __shared__ uint8_t sOK[NPB][NB];
   const int tid = threadIdx.x;
   const int ln = tid / NB, c = tid % NB;
   const int64_t nbatch = (n + NPB - 1) / NPB;
@@ -692,9 +695,13 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__
         pk[b / 2] = *reinterpret_cast<const double2*>(in + b);
         pm[b / 2] = *reinterpret_cast<const double2*>(in + NB + b);
       }
+      if constexpr (CLOSED) {
+        pok = cn[c] == (int32_t)nd;
+      } else {
 #pragma unroll
-      for (int b = 0; b < NB; ++b) pc[b] = cn[b];
-      pok = pc[c] == (int32_t)nd;
+        for (int b = 0; b < NB; ++b) pc[b] = cn[b];
+        pok = pc[c] == (int32_t)nd;
+      }
     }
   };
   fetch(blockIdx.x);
@@ -708,18 +715,22 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__
         sK[ln][c][b] = pk[b / 2].x; sK[ln][c][b + 1] = pk[b / 2].y;
         sM[ln][c][b] = pm[b / 2].x; sM[ln][c][b + 1] = pm[b / 2].y;
       }
+      sOK[ln][c] = pok ? 1 : 0;
+      if constexpr (!CLOSED) {
 #pragma unroll
-      for (int b = 0; b < NB; ++b) sC[ln][c][b] = pok ? pc[b] : -1;
+        for (int b = 0; b < NB; ++b) sC[ln][c][b] = pok ? pc[b] : -1;
+      }
     } else {
+      sOK[ln][c] = 0;
+      if constexpr (!CLOSED) {
 #pragma unroll
-      for (int b = 0; b < NB; ++b) sC[ln][c][b] = -1;
+        for (int b = 0; b < NB; ++b) sC[ln][c][b] = -1;
+      }
     }
     fetch(batch + gridDim.x);
     __syncthreads();
     if (valid) {
       const int64_t s = rowptr[node], e = rowptr[node + 1];
-      // closed-form matching needs an unambiguous decode of the column offset (>= 2 cells per direction)
-      const bool closed = px >= 3 && py >= 3 && (DIM == 2 || nzl >= 2);
       // fused epilogue state of this lane's share of the row
       bool near = false;
       uint8_t r1 = 0, r2 = 0;
@@ -731,7 +742,7 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__
       for (int64_t k = s + c; k < e; k += NB) {
         const int32_t j = col[k];
         double kv = 0.0, mv = 0.0;
-        if (closed) {
+        if constexpr (CLOSED) {
           // column = node + (dx, dy, dz); incident cell cc = (cx,cy,cz) holds the node at local corner cc and the
           // column at corner b = cc + d: per direction d=0 -> corners (0,0),(1,1); d=+1 -> (0,1); d=-1 -> (1,0)
           const int64_t pxy = (int64_t)px * py;
@@ -753,7 +764,7 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__
               cc |= cb << a;
               b |= (bb & 1) << a;
             }
-            if (okc && sC[ln][cc][0] >= 0) {
+            if (okc && sOK[ln][cc]) {
               kv += sK[ln][cc][b];
               mv += sM[ln][cc][b];
             }
@@ -1017,14 +1028,23 @@ int pph_launch_assemble_KM(pph_ctx* ctx_, MeshData& mesh) {
     if (mesh.kind == PPH_CELL_QUAD) {
       hipLaunchKernelGGL(k_elem_rows<2>, dim3(g1), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p, mesh.cy.p,
                          mesh.cz.p, mesh.erows.p, ncell);
-      hipLaunchKernelGGL(k_gather_rows<2>, dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
-                         mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, mesh.nx, mesh.ny, 0, mesh.px, mesh.py, mesh.n, FuseArgs{});
+      if (mesh.px >= 3 && mesh.py >= 3)
+        hipLaunchKernelGGL((k_gather_rows<2, false, true>), dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
+                           mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, mesh.nx, mesh.ny, 0, mesh.px, mesh.py, mesh.n, FuseArgs{});
+      else
+        hipLaunchKernelGGL((k_gather_rows<2, false, false>), dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
+                           mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, mesh.nx, mesh.ny, 0, mesh.px, mesh.py, mesh.n, FuseArgs{});
     } else {
       hipLaunchKernelGGL(k_elem_rows<3>, dim3(g1), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p, mesh.cy.p,
                          mesh.cz.p, mesh.erows.p, ncell);
-      hipLaunchKernelGGL(k_gather_rows<3>, dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
-                         mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, mesh.nx, mesh.ny, mesh.nzl, mesh.px, mesh.py,
-                         mesh.n, FuseArgs{});
+      if (mesh.px >= 3 && mesh.py >= 3 && mesh.nzl >= 2)
+        hipLaunchKernelGGL((k_gather_rows<3, false, true>), dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
+                           mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, mesh.nx, mesh.ny, mesh.nzl, mesh.px, mesh.py,
+                           mesh.n, FuseArgs{});
+      else
+        hipLaunchKernelGGL((k_gather_rows<3, false, false>), dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
+                           mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, mesh.nx, mesh.ny, mesh.nzl, mesh.px, mesh.py,
+                           mesh.n, FuseArgs{});
     }
     PPH_HIP(ctx, hipGetLastError());
     return PPH_OK;
@@ -1402,13 +1422,21 @@ int pph_launch_assemble_fused(pph_ctx* ctx, int monolithic) {
   } else if (mesh.kind == PPH_CELL_QUAD) {
     hipLaunchKernelGGL(k_elem_rows<2>, dim3(g1), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p, mesh.cy.p, mesh.cz.p,
                        mesh.erows.p, mesh.ncell);
-    hipLaunchKernelGGL((k_gather_rows<2, true>), dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
-                       mesh.rowptr.p, mesh.col.p, Kp, Mp, mesh.nx, mesh.ny, 0, mesh.px, mesh.py, mesh.n, fa);
+    if (mesh.px >= 3 && mesh.py >= 3)
+      hipLaunchKernelGGL((k_gather_rows<2, true, true>), dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
+                         mesh.rowptr.p, mesh.col.p, Kp, Mp, mesh.nx, mesh.ny, 0, mesh.px, mesh.py, mesh.n, fa);
+    else
+      hipLaunchKernelGGL((k_gather_rows<2, true, false>), dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
+                         mesh.rowptr.p, mesh.col.p, Kp, Mp, mesh.nx, mesh.ny, 0, mesh.px, mesh.py, mesh.n, fa);
   } else {
     hipLaunchKernelGGL(k_elem_rows<3>, dim3(g1), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p, mesh.cy.p, mesh.cz.p,
                        mesh.erows.p, mesh.ncell);
-    hipLaunchKernelGGL((k_gather_rows<3, true>), dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
-                       mesh.rowptr.p, mesh.col.p, Kp, Mp, mesh.nx, mesh.ny, mesh.nzl, mesh.px, mesh.py, mesh.n, fa);
+    if (mesh.px >= 3 && mesh.py >= 3 && mesh.nzl >= 2)
+      hipLaunchKernelGGL((k_gather_rows<3, true, true>), dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
+                         mesh.rowptr.p, mesh.col.p, Kp, Mp, mesh.nx, mesh.ny, mesh.nzl, mesh.px, mesh.py, mesh.n, fa);
+    else
+      hipLaunchKernelGGL((k_gather_rows<3, true, false>), dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
+                         mesh.rowptr.p, mesh.col.p, Kp, Mp, mesh.nx, mesh.ny, mesh.nzl, mesh.px, mesh.py, mesh.n, fa);
   }
   PPH_HIP(ctx, hipGetLastError());
   mesh.km_valid = ctx->asm_keep_km != 0;
