@@ -745,3 +745,65 @@ def test_fused_assembly_equals_two_step(gpu_ctx_factory, dim, kind, nx, ny, nz):
         np.testing.assert_array_equal(got[6].data, ref[6].data)
     osys = o.build_system(om, P)
     assert abs(ref[0][f.MAT_MONO] - osys.A).max() <= 1e-12 * abs(osys.A).max()
+
+
+@pytest.mark.gpu
+def test_config3_128cubed_picard_with_jacobi_block_solves(gpu_ctx_factory):
+    """BASELINE config 3 at full size: 128^3 Q1, Picard-split with Jacobi-preconditioned CG block solves (the fused
+    CG-update kernel path), against the multigrid-preconditioned Picard solve of the same system and an
+    independently recomputed residual."""
+    f = _ffi()
+    N = 128
+    ctx = gpu_ctx_factory()
+    ctx.mesh_build(3, f.CELL_HEX, N, N, N)
+    n = ctx.n
+    import perphil_amd.fd as fdm
+
+    mesh = fdm.UnitCubeMesh(N, N, N, hexahedral=True)
+    b = mesh.boundary_nodes()
+    e1, e2 = o.exact_pressures(mesh.node_coordinates(b), P)
+    ctx.set_dirichlet(0, b, e1)
+    ctx.set_dirichlet(1, b, e2)
+    ctx.assemble(P.k1, P.k2, P.beta, P.mu, monolithic=False)
+    xj, ij, _ = ctx.solve(_cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_JACOBI, inner_rtol=1e-10,
+                               inner_reduction=1e-2, picard_rtol=1e-8, picard_max_it=100))
+    assert ij.converged and ij.iterations <= 12
+    r, u0 = ctx.rhs()
+    d = xj - u0
+    res1 = r[:n] - ctx.spmv(f.MAT_A11, d[:n]) - ctx.spmv(f.MAT_A12, d[n:])
+    res2 = r[n:] - ctx.spmv(f.MAT_A21, d[:n]) - ctx.spmv(f.MAT_A22, d[n:])
+    assert np.sqrt(res1 @ res1 + res2 @ res2) <= 1.05e-8 * np.linalg.norm(r)
+    xm, im, _ = ctx.solve(_cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_MG, inner_rtol=1e-10,
+                               inner_reduction=1e-1, inner_norm=1, mg_smooth=1, picard_rtol=1e-8, picard_max_it=100))
+    assert im.converged
+    assert np.abs(xj - xm).max() <= 2e-6 * np.abs(xm).max()
+    assert ij.inner_iterations > 20 * im.inner_iterations      # what the multigrid block solves buy at this size
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pc", ["block2", "jacobi"])
+def test_config2_64cubed_monolithic_cg(gpu_ctx_factory, pc):
+    """BASELINE config 2 at full size: 64^3 Q1, monolithic CSR, CG with the 2x2 node-block Jacobi (or point Jacobi)
+    preconditioner; the solution is checked through an independently recomputed residual and against the
+    field-split GMRES solve of the same system."""
+    f = _ffi()
+    N = 64
+    ctx = gpu_ctx_factory()
+    ctx.mesh_build(3, f.CELL_HEX, N, N, N)
+    n = ctx.n
+    import perphil_amd.fd as fdm
+
+    mesh = fdm.UnitCubeMesh(N, N, N, hexahedral=True)
+    b = mesh.boundary_nodes()
+    e1, e2 = o.exact_pressures(mesh.node_coordinates(b), P)
+    ctx.set_dirichlet(0, b, e1)
+    ctx.set_dirichlet(1, b, e2)
+    ctx.assemble(P.k1, P.k2, P.beta, P.mu, monolithic=True)
+    xs, info, hist = ctx.solve(_cfg(ksp_type=f.KSP_CG, pc_type=f.PC_BLOCK2 if pc == "block2" else f.PC_JACOBI, rtol=1e-10),
+                               hist_cap=4096)
+    assert info.converged and 50 < info.iterations < 2000
+    r, u0 = ctx.rhs()
+    res = r - ctx.spmv(f.MAT_MONO, xs - u0)
+    assert np.linalg.norm(res) <= 1e-7 * np.linalg.norm(r)
+    xg, ig, _ = ctx.solve(_cfg(pc_type=f.PC_FIELDSPLIT, inner_pc_type=f.PC_MG, inner_rtol=1e-12, rtol=1e-10))
+    assert ig.converged and np.abs(xs - xg).max() <= 1e-6 * np.abs(xg).max()
