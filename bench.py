@@ -234,6 +234,7 @@ def main():
         ctx.synchronize()
         if dist is not None:
             dist.barrier()
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
