@@ -1131,7 +1131,7 @@ __global__ __launch_bounds__(256) void k_cg_update(double* __restrict__ x, doubl
     const double ri = r[i] - alpha * q[i];
     r[i] = ri;
     const double zi = dinv ? dinv[i] * ri : ri;
-    z[i] = zi;
+    if (z) z[i] = zi;   // z == null: only the updates and r.r are wanted (unpreconditioned-norm CG)
     if ((i >= sg.off1 && i < sg.off1 + sg.len1) || (i >= sg.off2 && i < sg.off2 + sg.len2)) {  // owned entries only
       a += ri * zi;
       b += zi * zi;

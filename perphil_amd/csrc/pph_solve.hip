@@ -117,9 +117,7 @@ static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double*
     const double pq = ctx->h_scal[slot];
     if (!(pq > 0.0) || !(rz == rz)) { out->breakdown = true; break; }
     const double alpha = rz / pq;
-    la_axpy(ctx, x, alpha, p, n);
-    la_axpy(ctx, r, -alpha, q, n);
-    la_mdot_seg(ctx, r, 0, 1, r, sg, slot);
+    la_cg_update(ctx, x, r, nullptr, p, q, nullptr, alpha, n, slot, sg);   // x += alpha p ; r -= alpha q ; r.r
     PPH_TRY(la_fetch(ctx, slot, 1));
     res = std::sqrt(ctx->h_scal[slot]);
     ++its;
@@ -475,9 +473,8 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
     // block Picard / fixed-stress sweeps on the correction du (homogeneous BCs):
     //   A11 du1 = b1 - A12 du2_old ;  A22 du2 = b2 - A21 du1_new        (dpp.py:196-203)
     PPH_TRY(bs.setup());
-    double *pb, *t;
+    double* pb;
     PPH_TRY(work(ctx, W_PB, (size_t)n, &pb));
-    PPH_TRY(work(ctx, W_T, (size_t)n, &t));
     const double* b1 = ctx->rhs.p;
     const double* b2 = ctx->rhs.p + n;
     double* du1 = du;
