@@ -88,6 +88,14 @@ def _inner_cfg(cfg: _ffi.SolverCfg, subs: List[Dict], notes: List[str]) -> None:
     else:
         raise NotImplementedError(f"fieldsplit block ksp_type {k!r} is not supported")
     cfg.inner_rtol = min(rtols) if rtols else 1e-5  # PETSc default ksp_rtol
+    # inexact block solves: ksp_norm_type of the sub-solvers (PETSc's option name) and the residual reduction each
+    # block solve has to reach from its own starting residual (pph_reduction; 0 = ksp_rtol only)
+    norms = {str(s.get("ksp_norm_type", "preconditioned")).lower() for s in subs}
+    if len(norms) != 1 or norms - {"preconditioned", "unpreconditioned"}:
+        raise NotImplementedError("fieldsplit ksp_norm_type must be preconditioned or unpreconditioned on both blocks")
+    cfg.inner_norm = 1 if norms.pop() == "unpreconditioned" else 0
+    reds = [float(s["pph_reduction"]) for s in subs if "pph_reduction" in s]
+    cfg.inner_reduction = max(reds) if reds else 0.0
 
 
 def translate_options(params: Dict, nonlinear: bool = False) -> Tuple[_ffi.SolverCfg, dict]:

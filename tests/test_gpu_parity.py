@@ -322,6 +322,25 @@ def test_mg_pcg_iterations_match_mg_oracle(gpu_ctx_factory, dim, kind, n, k2):
     assert np.abs(x - (osys.u0 + du)).max() <= 1e-7 * np.abs(osys.u0 + du).max()
 
 
+def test_public_api_inexact_picard_preset(gpu_ctx_factory):
+    """solve_dpp_nonlinear with PICARD_MG_INEXACT_SOLVER_PARAMS (the benchmark's algorithm through the public API)
+    reaches the fixed point of the exact-block-solve preset with far fewer block iterations."""
+    import perphil_amd as pa
+    from perphil_amd import fd, solver_parameters as spar
+
+    mesh = fd.UnitCubeMesh(16, 16, 16, hexahedral=True)
+    V = fd.FunctionSpace(mesh, "CG", 1)
+    W = V * V
+    params = pa.DPPParameters(k1=1.0, k2=0.01)
+    _, p1e, _, p2e = pa.exact_expressions_3d(mesh, params)
+    bcs = [fd.DirichletBC(W.sub(0), p1e, "on_boundary"), fd.DirichletBC(W.sub(1), p2e, "on_boundary")]
+    exact = pa.solve_dpp_nonlinear(W, params, bcs, solver_parameters=spar.PICARD_MG_SOLVER_PARAMS)
+    inexact = pa.solve_dpp_nonlinear(W, params, bcs, solver_parameters=spar.PICARD_MG_INEXACT_SOLVER_PARAMS)
+    a, b = exact.solution.vector(), inexact.solution.vector()
+    assert np.abs(a - b).max() <= 1e-6 * np.abs(a).max()
+    assert inexact.info["inner_iterations"] < exact.info["inner_iterations"] / 2
+
+
 def test_public_api_solvers_and_errors(gpu_ctx_factory):
     """solve_dpp / solve_dpp_nonlinear through the mirror of the reference API
     (reference solvers/_tests/test_solver.py:24-50)."""

@@ -91,6 +91,14 @@ def test_option_translation():
     cfg, _ = translate_options({**sp.GMRES_PARAMS, **sp.FIELDSPLIT_LU_PARAMS, "fieldsplit_0_pc_type": "jacobi",
                                 "fieldsplit_1_pc_type": "jacobi", "fieldsplit_0_ksp_type": "cg", "fieldsplit_1_ksp_type": "cg"})
     assert cfg.inner_pc_type == _ffi.PC_JACOBI
+    # inexact Picard preset (the benchmark's algorithm): sub-solver norm type and reduction target
+    cfg, _ = translate_options(sp.PICARD_MG_INEXACT_SOLVER_PARAMS, nonlinear=True)
+    assert (cfg.picard, cfg.inner_pc_type, cfg.inner_norm, cfg.mg_smooth) == (1, _ffi.PC_MG, 1, 1)
+    assert cfg.inner_reduction == 0.1 and cfg.inner_rtol == 1e-10
+    cfg, _ = translate_options(sp.PICARD_MG_SOLVER_PARAMS, nonlinear=True)
+    assert cfg.inner_norm == 0 and cfg.inner_reduction == 0.0
+    with pytest.raises(NotImplementedError):
+        translate_options({**sp.PICARD_MG_SOLVER_PARAMS, "fieldsplit_0_ksp_norm_type": "natural"}, nonlinear=True)
     with pytest.warns(UserWarning):
         cfg, info = translate_options(sp.GMRES_ILU_PARAMS)
     assert cfg.pc_type == _ffi.PC_BLOCK2 and any("ILU" in n for n in info["notes"])
