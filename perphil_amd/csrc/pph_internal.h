@@ -213,6 +213,12 @@ void la_axpby(pph_ctx* ctx, double* y, double alpha, const double* x, double bet
 void la_scale(pph_ctx* ctx, double* y, double alpha, int64_t n);
 void la_pointwise_mult(pph_ctx* ctx, double* z, const double* d, const double* r, int64_t n);  // z = d .* r
 void la_sub(pph_ctx* ctx, double* z, const double* a, const double* b, int64_t n);          // z = a - b
+bool la_device_scalars(const pph_ctx* ctx);
+int la_reduce_device(pph_ctx* ctx, int slot, int count);
+int la_fetch_raw(pph_ctx* ctx, int slot, int count);
+void la_cg_update_dev(pph_ctx* ctx, double* x, double* r, const double* p, const double* q, int slot_num, int slot_den,
+                      int64_t n, int slot_out, Seg sg);
+void la_p_update_dev(pph_ctx* ctx, double* p, const double* z, int slot_num, int slot_den, int64_t n);
 void la_shift(pph_ctx* ctx, double* R, double* told, const double* tnew, double sign, int64_t n);  // R += sign (tnew - told); told = tnew
 void la_block2_apply(pph_ctx* ctx, double* z, const double* binv /*[4][n]*/, const double* r, int64_t n);
 // k dots in one pass: out[slot+i] = dot(V_i, w), i < k  (V_i = V + i*ld)

@@ -1172,6 +1172,66 @@ void la_extract_diag_inv(pph_ctx* ctx, const Csr& A, double* dinv) {
                      dinv);
 }
 
+// ---- reduction scalars that stay on the device ---------------------------------------------------
+// A Krylov iteration needs alpha = r.z / p.Ap and beta = r.z_new / r.z only inside the next vector kernels; when
+// those read them from ctx->scal, the host has to see one number per iteration (the residual norm for the
+// convergence test) instead of three.  Possible on a single context and with the RCCL transport (sums are
+// all-reduced on the stream); the callback transport reduces on the host and keeps the host-scalar path.
+bool la_device_scalars(const pph_ctx* ctx) { return ctx->world == 1 || ctx->comm_suspended || ctx->nccl_comm != nullptr; }
+
+int la_reduce_device(pph_ctx* ctx, int slot, int count) {
+  if (ctx->world > 1 && !ctx->comm_suspended && ctx->nccl_comm) return comm_allreduce_device(ctx, ctx->scal.p + slot, count);
+  return PPH_OK;
+}
+
+// host copy of already reduced scalars
+int la_fetch_raw(pph_ctx* ctx, int slot, int count) {
+  PPH_HIP(ctx, hipMemcpyAsync(ctx->h_scal + slot, ctx->scal.p + slot, sizeof(double) * (size_t)count,
+                              hipMemcpyDeviceToHost, ctx->stream));
+  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PPH_OK;
+}
+
+// x += alpha p ; r -= alpha q ; partials of r.r, with alpha = *num / *den read on the device
+__global__ __launch_bounds__(256) void k_cg_update_dev(double* __restrict__ x, double* __restrict__ r,
+                                                       const double* __restrict__ p, const double* __restrict__ q,
+                                                       const double* __restrict__ num, const double* __restrict__ den,
+                                                       int64_t n, Seg sg, double* __restrict__ part) {
+  __shared__ double lds[4];
+  const double alpha = *num / *den;
+  double a = 0.0;
+  EW_LOOP(i, n) {
+    x[i] += alpha * p[i];
+    const double ri = r[i] - alpha * q[i];
+    r[i] = ri;
+    if ((i >= sg.off1 && i < sg.off1 + sg.len1) || (i >= sg.off2 && i < sg.off2 + sg.len2)) a += ri * ri;
+  }
+  a = block_sum(a, lds);
+  if (threadIdx.x == 0) part[blockIdx.x] = a;
+}
+
+void la_cg_update_dev(pph_ctx* ctx, double* x, double* r, const double* p, const double* q, int slot_num, int slot_den,
+                      int64_t n, int slot_out, Seg sg) {
+  double* part = partials(ctx);
+  int grid = ew_grid(n);
+  if (grid > RED_BLOCKS) grid = RED_BLOCKS;
+  hipLaunchKernelGGL(k_cg_update_dev, dim3(grid), dim3(256), 0, ctx->stream, x, r, p, q, ctx->scal.p + slot_num,
+                     ctx->scal.p + slot_den, n, sg, part);
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, ctx->stream, part, grid, ctx->scal.p + slot_out);
+}
+
+// p = z + beta p with beta = *num / *den read on the device
+__global__ void k_p_update_dev(double* __restrict__ p, const double* __restrict__ z, const double* __restrict__ num,
+                               const double* __restrict__ den, int64_t n) {
+  const double beta = *num / *den;
+  EW_LOOP(i, n) p[i] = z[i] + beta * p[i];
+}
+
+void la_p_update_dev(pph_ctx* ctx, double* p, const double* z, int slot_num, int slot_den, int64_t n) {
+  hipLaunchKernelGGL(k_p_update_dev, dim3(ew_grid(n)), dim3(256), 0, ctx->stream, p, z, ctx->scal.p + slot_num,
+                     ctx->scal.p + slot_den, n);
+}
+
 int la_fetch(pph_ctx* ctx, int slot, int count) {
   const bool reduce = ctx->world > 1 && !ctx->comm_suspended;
   // RCCL: sum the partial results on the device, on the stream, before they travel to the host

@@ -106,6 +106,37 @@ static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double*
   if (!(res == res)) { out->breakdown = true; return PPH_OK; }
   if (res <= tol) { out->converged = true; return PPH_OK; }
   apply_pc(r, z);
+  if (la_device_scalars(ctx)) {
+    // alpha and beta live in ctx->scal: the host sees p.Ap (breakdown test) and r.r (convergence test) once per
+    // iteration, in one copy
+    const int sPQ = slot, sRR = slot + 1;
+    int sRZ[2] = {slot + 2, slot + 3};
+    la_mdot_seg(ctx, r, 0, 1, z, sg, sRZ[0]);
+    PPH_TRY(la_reduce_device(ctx, sRZ[0], 1));
+    la_copy(ctx, p, z, n);
+    int its = 0;
+    while (its < max_it) {
+      la_spmv_dot(ctx, A, p, q, sPQ);
+      PPH_TRY(la_reduce_device(ctx, sPQ, 1));
+      la_cg_update_dev(ctx, x, r, p, q, sRZ[0], sPQ, n, sRR, sg);        // x += alpha p ; r -= alpha q ; r.r
+      PPH_TRY(la_reduce_device(ctx, sRR, 1));
+      PPH_TRY(la_fetch_raw(ctx, sPQ, 2));
+      const double pq = ctx->h_scal[sPQ];
+      res = std::sqrt(ctx->h_scal[sRR]);
+      ++its;
+      if (hist && its < hist_cap) hist[its] = res;
+      if (!(pq > 0.0) || !(res == res)) { out->breakdown = true; break; }
+      if (res <= tol) { out->converged = true; break; }
+      apply_pc(r, z);
+      la_mdot_seg(ctx, r, 0, 1, z, sg, sRZ[1]);
+      PPH_TRY(la_reduce_device(ctx, sRZ[1], 1));
+      la_p_update_dev(ctx, p, z, sRZ[1], sRZ[0], n);                      // p = z + (r.z_new / r.z) p
+      std::swap(sRZ[0], sRZ[1]);
+    }
+    out->its = its;
+    out->res = res;
+    return PPH_OK;
+  }
   la_mdot_seg(ctx, r, 0, 1, z, sg, slot);
   PPH_TRY(la_fetch(ctx, slot, 1));
   double rz = ctx->h_scal[slot];
@@ -136,11 +167,6 @@ static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double*
   return PPH_OK;
 }
 
-// ------------------------------------------------------------------------------------------------
-// preconditioned CG.  `dinv` != null selects the fused Jacobi path; otherwise `pc` (may be empty =
-// identity) is called.  x holds the initial guess when warm != 0, else it is zeroed here.
-// work vectors r,z,p,q are supplied by the caller (inner and outer solves use disjoint sets).
-// ------------------------------------------------------------------------------------------------
 static int cg_solve(pph_ctx* ctx, const Csr& A, const double* b, double* x, const double* dinv, const ApplyFn& pc,
                     double rtol, double atol, int max_it, bool warm, double* r, double* z, double* p, double* q,
                     int slot, KspOut* out, double* hist, int hist_cap, double bnorm_hint = -1.0,
