@@ -361,7 +361,8 @@ int mg_setup(pph_ctx* ctx) {
   PPH_REQUIRE(ctx, (int)ctx->mg.size() == nlev, "multigrid hierarchy out of date");
   DevBuf<unsigned long long> lamdev;
   DevBuf<double> mtmp;
-  PPH_TRY(lamdev.alloc(ctx, 2));
+  PPH_TRY(lamdev.alloc(ctx, (size_t)(2 * nlev)));   // spectral bounds of all levels: read back once after the loop
+  PPH_HIP(ctx, hipMemsetAsync(lamdev.p, 0, 2 * nlev * sizeof(unsigned long long), ctx->stream));
   const double coefK[2] = {ctx->a, ctx->c};
   for (int l = 0; l < nlev; ++l) {
     MgLevel& L = ctx->mg[l];
@@ -417,33 +418,38 @@ int mg_setup(pph_ctx* ctx) {
         hipLaunchKernelGGL(k_to_float, dim3(mg_grid(L.nnz)), dim3(256), 0, ctx->stream, L.val32[f].p, L.val[f], L.nnz);
       }
     }
-    PPH_HIP(ctx, hipMemsetAsync(lamdev.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
     if (l == 0 && ctx->diag0_valid) {
       // the fused assembly already produced the fine-level diagonal inverses and bounds
       for (int f = 0; f < 2; ++f)
         PPH_HIP(ctx, hipMemcpyAsync(L.dinv[f].p, ctx->dinv0[f].p, sizeof(double) * (size_t)L.n, hipMemcpyDeviceToDevice,
                                     ctx->stream));
-      PPH_HIP(ctx, hipMemcpyAsync(lamdev.p, ctx->lam0.p, 2 * sizeof(unsigned long long), hipMemcpyDeviceToDevice,
-                                  ctx->stream));
+      PPH_HIP(ctx, hipMemcpyAsync(lamdev.p + 2 * l, ctx->lam0.p, 2 * sizeof(unsigned long long),
+                                  hipMemcpyDeviceToDevice, ctx->stream));
     } else
     for (int f = 0; f < 2; ++f)
       hipLaunchKernelGGL(k_diag_lam, dim3(mg_grid(L.n * 8)), dim3(256), 0, ctx->stream, L.rowptr, L.col, L.val[f], L.n,
-                         L.dinv[f].p, lamdev.p + f);
-    unsigned long long bits[2];
-    PPH_HIP(ctx, hipMemcpyAsync(bits, lamdev.p, sizeof(bits), hipMemcpyDeviceToHost, ctx->stream));
-    PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int f = 0; f < 2; ++f) {
-      double v;
-      memcpy(&v, &bits[f], sizeof(double));
-      if (dist && !L.replicated) PPH_TRY(comm_max_double(ctx, v, &v));
-      L.lam[f] = v;
-      PPH_REQUIRE(ctx, v > 0.0 && v == v, "multigrid level %d: bad spectral bound %g", l, v);
-    }
+                         L.dinv[f].p, lamdev.p + 2 * l + f);
     if (l > 0) { PPH_TRY(L.x.alloc(ctx, (size_t)L.n)); PPH_TRY(L.b.alloc(ctx, (size_t)L.n)); }
     PPH_TRY(L.r.alloc(ctx, (size_t)L.n));
     PPH_TRY(L.d.alloc(ctx, (size_t)L.n));
     PPH_TRY(L.t.alloc(ctx, (size_t)L.n));
     if (l == nlev - 1) PPH_TRY(L.w.alloc(ctx, (size_t)L.n));
+  }
+  {
+    std::vector<unsigned long long> bits((size_t)(2 * nlev));
+    PPH_HIP(ctx, hipMemcpyAsync(bits.data(), lamdev.p, sizeof(unsigned long long) * bits.size(), hipMemcpyDeviceToHost,
+                                ctx->stream));
+    PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int l = 0; l < nlev; ++l) {
+      MgLevel& L = ctx->mg[l];
+      for (int f = 0; f < 2; ++f) {
+        double v;
+        memcpy(&v, &bits[(size_t)(2 * l + f)], sizeof(double));
+        if (dist && !L.replicated) PPH_TRY(comm_max_double(ctx, v, &v));
+        L.lam[f] = v;
+        PPH_REQUIRE(ctx, v > 0.0 && v == v, "multigrid level %d: bad spectral bound %g", l, v);
+      }
+    }
   }
   lamdev.release();
   mtmp.release();
