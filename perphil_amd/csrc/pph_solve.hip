@@ -105,15 +105,14 @@ static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double*
   if (hist && hist_cap > 0) hist[0] = res;
   if (!(res == res)) { out->breakdown = true; return PPH_OK; }
   if (res <= tol) { out->converged = true; return PPH_OK; }
-  apply_pc(r, z);
   if (la_device_scalars(ctx)) {
     // alpha and beta live in ctx->scal: the host sees p.Ap (breakdown test) and r.r (convergence test) once per
     // iteration, in one copy
     const int sPQ = slot, sRR = slot + 1;
     int sRZ[2] = {slot + 2, slot + 3};
-    la_mdot_seg(ctx, r, 0, 1, z, sg, sRZ[0]);
+    apply_pc(r, p);                                   // first direction p = z_0: written in place
+    la_mdot_seg(ctx, r, 0, 1, p, sg, sRZ[0]);
     PPH_TRY(la_reduce_device(ctx, sRZ[0], 1));
-    la_copy(ctx, p, z, n);
     int its = 0;
     while (its < max_it) {
       la_spmv_dot(ctx, A, p, q, sPQ);
@@ -137,6 +136,7 @@ static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double*
     out->res = res;
     return PPH_OK;
   }
+  apply_pc(r, z);
   la_mdot_seg(ctx, r, 0, 1, z, sg, slot);
   PPH_TRY(la_fetch(ctx, slot, 1));
   double rz = ctx->h_scal[slot];
