@@ -826,3 +826,23 @@ def test_config2_64cubed_monolithic_cg(gpu_ctx_factory, pc):
     assert np.linalg.norm(res) <= 1e-7 * np.linalg.norm(r)
     xg, ig, _ = ctx.solve(_cfg(pc_type=f.PC_FIELDSPLIT, inner_pc_type=f.PC_MG, inner_rtol=1e-12, rtol=1e-10))
     assert ig.converged and np.abs(xs - xg).max() <= 1e-6 * np.abs(xg).max()
+
+
+@pytest.mark.gpu
+def test_option_paths_agree(gpu_ctx_factory):
+    """Alternative code paths kept behind pph_set_option give the same solve: host-driven coarsest CG vs the
+    single-workgroup device CG, software-pipelined SpMV (17) vs the default kernel."""
+    f = _ffi()
+    ref = None
+    for opts in ({}, {"coarse_on_device": 0}, {"spmv_kernel": 17}, {"spmv_kernel": 1}):
+        ctx, om, osys = _setup(gpu_ctx_factory, 3, o.CELL_HEX, 12, 8, 16)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        xs, info, _ = ctx.solve(_cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_MG, inner_rtol=1e-10,
+                                     inner_reduction=1e-1, inner_norm=1, mg_smooth=1, picard_rtol=1e-9))
+        assert info.converged
+        if ref is None:
+            ref = (xs, info.iterations, info.inner_iterations)
+        else:
+            assert (info.iterations, info.inner_iterations) == ref[1:], opts
+            np.testing.assert_allclose(xs, ref[0], rtol=0, atol=1e-11 * np.abs(ref[0]).max())
