@@ -268,7 +268,9 @@ def main():
     # measured offline with tools/pmc_summarize.py and committed under profiles/ (cannot be sampled in-process)
     traffic = None
     pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_spmv_bench256.json")
-    if os.path.exists(pmc_file) and N == 256 and world == 1:
+    defaults = (args.inner_norm == 1 and args.inner_reduction == 1e-1 and args.smooth == 1 and args.inner_rtol == 1e-10
+                and args.asm_kernel == 2 and not args.set)
+    if os.path.exists(pmc_file) and N == 256 and world == 1 and defaults:
         try:
             with open(pmc_file) as f:
                 traffic = json.load(f).get("traffic_bytes_per_launch")
