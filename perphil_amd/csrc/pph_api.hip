@@ -177,6 +177,7 @@ int pph_mesh_build(pph_ctx* ctx, int dim, int cell_kind, int nx, int ny, int nz,
     PPH_TRY(ctx->g[f].alloc(ctx, (size_t)m.n));
     PPH_HIP(ctx, hipMemsetAsync(ctx->bcmask[f].p, 0, (size_t)m.n, ctx->stream));
     ctx->bc_dirty = true;
+    ctx->bc_epoch++;
     PPH_HIP(ctx, hipMemsetAsync(ctx->g[f].p, 0, sizeof(double) * (size_t)m.n, ctx->stream));
     const int64_t plane = (int64_t)m.px * m.py;
     if (ctx->ghost_lo)
@@ -252,6 +253,7 @@ int pph_set_dirichlet(pph_ctx* ctx, int field, const int64_t* nodes, const doubl
   }
   PPH_HIP(ctx, hipMemcpyAsync(ctx->bcmask[field].p, hmask.data(), (size_t)n, hipMemcpyHostToDevice, ctx->stream));
   ctx->bc_dirty = true;
+  ctx->bc_epoch++;
   PPH_HIP(ctx, hipMemcpyAsync(ctx->g[field].p, hg.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice,
                               ctx->stream));
   PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));

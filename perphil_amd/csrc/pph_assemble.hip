@@ -646,7 +646,9 @@ struct FuseArgs {
   double *dinv1, *dinv2;           // [n] each
   unsigned long long* lam;         // [2] max_i sum_j |a_ij| / |a_ii| as the bit pattern of a non-negative double
   int keep_km;                     // also store K and M
+  int same;                        // both fields carry the same Dirichlet set (one mask gather per entry)
 };
+// A12 / A21 null: coupling blocks not wanted; rhs null: no lifting (multigrid coarse levels: g1, g2, u0 unused)
 
 template <int DIM, bool FUSED = false, bool CLOSED = false>
 __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__ cells,
@@ -788,9 +790,11 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__
           double o11 = fa.a * kv + fa.b * mv, o22 = fa.c * kv + fa.b * mv, o12 = -fa.b * mv, o21 = o12;
           if (near) {
             // same arithmetic as k_lift_rhs / k_blocks: ghost rows empty, Dirichlet rows identity, constrained columns zero
-            const bool c1 = (fa.m1[j] & 1) != 0, c2 = fa.A21 ? (fa.m2[j] & 1) != 0 : c1;
-            const double v1 = fa.g1[j], v2 = fa.g2[j];
-            lK1 += kv * v1; lK2 += kv * v2; lM += mv * (v1 - v2);
+            const bool c1 = (fa.m1[j] & 1) != 0, c2 = fa.same ? c1 : (fa.m2[j] & 1) != 0;
+            if (fa.rhs) {
+              const double v1 = fa.g1[j], v2 = fa.g2[j];
+              lK1 += kv * v1; lK2 += kv * v2; lM += mv * (v1 - v2);
+            }
             o11 = (r1 & 2) ? 0.0 : (r1 & 1) ? (diag ? 1.0 : 0.0) : (c1 ? 0.0 : o11);
             o22 = (r2 & 2) ? 0.0 : (r2 & 1) ? (diag ? 1.0 : 0.0) : (c2 ? 0.0 : o22);
             o12 = (r1 != 0 || c2) ? 0.0 : -fa.b * mv;
@@ -798,7 +802,7 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__
           }
           fa.A11[k] = o11;
           fa.A22[k] = o22;
-          fa.A12[k] = o12;
+          if (fa.A12) fa.A12[k] = o12;
           if (fa.A21) fa.A21[k] = o21;
           s11 += fabs(o11); s22 += fabs(o22);
           if (diag) { d11 = o11; d22 = o22; }
@@ -819,10 +823,12 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__
           const double q1 = s11 * fabs(i1), q2 = s22 * fabs(i2);
           best1 = q1 > best1 ? q1 : best1;
           best2 = q2 > best2 ? q2 : best2;
-          fa.rhs[node] = (!near || r1 != 0) ? 0.0 : -(fa.a * lK1 + fa.b * lM);
-          fa.rhs[n + node] = (!near || r2 != 0) ? 0.0 : -(fa.c * lK2 - fa.b * lM);
-          fa.u0[node] = near ? fa.g1[node] : 0.0;
-          fa.u0[n + node] = near ? fa.g2[node] : 0.0;
+          if (fa.rhs) {
+            fa.rhs[node] = (!near || r1 != 0) ? 0.0 : -(fa.a * lK1 + fa.b * lM);
+            fa.rhs[n + node] = (!near || r2 != 0) ? 0.0 : -(fa.c * lK2 - fa.b * lM);
+            fa.u0[node] = near ? fa.g1[node] : 0.0;
+            fa.u0[n + node] = near ? fa.g2[node] : 0.0;
+          }
         }
       }
     }
@@ -973,9 +979,11 @@ __global__ __launch_bounds__(256) void k_asm_simplex_gather(const int32_t* __res
           const bool diag = (jc == (int32_t)node);
           double o11 = fa.a * kv + fa.b * mv, o22 = fa.c * kv + fa.b * mv, o12 = -fa.b * mv, o21 = o12;
           if (near) {
-            const bool c1 = (fa.m1[jc] & 1) != 0, c2 = fa.A21 ? (fa.m2[jc] & 1) != 0 : c1;
-            const double v1 = fa.g1[jc], v2 = fa.g2[jc];
-            lK1 += kv * v1; lK2 += kv * v2; lM += mv * (v1 - v2);
+            const bool c1 = (fa.m1[jc] & 1) != 0, c2 = fa.same ? c1 : (fa.m2[jc] & 1) != 0;
+            if (fa.rhs) {
+              const double v1 = fa.g1[jc], v2 = fa.g2[jc];
+              lK1 += kv * v1; lK2 += kv * v2; lM += mv * (v1 - v2);
+            }
             o11 = (r1 & 2) ? 0.0 : (r1 & 1) ? (diag ? 1.0 : 0.0) : (c1 ? 0.0 : o11);
             o22 = (r2 & 2) ? 0.0 : (r2 & 1) ? (diag ? 1.0 : 0.0) : (c2 ? 0.0 : o22);
             o12 = (r1 != 0 || c2) ? 0.0 : -fa.b * mv;
@@ -983,7 +991,7 @@ __global__ __launch_bounds__(256) void k_asm_simplex_gather(const int32_t* __res
           }
           fa.A11[s + q] = o11;
           fa.A22[s + q] = o22;
-          fa.A12[s + q] = o12;
+          if (fa.A12) fa.A12[s + q] = o12;
           if (fa.A21) fa.A21[s + q] = o21;
           s11 += fabs(o11); s22 += fabs(o22);
           if (diag) { d11 = o11; d22 = o22; }
@@ -994,10 +1002,12 @@ __global__ __launch_bounds__(256) void k_asm_simplex_gather(const int32_t* __res
       const double q1 = s11 * fabs(i1), q2 = s22 * fabs(i2);
       best1 = q1 > best1 ? q1 : best1;
       best2 = q2 > best2 ? q2 : best2;
-      fa.rhs[node] = (!near || r1 != 0) ? 0.0 : -(fa.a * lK1 + fa.b * lM);
-      fa.rhs[n + node] = (!near || r2 != 0) ? 0.0 : -(fa.c * lK2 - fa.b * lM);
-      fa.u0[node] = near ? fa.g1[node] : 0.0;
-      fa.u0[n + node] = near ? fa.g2[node] : 0.0;
+      if (fa.rhs) {
+        fa.rhs[node] = (!near || r1 != 0) ? 0.0 : -(fa.a * lK1 + fa.b * lM);
+        fa.rhs[n + node] = (!near || r2 != 0) ? 0.0 : -(fa.c * lK2 - fa.b * lM);
+        fa.u0[node] = near ? fa.g1[node] : 0.0;
+        fa.u0[n + node] = near ? fa.g2[node] : 0.0;
+      }
     }
   }
   if constexpr (FUSED) {
@@ -1380,34 +1390,13 @@ bool pph_can_fuse_assembly(const pph_ctx* ctx) {
   return ctx->asm_kernel != 0;   // simplices: the node-centred gather kernel
 }
 
-int pph_launch_assemble_fused(pph_ctx* ctx, int monolithic) {
-  MeshData& mesh = ctx->mesh;
-  const int64_t n = ctx->n;
-  PPH_TRY(blocks_prepare(ctx));
-  if (ctx->asm_keep_km) {
-    PPH_TRY(mesh.K.alloc(ctx, (size_t)mesh.nnzb));
-    PPH_TRY(mesh.M.alloc(ctx, (size_t)mesh.nnzb));
-  }
-  PPH_TRY(ctx->dinv0[0].alloc(ctx, (size_t)n));
-  PPH_TRY(ctx->dinv0[1].alloc(ctx, (size_t)n));
-  PPH_TRY(ctx->lam0.alloc(ctx, 2));
-  PPH_HIP(ctx, hipMemsetAsync(ctx->lam0.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+// element rows (multilinear cells) + the fused node-centred pass on any level mesh
+int pph_launch_fused_kernels(pph_ctx* ctx, MeshData& mesh, const FuseArgs& fa, double* Kp, double* Mp) {
   const bool multilinear = (mesh.kind == PPH_CELL_QUAD || mesh.kind == PPH_CELL_HEX);
   if (multilinear) PPH_TRY(mesh.erows.alloc(ctx, (size_t)mesh.ncell * mesh.m * 2 * mesh.m));
   const int cpb = 256 / mesh.m;
   int64_t nb1 = ceil_div64(mesh.ncell, cpb), nb2 = ceil_div64(mesh.n, cpb);
   int g1 = (int)(nb1 < 256 * 16 ? nb1 : 256 * 16), g2 = (int)(nb2 < 256 * 16 ? nb2 : 256 * 16);
-  FuseArgs fa;
-  fa.m1 = ctx->bcmask[0].p; fa.m2 = ctx->bcmask[1].p; fa.near = ctx->rownear.p;
-  fa.g1 = ctx->g[0].p; fa.g2 = ctx->g[1].p;
-  fa.a = ctx->a; fa.b = ctx->b; fa.c = ctx->c;
-  fa.A11 = ctx->A11.p; fa.A22 = ctx->A22.p; fa.A12 = ctx->A12.p; fa.A21 = ctx->a21_alias ? nullptr : ctx->A21.p;
-  fa.rhs = ctx->rhs.p; fa.u0 = ctx->u0.p;
-  fa.dinv1 = ctx->dinv0[0].p; fa.dinv2 = ctx->dinv0[1].p;
-  fa.lam = ctx->lam0.p;
-  fa.keep_km = ctx->asm_keep_km;
-  double* Kp = ctx->asm_keep_km ? mesh.K.p : nullptr;
-  double* Mp = ctx->asm_keep_km ? mesh.M.p : nullptr;
   if (!multilinear) {
     int64_t nbs = ceil_div64(mesh.n, 256);
     const int gs = (int)(nbs < 256 * 32 ? nbs : 256 * 32);
@@ -1438,6 +1427,58 @@ int pph_launch_assemble_fused(pph_ctx* ctx, int monolithic) {
       hipLaunchKernelGGL((k_gather_rows<3, true, false>), dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
                          mesh.rowptr.p, mesh.col.p, Kp, Mp, mesh.nx, mesh.ny, mesh.nzl, mesh.px, mesh.py, mesh.n, fa);
   }
+  PPH_HIP(ctx, hipGetLastError());
+  return PPH_OK;
+}
+
+// Dirichlet-eliminated operators coefK[f] K + coefM M (f = 0, 1) of a multigrid level straight from the element
+// rows, with the smoother's diagonal inverses and spectral bounds (no K/M, no coupling blocks, no lifting)
+int pph_launch_level_operators(pph_ctx* ctx, MeshData& mesh, const uint8_t* m1, const uint8_t* m2, const uint8_t* near,
+                               int same, double coefK1, double coefK2, double coefM, double* A1, double* A2,
+                               double* dinv1, double* dinv2, unsigned long long* lam) {
+  FuseArgs fa;
+  fa.m1 = m1; fa.m2 = m2; fa.near = near;
+  fa.g1 = nullptr; fa.g2 = nullptr;
+  fa.a = coefK1; fa.b = coefM; fa.c = coefK2;
+  fa.A11 = A1; fa.A22 = A2; fa.A12 = nullptr; fa.A21 = nullptr;
+  fa.rhs = nullptr; fa.u0 = nullptr;
+  fa.dinv1 = dinv1; fa.dinv2 = dinv2;
+  fa.lam = lam;
+  fa.keep_km = 0;
+  fa.same = same;
+  return pph_launch_fused_kernels(ctx, mesh, fa, nullptr, nullptr);
+}
+
+void pph_launch_row_near(pph_ctx* ctx, const MeshData& mesh, const uint8_t* m1, const uint8_t* m2, uint8_t* out) {
+  int64_t nbn = ceil_div64(mesh.n * 8, 256);
+  hipLaunchKernelGGL(k_row_near, dim3((int)(nbn < 4096 ? nbn : 4096)), dim3(256), 0, ctx->stream, mesh.rowptr.p, mesh.col.p,
+                     m1, m2, mesh.n, out);
+}
+
+int pph_launch_assemble_fused(pph_ctx* ctx, int monolithic) {
+  MeshData& mesh = ctx->mesh;
+  const int64_t n = ctx->n;
+  PPH_TRY(blocks_prepare(ctx));
+  if (ctx->asm_keep_km) {
+    PPH_TRY(mesh.K.alloc(ctx, (size_t)mesh.nnzb));
+    PPH_TRY(mesh.M.alloc(ctx, (size_t)mesh.nnzb));
+  }
+  PPH_TRY(ctx->dinv0[0].alloc(ctx, (size_t)n));
+  PPH_TRY(ctx->dinv0[1].alloc(ctx, (size_t)n));
+  PPH_TRY(ctx->lam0.alloc(ctx, 2));
+  PPH_HIP(ctx, hipMemsetAsync(ctx->lam0.p, 0, 2 * sizeof(unsigned long long), ctx->stream));
+  FuseArgs fa;
+  fa.m1 = ctx->bcmask[0].p; fa.m2 = ctx->bcmask[1].p; fa.near = ctx->rownear.p;
+  fa.g1 = ctx->g[0].p; fa.g2 = ctx->g[1].p;
+  fa.a = ctx->a; fa.b = ctx->b; fa.c = ctx->c;
+  fa.A11 = ctx->A11.p; fa.A22 = ctx->A22.p; fa.A12 = ctx->A12.p; fa.A21 = ctx->a21_alias ? nullptr : ctx->A21.p;
+  fa.rhs = ctx->rhs.p; fa.u0 = ctx->u0.p;
+  fa.dinv1 = ctx->dinv0[0].p; fa.dinv2 = ctx->dinv0[1].p;
+  fa.lam = ctx->lam0.p;
+  fa.keep_km = ctx->asm_keep_km;
+  fa.same = ctx->a21_alias ? 1 : 0;
+  PPH_TRY(pph_launch_fused_kernels(ctx, mesh, fa, ctx->asm_keep_km ? mesh.K.p : nullptr,
+                                   ctx->asm_keep_km ? mesh.M.p : nullptr));
   PPH_HIP(ctx, hipGetLastError());
   mesh.km_valid = ctx->asm_keep_km != 0;
   ctx->diag0_valid = true;

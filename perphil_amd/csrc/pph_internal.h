@@ -102,6 +102,8 @@ struct MgLevel {
   DevBuf<float> val32[2];        // fp32 copies of val[] for the smoother / residual SpMVs of the V-cycle
   DevBuf<double> dinv[2];
   DevBuf<uint8_t> mask[2];       // per field: non-zero where the dof is constrained
+  DevBuf<uint8_t> rownear;       // rows that need the masks (fused level operators); follows the masks
+  int bc_epoch = -1;             // ctx->bc_epoch the masks / rownear were derived from
   const uint8_t* maskp[2] = {nullptr, nullptr};
   DevBuf<double> x, b, r, d, t, w;  // work vectors of the V-cycle (x, b unused on level 0)
   const MeshData* geom = nullptr;  // slab geometry of this level (level 0: the context's mesh)
@@ -130,6 +132,7 @@ struct pph_ctx {
   int asm_keep_km = 0;                  // 1: the fused pass also stores K and M (two more 8 B/nnz streams); 0: they are integrated on demand (pph_get_csr K/M, Darcy projection)
   DevBuf<uint8_t> rownear;              // 1: the row is constrained / ghost or has a constrained column (needs the masks)
   bool bc_dirty = true;                 // masks changed since rownear / a21_alias were derived from them
+  int bc_epoch = 0;                     // counts changes of the Dirichlet sets (multigrid levels cache injected masks)
   DevBuf<double> g[2];                  // per field Dirichlet values (dense, 0 elsewhere)
   DevBuf<double> A11, A22, A12, A21;    // eliminated blocks on the scalar pattern
   bool a21_alias = false;               // both fields share one Dirichlet set: A21 == A12, A21 not stored
@@ -200,6 +203,10 @@ int pph_launch_assemble_KM(pph_ctx* ctx, MeshData& mesh);
 int pph_launch_blocks(pph_ctx* ctx, int monolithic);
 bool pph_can_fuse_assembly(const pph_ctx* ctx);
 int pph_launch_assemble_fused(pph_ctx* ctx, int monolithic);
+int pph_launch_level_operators(pph_ctx* ctx, MeshData& mesh, const uint8_t* m1, const uint8_t* m2, const uint8_t* near,
+                               int same, double coefK1, double coefK2, double coefM, double* A1, double* A2,
+                               double* dinv1, double* dinv2, unsigned long long* lam);
+void pph_launch_row_near(pph_ctx* ctx, const MeshData& mesh, const uint8_t* m1, const uint8_t* m2, uint8_t* out);
 
 // linear algebra on the context stream; all results that feed control flow go through ctx->scal
 void la_spmv(pph_ctx* ctx, const Csr& A, const double* x, double* y);

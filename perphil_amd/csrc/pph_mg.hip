@@ -366,6 +366,7 @@ int mg_setup(pph_ctx* ctx) {
   const double coefK[2] = {ctx->a, ctx->c};
   for (int l = 0; l < nlev; ++l) {
     MgLevel& L = ctx->mg[l];
+    bool level_fused = false;   // dinv / spectral bound of this level already produced by the fused pass
     L.replicated = dist && l >= ndist;
     if (l == 0) {
       L.rowptr = fm.rowptr.p; L.col = fm.col.p; L.val[0] = ctx->A11.p; L.val[1] = ctx->A22.p;
@@ -381,7 +382,9 @@ int mg_setup(pph_ctx* ctx) {
       else if (L.replicated || !dist) { m.z0 = 0; m.nzl = m.nz; m.glo = m.ghi = 0; }
       else { m.glo = fm.glo; m.ghi = fm.ghi; m.z0 = (c0 >> l) - m.glo; m.nzl = (c1 >> l) - m.z0; }
       if (build) PPH_TRY(pph_launch_mesh(ctx, m));
-      if (!m.km_valid) {
+      // level operators straight from the element rows (fused pass) or from K, M of this level (two-step path)
+      const bool fuse_lv = pph_can_fuse_assembly(ctx);
+      if (!fuse_lv && !m.km_valid) {
         PPH_TRY(pph_launch_assemble_KM(ctx, m));
         m.km_valid = true;
       }
@@ -390,19 +393,38 @@ int mg_setup(pph_ctx* ctx) {
       L.gz0 = m.z0;
       L.own_lo = m.z0 + m.glo; L.own_hi = m.z0 + m.pzl - m.ghi;
       const TGeom tg = tgeom(F, L);
-      PPH_TRY(mtmp.alloc(ctx, (size_t)L.n));
+      // injected masks depend on the Dirichlet sets only: rebuilt when those (or the hierarchy) change
+      const bool masks_stale = build || L.bc_epoch != ctx->bc_epoch;
+      if (masks_stale) {
+        PPH_TRY(mtmp.alloc(ctx, (size_t)L.n));
+        for (int f = 0; f < 2; ++f) {
+          PPH_TRY(L.mask[f].alloc(ctx, (size_t)L.n));
+          hipLaunchKernelGGL(k_inject_mask, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, mtmp.p, F.maskp[f], tg);
+          if (L.replicated && !F.replicated) PPH_TRY(la_allreduce_vec(ctx, mtmp.p, L.n));
+          else if (dist && !L.replicated) PPH_TRY(la_halo(ctx, m, mtmp.p));
+          hipLaunchKernelGGL(k_mask_from_double, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, L.mask[f].p, mtmp.p, L.n,
+                             m.plane(), m.glo, m.ghi);
+        }
+      }
       for (int f = 0; f < 2; ++f) {
-        PPH_TRY(L.mask[f].alloc(ctx, (size_t)L.n));
-        hipLaunchKernelGGL(k_inject_mask, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, mtmp.p, F.maskp[f], tg);
-        if (L.replicated && !F.replicated) PPH_TRY(la_allreduce_vec(ctx, mtmp.p, L.n));
-        else if (dist && !L.replicated) PPH_TRY(la_halo(ctx, m, mtmp.p));
-        hipLaunchKernelGGL(k_mask_from_double, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, L.mask[f].p, mtmp.p, L.n,
-                           m.plane(), m.glo, m.ghi);
         L.maskp[f] = L.mask[f].p;
         PPH_TRY(L.own_val[f].alloc(ctx, (size_t)L.nnz));
-        pph_launch_scalar_block(ctx, m, L.maskp[f], coefK[f], ctx->b, L.own_val[f].p);
         L.val[f] = L.own_val[f].p;
       }
+      if (fuse_lv) {
+        if (masks_stale) {
+          PPH_TRY(L.rownear.alloc(ctx, (size_t)L.n));
+          pph_launch_row_near(ctx, m, L.maskp[0], L.maskp[1], L.rownear.p);
+        }
+        for (int f = 0; f < 2; ++f) PPH_TRY(L.dinv[f].alloc(ctx, (size_t)L.n));
+        PPH_TRY(pph_launch_level_operators(ctx, m, L.maskp[0], L.maskp[1], L.rownear.p, ctx->a21_alias ? 1 : 0, coefK[0],
+                                           coefK[1], ctx->b, L.own_val[0].p, L.own_val[1].p, L.dinv[0].p, L.dinv[1].p,
+                                           lamdev.p + 2 * l));
+        level_fused = true;
+      } else {
+        for (int f = 0; f < 2; ++f) pph_launch_scalar_block(ctx, m, L.maskp[f], coefK[f], ctx->b, L.own_val[f].p);
+      }
+      L.bc_epoch = ctx->bc_epoch;
     }
     if (l == 0) {
       L.gz0 = fm.z0;
@@ -425,7 +447,7 @@ int mg_setup(pph_ctx* ctx) {
                                     ctx->stream));
       PPH_HIP(ctx, hipMemcpyAsync(lamdev.p + 2 * l, ctx->lam0.p, 2 * sizeof(unsigned long long),
                                   hipMemcpyDeviceToDevice, ctx->stream));
-    } else
+    } else if (!level_fused)
     for (int f = 0; f < 2; ++f)
       hipLaunchKernelGGL(k_diag_lam, dim3(mg_grid(L.n * 8)), dim3(256), 0, ctx->stream, L.rowptr, L.col, L.val[f], L.n,
                          L.dinv[f].p, lamdev.p + 2 * l + f);
