@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void k_spmv_wide_u(const int64_t* __restrict__
   double acc = 0.0;
   for (int64_t ch0 = blockIdx.x; ch0 < nchunks; ch0 += (int64_t)UR * gridDim.x) {
     int64_t row[UR], s[UR], e[UR], base[UR];
-    double sum[UR];
+    double sum[UR], bv[UR], xr[UR];   // epilogue operands requested with the row pointers (see k_spmv_wide)
 #pragma unroll
     for (int u = 0; u < UR; ++u) {
       const int64_t ch = ch0 + (int64_t)u * gridDim.x;
@@ -517,6 +517,8 @@ __global__ __launch_bounds__(256) void k_spmv_wide_u(const int64_t* __restrict__
       if (!ok) row[u] = -1;
       s[u] = ok ? rowptr[row[u]] : 0;
       e[u] = ok ? rowptr[row[u] + 1] : 0;
+      bv[u] = (ok && bvec) ? bvec[row[u]] : 0.0;
+      xr[u] = (ok && DOT) ? x[row[u]] : 0.0;
       sum[u] = 0.0;
     }
 #pragma unroll
@@ -564,8 +566,8 @@ __global__ __launch_bounds__(256) void k_spmv_wide_u(const int64_t* __restrict__
 #pragma unroll
       for (int o = G / 2; o > 0; o >>= 1) t += __shfl_down(t, o, G);
       if (sub == 0 && row[u] >= 0) {
-        y[row[u]] = bvec ? bvec[row[u]] - t : t;
-        if (DOT) acc += t * x[row[u]];
+        y[row[u]] = bvec ? bv[u] - t : t;
+        if (DOT) acc += t * xr[u];
       }
     }
   }
