@@ -171,7 +171,8 @@ int pph_bw_probe(pph_ctx* ctx, int64_t bytes, int mode, int blocks, double* ms_o
  * replaces: l2_error() / h1_seminorm_error() (reference src/perphil/utils/postprocessing.py:89-124) for
  * the manufactured pressures of src/perphil/utils/manufactured_solutions.py:39-51 (2D), :87-88 (3D).
  * `nodal_host`: the n nodal values of p1_h (field 0) or p2_h (field 1); nq-point Gauss rule per
- * direction (1..8) on quadrilateral / hexahedral cells. */
+ * direction (1..8) on quadrilateral / hexahedral cells, collapsed onto the simplex (Duffy transform) on
+ * triangles / tetrahedra. */
 int pph_error_norms_mms(pph_ctx* ctx, int field, const double* nodal_host, double k1, double k2, double beta,
                         double mu, int nq, double* l2_out, double* h1s_out);
 

@@ -503,9 +503,34 @@ def slice_along_x(mesh: Mesh, field: np.ndarray, x_value: float) -> Tuple[np.nda
 # error norms (utils/postprocessing.py:89-124) with a high-order tensor Gauss rule
 # --------------------------------------------------------------------------------------
 def error_norms(mesh: Mesh, ph: np.ndarray, exact: Callable, exact_grad: Callable, nq: int = 6) -> Tuple[float, float]:
-    """L2 and H1-seminorm errors of the nodal CG-1 field ``ph`` on quad/hex meshes."""
-    assert mesh.kind in (CELL_QUAD, CELL_HEX)
+    """L2 and H1-seminorm errors of the nodal CG-1 field ``ph``: tensor Gauss rule on quads / hexes, the same rule
+    collapsed onto the simplex (Duffy transform) on triangles / tetrahedra."""
     d = mesh.dim
+    if mesh.kind in (CELL_TRI, CELL_TET):
+        pts, wts = np.polynomial.legendre.leggauss(nq)
+        pts, wts = 0.5 * (pts + 1.0), 0.5 * wts
+        X = mesh.coords[mesh.cells]
+        U = ph[mesh.cells]
+        E = X[:, 1:, :] - X[:, :1, :]
+        dU = U[:, 1:] - U[:, :1]
+        gh = np.linalg.solve(E, dU[:, :, None])[:, :, 0]
+        detE = np.abs(np.linalg.det(E))
+        l2 = h1 = 0.0
+        grids = np.meshgrid(*([np.arange(nq)] * d), indexing="ij")
+        for q in zip(*[g.ravel() for g in grids]):
+            u_, v_ = pts[q[0]], pts[q[1]]
+            lam = [u_, v_ * (1.0 - u_)]
+            w = wts[q[0]] * wts[q[1]] * (1.0 - u_)
+            if d == 3:
+                w_ = pts[q[2]]
+                lam.append(w_ * (1.0 - u_) * (1.0 - v_))
+                w *= wts[q[2]] * (1.0 - u_) * (1.0 - v_)
+            lam = np.array(lam)
+            xq = X[:, 0, :] + np.einsum("r,crd->cd", lam, E)
+            uh = U[:, 0] + dU @ lam
+            l2 += float(np.sum(w * detE * (uh - exact(xq)) ** 2))
+            h1 += float(np.sum(w * detE * np.sum((gh - exact_grad(xq)) ** 2, axis=1)))
+        return math.sqrt(l2), math.sqrt(h1)
     pts, wts = np.polynomial.legendre.leggauss(nq)
     X = mesh.coords[mesh.cells]
     U = ph[mesh.cells]

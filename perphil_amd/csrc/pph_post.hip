@@ -3,8 +3,9 @@
 // Replaces l2_error / h1_seminorm_error (reference src/perphil/utils/postprocessing.py:89-124, which
 // assemble ||p_h - p||^2 and |p_h - p|_1^2 with Firedrake) for the exact solutions of
 // src/perphil/utils/manufactured_solutions.py:39-51 (2D) and :87-88 (3D) — SURVEY.md §8f rank 2.
-// One thread per multilinear cell, nq-point Gauss rule per direction on the isoparametric map; the
-// exact pressure and its gradient are evaluated in closed form at every quadrature point.
+// One thread per cell, nq-point Gauss rule per direction on the isoparametric map (multilinear cells) or collapsed
+// onto the simplex (P1 cells); the exact pressure and its gradient are evaluated in closed form at every
+// quadrature point.
 #include "pph_internal.h"
 #include <cmath>
 
@@ -156,6 +157,113 @@ __global__ __launch_bounds__(256) void k_error_norms(const int32_t* __restrict__
   }
 }
 
+// P1 simplices (left-diagonal triangles, Kuhn tetrahedra): constant gradient of p_h per cell; quadrature by the
+// collapsed (Duffy) tensor Gauss rule: lambda_1 = u, lambda_2 = v (1 - u), lambda_3 = w (1 - u)(1 - v) on [0,1]^d.
+template <int DIM>
+__global__ __launch_bounds__(256) void k_error_norms_simplex(const int32_t* __restrict__ cells, const double* __restrict__ cx,
+                                                             const double* __restrict__ cy, const double* __restrict__ cz,
+                                                             const double* __restrict__ u, GaussRule g, MmsPar p,
+                                                             int64_t ncell, double* __restrict__ part) {
+  constexpr int NB = DIM + 1;
+  __shared__ double lds[4];
+  const double PI = 3.14159265358979323846;
+  double l2 = 0.0, h1 = 0.0;
+  for (int64_t cell = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; cell < ncell;
+       cell += (int64_t)gridDim.x * blockDim.x) {
+    double X[NB][DIM], U[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int32_t nd = cells[cell * NB + b];
+      X[b][0] = cx[nd];
+      X[b][1] = cy[nd];
+      if constexpr (DIM == 3) X[b][2] = cz[nd];
+      U[b] = u[nd];
+    }
+    double E[DIM][DIM], dU[DIM], gh[DIM], det;
+#pragma unroll
+    for (int r = 0; r < DIM; ++r) {
+      dU[r] = U[r + 1] - U[0];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) E[r][d] = X[r + 1][d] - X[0][d];
+    }
+    if constexpr (DIM == 2) {
+      det = E[0][0] * E[1][1] - E[0][1] * E[1][0];
+      gh[0] = (E[1][1] * dU[0] - E[0][1] * dU[1]) / det;
+      gh[1] = (-E[1][0] * dU[0] + E[0][0] * dU[1]) / det;
+    } else {
+      const double c00 = E[1][1] * E[2][2] - E[1][2] * E[2][1];
+      const double c01 = E[1][2] * E[2][0] - E[1][0] * E[2][2];
+      const double c02 = E[1][0] * E[2][1] - E[1][1] * E[2][0];
+      det = E[0][0] * c00 + E[0][1] * c01 + E[0][2] * c02;
+      const double r = 1.0 / det;
+      gh[0] = (c00 * dU[0] + (E[0][2] * E[2][1] - E[0][1] * E[2][2]) * dU[1] + (E[0][1] * E[1][2] - E[0][2] * E[1][1]) * dU[2]) * r;
+      gh[1] = (c01 * dU[0] + (E[0][0] * E[2][2] - E[0][2] * E[2][0]) * dU[1] + (E[0][2] * E[1][0] - E[0][0] * E[1][2]) * dU[2]) * r;
+      gh[2] = (c02 * dU[0] + (E[0][1] * E[2][0] - E[0][0] * E[2][1]) * dU[1] + (E[0][0] * E[1][1] - E[0][1] * E[1][0]) * dU[2]) * r;
+    }
+    const int nq = g.nq;
+    const int npts = (DIM == 2) ? nq * nq : nq * nq * nq;
+    for (int q = 0; q < npts; ++q) {
+      const int qi[3] = {q % nq, (q / nq) % nq, q / (nq * nq)};
+      const double uu = 0.5 * (g.x[qi[0]] + 1.0), vv = 0.5 * (g.x[qi[1]] + 1.0);
+      double lam[DIM], w = 0.25 * g.w[qi[0]] * g.w[qi[1]] * (1.0 - uu);
+      lam[0] = uu;
+      lam[1] = vv * (1.0 - uu);
+      if constexpr (DIM == 3) {
+        const double ww = 0.5 * (g.x[qi[2]] + 1.0);
+        lam[2] = ww * (1.0 - uu) * (1.0 - vv);
+        w *= 0.5 * g.w[qi[2]] * (1.0 - uu) * (1.0 - vv);
+      }
+      double xq[DIM], uh = U[0];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) xq[d] = X[0][d];
+#pragma unroll
+      for (int r = 0; r < DIM; ++r) {
+        uh += lam[r] * dU[r];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) xq[d] += lam[r] * E[r][d];
+      }
+      const double ex = exp(PI * xq[0]);
+      const double S = sin(PI * xq[1]), Ey = exp(p.eta * xq[1]);
+      double pe, ge[DIM];
+      if constexpr (DIM == 3) {
+        const double Sz = sin(PI * xq[2]), Ez = exp(p.eta * xq[2]);
+        pe = p.mu_over_pi * ex * (S + Sz) + p.coef_e * (Ey + Ez);
+        ge[0] = p.mu * ex * (S + Sz);
+        ge[1] = p.mu * ex * cos(PI * xq[1]) + p.coef_e * p.eta * Ey;
+        ge[2] = p.mu * ex * cos(PI * xq[2]) + p.coef_e * p.eta * Ez;
+      } else {
+        pe = p.mu_over_pi * ex * S + p.coef_e * Ey;
+        ge[0] = p.mu * ex * S;
+        ge[1] = p.mu * ex * cos(PI * xq[1]) + p.coef_e * p.eta * Ey;
+      }
+      const double wd = w * fabs(det);
+      const double du = uh - pe;
+      l2 += wd * du * du;
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) {
+        const double dg = gh[d] - ge[d];
+        h1 += wd * dg * dg;
+      }
+    }
+  }
+  auto bsum = [&](double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) lds[wv] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) for (int q = 0; q < (int)(blockDim.x >> 6); ++q) t += lds[q];
+    return t;
+  };
+  const double a = bsum(l2);
+  const double b = bsum(h1);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = a;
+    part[2048 + blockIdx.x] = b;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_sum_partials(const double* __restrict__ part, int nblocks, double* __restrict__ out) {
   __shared__ double lds[256];
   const double* p = part + (int64_t)blockIdx.x * 2048;
@@ -198,7 +306,6 @@ extern "C" int pph_error_norms_mms(pph_ctx* ctx, int field, const double* nodal_
   PPH_REQUIRE(ctx, ctx->mesh_ok, "pph_error_norms_mms before pph_mesh_build");
   PPH_REQUIRE(ctx, ctx->world == 1, "error norms are implemented for single-context meshes");
   const MeshData& m = ctx->mesh;
-  PPH_REQUIRE(ctx, m.kind == PPH_CELL_QUAD || m.kind == PPH_CELL_HEX, "error norms: quadrilateral / hexahedral cells only");
   PPH_REQUIRE(ctx, field == 0 || field == 1, "field must be 0 or 1");
   PPH_REQUIRE(ctx, nq >= 1 && nq <= 8 && nodal_host && l2_out && h1s_out, "bad arguments");
   PPH_REQUIRE(ctx, k1 > 0 && k2 > 0 && mu > 0 && beta > 0, "need positive parameters");
@@ -220,6 +327,12 @@ extern "C" int pph_error_norms_mms(pph_ctx* ctx, int field, const double* nodal_
   if (m.kind == PPH_CELL_QUAD)
     hipLaunchKernelGGL(k_error_norms<2>, dim3(grid), dim3(256), 0, ctx->stream, m.cells.p, m.cx.p, m.cy.p, m.cz.p, u.p, g,
                        p, m.ncell, part.p);
+  else if (m.kind == PPH_CELL_TRI)
+    hipLaunchKernelGGL(k_error_norms_simplex<2>, dim3(grid), dim3(256), 0, ctx->stream, m.cells.p, m.cx.p, m.cy.p, m.cz.p,
+                       u.p, g, p, m.ncell, part.p);
+  else if (m.kind == PPH_CELL_TET)
+    hipLaunchKernelGGL(k_error_norms_simplex<3>, dim3(grid), dim3(256), 0, ctx->stream, m.cells.p, m.cx.p, m.cy.p, m.cz.p,
+                       u.p, g, p, m.ncell, part.p);
   else
     hipLaunchKernelGGL(k_error_norms<3>, dim3(grid), dim3(256), 0, ctx->stream, m.cells.p, m.cx.p, m.cy.p, m.cz.p, u.p, g,
                        p, m.ncell, part.p);

@@ -846,3 +846,39 @@ def test_option_paths_agree(gpu_ctx_factory):
         else:
             assert (info.iterations, info.inner_iterations) == ref[1:], opts
             np.testing.assert_allclose(xs, ref[0], rtol=0, atol=1e-11 * np.abs(ref[0]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,kind,ns", [(2, o.CELL_TRI, (8, 16)), (3, o.CELL_TET, (6, 12))])
+def test_error_norms_on_simplices(gpu_ctx_factory, dim, kind, ns):
+    """l2_error / h1_seminorm_error on P1 triangles and Kuhn tetrahedra: device quadrature against the oracle's
+    (same collapsed Gauss rule; the reference stores no simplex error norms - parity unpinned beyond that) and
+    second / first order convergence of the manufactured problem."""
+    import math
+    f = _ffi()
+    Pd = o.Params()
+    eta, pi = Pd.eta, math.pi
+    if dim == 2:
+        ex = lambda X: (Pd.mu / pi) * np.exp(pi * X[:, 0]) * np.sin(pi * X[:, 1]) - (Pd.mu / (Pd.beta * Pd.k1)) * np.exp(eta * X[:, 1])
+        gr = lambda X: np.stack([Pd.mu * np.exp(pi * X[:, 0]) * np.sin(pi * X[:, 1]),
+                                 Pd.mu * np.exp(pi * X[:, 0]) * np.cos(pi * X[:, 1])
+                                 - (Pd.mu / (Pd.beta * Pd.k1)) * eta * np.exp(eta * X[:, 1])], 1)
+    else:
+        ex = lambda X: ((Pd.mu / pi) * np.exp(pi * X[:, 0]) * (np.sin(pi * X[:, 1]) + np.sin(pi * X[:, 2]))
+                        - (Pd.mu / (Pd.beta * Pd.k1)) * (np.exp(eta * X[:, 1]) + np.exp(eta * X[:, 2])))
+        gr = lambda X: np.stack([Pd.mu * np.exp(pi * X[:, 0]) * (np.sin(pi * X[:, 1]) + np.sin(pi * X[:, 2])),
+                                 Pd.mu * np.exp(pi * X[:, 0]) * np.cos(pi * X[:, 1]) - (Pd.mu / (Pd.beta * Pd.k1)) * eta * np.exp(eta * X[:, 1]),
+                                 Pd.mu * np.exp(pi * X[:, 0]) * np.cos(pi * X[:, 2]) - (Pd.mu / (Pd.beta * Pd.k1)) * eta * np.exp(eta * X[:, 2])], 1)
+    errs = []
+    for n in ns:
+        nz = n if dim == 3 else 0
+        ctx, om, osys = _setup(gpu_ctx_factory, dim, kind, n, n, nz)
+        xs, info, _ = ctx.solve(_cfg(pc_type=f.PC_FIELDSPLIT, inner_pc_type=f.PC_MG, inner_rtol=1e-12, rtol=1e-11))
+        assert info.converged
+        p1h = xs[: osys.n]
+        l2, h1 = ctx.error_norms_mms(0, p1h, Pd.k1, Pd.k2, Pd.beta, Pd.mu, 5)
+        rl2, rh1 = o.error_norms(om, p1h, ex, gr, nq=5)
+        assert l2 == pytest.approx(rl2, rel=1e-10) and h1 == pytest.approx(rh1, rel=1e-10)
+        errs.append((l2, h1))
+    assert 1.6 < np.log2(errs[0][0] / errs[1][0]) < 2.4       # L2: O(h^2)
+    assert 0.7 < np.log2(errs[0][1] / errs[1][1]) < 1.3       # H1 seminorm: O(h)
