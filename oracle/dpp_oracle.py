@@ -260,13 +260,27 @@ def eliminate_dirichlet(A_full: sp.csr_matrix, bc_dofs: np.ndarray) -> sp.csr_ma
 
 
 def build_system(mesh: Mesh, p: Params, g1: Optional[np.ndarray] = None, g2: Optional[np.ndarray] = None,
-                 mms: bool = True) -> System:
+                 mms: bool = True, mask1: Optional[np.ndarray] = None, mask2: Optional[np.ndarray] = None) -> System:
     """Monolithic DPP system with Dirichlet data on the whole boundary of both fields.
     ``mms=True`` takes the data from the manufactured solution; otherwise ``g1``/``g2`` are
-    nodal arrays (only boundary entries are read); None -> homogeneous."""
+    nodal arrays (only boundary entries are read); None -> homogeneous.  ``mask1``/``mask2`` (boolean nodal
+    arrays) constrain an arbitrary node set per field instead of the boundary (same elimination), with the
+    values of ``g1``/``g2`` there."""
     K, M = assemble_scalar(mesh)
     n = mesh.num_nodes
     A_full = monolithic_matrix(K, M, p)
+    if mask1 is not None or mask2 is not None:
+        b1 = np.nonzero(mask1)[0] if mask1 is not None else np.zeros(0, np.int64)
+        b2 = np.nonzero(mask2)[0] if mask2 is not None else np.zeros(0, np.int64)
+        bc = np.concatenate([b1, b2 + n]).astype(np.int64)
+        u0 = np.zeros(2 * n)
+        if g1 is not None:
+            u0[b1] = g1[b1]
+        if g2 is not None:
+            u0[n + b2] = g2[b2]
+        F = A_full @ u0
+        F[bc] = 0.0
+        return System(A_full, eliminate_dirichlet(A_full, bc), u0, -F, bc, n)
     b = boundary_nodes(mesh)
     bc = np.concatenate([b, b + n])
     u0 = np.zeros(2 * n)

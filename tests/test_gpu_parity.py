@@ -882,3 +882,47 @@ def test_error_norms_on_simplices(gpu_ctx_factory, dim, kind, ns):
         errs.append((l2, h1))
     assert 1.6 < np.log2(errs[0][0] / errs[1][0]) < 2.4       # L2: O(h^2)
     assert 0.7 < np.log2(errs[0][1] / errs[1][1]) < 1.3       # H1 seminorm: O(h)
+
+
+@pytest.mark.gpu
+def test_assembly_and_solve_on_random_small_shapes(gpu_ctx_factory):
+    """Seeded sweep over small, odd-shaped meshes of all four cell kinds, with partial Dirichlet sets that differ
+    between the two fields: monolithic matrix and right-hand side against the oracle (1e-12 of the largest entry),
+    and the GMRES + field-split solve against the direct solution.  Exercises the tails of every kernel (last
+    partial batch, one-cell directions, rows at corners, non-aliased A21)."""
+    f = _ffi()
+    rng = np.random.default_rng(20260313)
+    kinds = [(2, o.CELL_QUAD), (2, o.CELL_TRI), (3, o.CELL_HEX), (3, o.CELL_TET)]
+    for it in range(24):
+        dim, kind = kinds[it % 4]
+        nx, ny = int(rng.integers(1, 8)), int(rng.integers(1, 8))
+        nz = int(rng.integers(1, 8)) if dim == 3 else 0
+        om = o.build_mesh(dim, kind, nx, ny, nz)
+        bnd = o.boundary_nodes(om)
+        e1, e2 = o.exact_pressures(om.coords, P)
+        if it % 3 == 2:
+            # field 1 constrained on part of the boundary only: the two Dirichlet sets differ
+            keep = bnd[om.coords[bnd, 0] < 0.75]
+            if keep.size == 0:
+                keep = bnd
+            sets = (bnd, keep)
+        else:
+            sets = (bnd, bnd)
+        ctx = gpu_ctx_factory()
+        ctx.mesh_build(dim, kind, nx, ny, nz)
+        ctx.set_dirichlet(0, sets[0], e1[sets[0]])
+        ctx.set_dirichlet(1, sets[1], e2[sets[1]])
+        ctx.assemble(P.k1, P.k2, P.beta, P.mu, monolithic=True)
+        g1 = np.zeros(om.num_nodes); g2 = np.zeros(om.num_nodes)
+        g1[sets[0]] = e1[sets[0]]; g2[sets[1]] = e2[sets[1]]
+        m1 = np.zeros(om.num_nodes, bool); m2 = np.zeros(om.num_nodes, bool)
+        m1[sets[0]] = True; m2[sets[1]] = True
+        osys = o.build_system(om, P, g1=g1, g2=g2, mask1=m1, mask2=m2)
+        A = ctx.csr(f.MAT_MONO)
+        assert abs(A - osys.A).max() <= 1e-12 * abs(osys.A).max(), (it, dim, kind, nx, ny, nz)
+        r, u0 = ctx.rhs()
+        np.testing.assert_allclose(r, osys.rhs, rtol=0, atol=1e-12 * max(np.abs(osys.rhs).max(), 1.0))
+        np.testing.assert_array_equal(u0, osys.u0)
+        xs, info, _ = ctx.solve(_cfg(pc_type=f.PC_FIELDSPLIT, inner_pc_type=f.PC_MG, inner_rtol=1e-13, rtol=1e-12))
+        ud = o.solve_direct(osys)
+        assert info.converged and np.abs(xs - ud).max() <= 1e-8 * max(np.abs(ud).max(), 1.0), (it, dim, kind, nx, ny, nz)
