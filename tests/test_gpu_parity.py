@@ -926,3 +926,26 @@ def test_assembly_and_solve_on_random_small_shapes(gpu_ctx_factory):
         xs, info, _ = ctx.solve(_cfg(pc_type=f.PC_FIELDSPLIT, inner_pc_type=f.PC_MG, inner_rtol=1e-13, rtol=1e-12))
         ud = o.solve_direct(osys)
         assert info.converged and np.abs(xs - ud).max() <= 1e-8 * max(np.abs(ud).max(), 1.0), (it, dim, kind, nx, ny, nz)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", [o.CELL_HEX, o.CELL_TET])
+def test_default_path_is_bitwise_reproducible(gpu_ctx_factory, kind):
+    """Two independent contexts, default options (fused assembly, MFMA contraction, device-side coarse solve,
+    device-resident CG scalars): identical blocks, right-hand side, iteration counts and solution bits."""
+    f = _ffi()
+    runs = []
+    for _ in range(2):
+        ctx, om, osys = _setup(gpu_ctx_factory, 3, kind, 20, 12, 16, monolithic=False)
+        mats = [ctx.csr(w).data.copy() for w in (f.MAT_A11, f.MAT_A22, f.MAT_A12)]
+        rhs, _ = ctx.rhs()
+        xs, info, _ = ctx.solve(_cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_MG, inner_rtol=1e-10,
+                                     inner_reduction=1e-1, inner_norm=1, mg_smooth=1, picard_rtol=1e-8))
+        assert info.converged
+        runs.append((mats, rhs, xs, info.iterations, info.inner_iterations, info.resnorm))
+    a, b = runs
+    for x, y in zip(a[0], b[0]):
+        np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(a[1], b[1])
+    np.testing.assert_array_equal(a[2], b[2])
+    assert a[3:] == b[3:]
