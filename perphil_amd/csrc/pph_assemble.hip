@@ -452,10 +452,23 @@ __global__ __launch_bounds__(256) void k_asm_gather(const int32_t* __restrict__ 
 // and sum matching columns into the CSR row in a fixed order: no atomics, bitwise reproducible, every
 // CSR entry written once.
 // ------------------------------------------------------------------------------------------------
+// Element-row buffer addressing.  The buffer is either the whole mesh ([cell][a][K row | M row]) or a RING of a few
+// cell layers: the assembly then alternates element pass (cell layers [begin, end)) and node-centred pass (the node
+// planes those layers complete), so that the rows are still in the memory-side cache (256 MB) when they are read
+// back and never travel to HBM and back (34 GB per 256^3 assembly otherwise).
+struct ERing {
+  int64_t begin, end;      // cells (element pass) or nodes (gather pass) handled by this launch
+  int64_t layer_cells;     // cells per layer
+  int ring;                // layers in the buffer (>= number of layers: plain addressing)
+  __host__ __device__ int64_t slot(int64_t cell) const {
+    return ((cell / layer_cells) % ring) * layer_cells + cell % layer_cells;
+  }
+};
+
 template <int DIM>
 __global__ __launch_bounds__(256) void k_elem_rows(const int32_t* __restrict__ cells, const double* __restrict__ cx,
                                                    const double* __restrict__ cy, const double* __restrict__ cz,
-                                                   double* __restrict__ erows, int64_t ncell) {
+                                                   double* __restrict__ erows, int64_t ncell, ERing er) {
   constexpr int NB = 1 << DIM;
   constexpr int CPB = 256 / NB;
   __shared__ double sN[NB][NB];
@@ -498,13 +511,13 @@ __global__ __launch_bounds__(256) void k_elem_rows(const int32_t* __restrict__ c
       sdN[q][b][e] = d;
     }
   }
-  const int64_t nbatch = (ncell + CPB - 1) / CPB;
+  const int64_t nbatch = (er.end - er.begin + CPB - 1) / CPB;
   // vertex coordinates of the NEXT batch (two dependent loads: cell->dof entry, then the coordinates) are requested
   // before the current batch is integrated
   double pxyz[3] = {0.0, 0.0, 0.0};
   auto fetch = [&](int64_t bt) {
-    const int64_t cl = bt * CPB + lc;
-    if (bt < nbatch && cl < ncell) {
+    const int64_t cl = er.begin + bt * CPB + lc;
+    if (bt < nbatch && cl < er.end) {
       const int32_t node = cells[cl * NB + a];
       pxyz[0] = cx[node];
       pxyz[1] = cy[node];
@@ -514,8 +527,8 @@ __global__ __launch_bounds__(256) void k_elem_rows(const int32_t* __restrict__ c
   fetch(blockIdx.x);
   for (int64_t batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
     __syncthreads();
-    const int64_t cell = batch * CPB + lc;
-    const bool valid = cell < ncell;
+    const int64_t cell = er.begin + batch * CPB + lc;
+    const bool valid = cell < er.end;
     if (valid) {
       sX(lc, a, 0) = pxyz[0];
       sX(lc, a, 1) = pxyz[1];
@@ -617,10 +630,10 @@ __global__ __launch_bounds__(256) void k_elem_rows(const int32_t* __restrict__ c
     }
     __syncthreads();
     {
-      const int64_t cell0 = batch * CPB;
-      const int64_t left = ncell - cell0;
+      const int64_t cell0 = er.begin + batch * CPB;    // a launch never straddles a ring wrap (whole layers)
+      const int64_t left = er.end - cell0;
       const int rows = (int)(left < CPB ? left : CPB) * NB;
-      double* out = erows + cell0 * NB * (2 * NB);
+      double* out = erows + er.slot(cell0) * NB * (2 * NB);
       for (int e2 = tid; e2 < rows * NB; e2 += 256) {     // one double2 per thread and pass
         const int row = e2 / NB, colp = 2 * (e2 % NB);
         const double* si = sGf + row * SOR + colp;
@@ -656,7 +669,7 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__
                                                      const int64_t* __restrict__ rowptr,
                                                      const int32_t* __restrict__ col, double* __restrict__ K,
                                                      double* __restrict__ M, int nx, int ny, int nzl, int px, int py,
-                                                     int64_t n, FuseArgs fa) {
+                                                     int64_t n, FuseArgs fa, ERing er) {
   constexpr int NB = 1 << DIM;
   double best1 = 0.0, best2 = 0.0;
   constexpr int NPB = 256 / NB;
@@ -668,7 +681,7 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__
   __shared__ uint8_t sOK[NPB][NB];
   const int tid = threadIdx.x;
   const int ln = tid / NB, c = tid % NB;
-  const int64_t nbatch = (n + NPB - 1) / NPB;
+  const int64_t nbatch = (er.end - er.begin + NPB - 1) / NPB;
   // the element row and the cell->dof entries of the NEXT batch are requested before the current batch is matched
   // and stored (register double buffer): the two phases of a batch are separated by barriers, and with a dozen
   // waves per CU the loads of one phase were not overlapping the stores of the other
@@ -679,8 +692,8 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__
   auto fetch = [&](int64_t bt) {
     pcell = -1;
     pok = false;
-    const int64_t nd = bt * NPB + ln;
-    if (bt < nbatch && nd < n) {
+    const int64_t nd = er.begin + bt * NPB + ln;
+    if (bt < nbatch && nd < er.end) {
       const int i = (int)(nd % px);
       const int64_t t = nd / px;
       const int j = (int)(t % py), k = (int)(t / py);
@@ -690,7 +703,7 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__
     }
     if (pcell >= 0) {
       // the node is local vertex c of this cell (checked against the cell->dof map)
-      const double* in = erows + (pcell * NB + c) * (2 * NB);
+      const double* in = erows + (er.slot(pcell) * NB + c) * (2 * NB);
       const int32_t* cn = cells + pcell * NB;
 #pragma unroll
       for (int b = 0; b < NB; b += 2) {
@@ -709,8 +722,8 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__
   fetch(blockIdx.x);
   for (int64_t batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
     __syncthreads();
-    const int64_t node = batch * NPB + ln;
-    const bool valid = node < n;
+    const int64_t node = er.begin + batch * NPB + ln;
+    const bool valid = node < er.end;
     if (pcell >= 0) {
 #pragma unroll
       for (int b = 0; b < NB; b += 2) {
@@ -1035,26 +1048,27 @@ int pph_launch_assemble_KM(pph_ctx* ctx_, MeshData& mesh) {
     const int cpb = 256 / mesh.m;
     int64_t nb1 = ceil_div64(ncell, cpb), nb2 = ceil_div64(mesh.n, cpb);
     int g1 = (int)(nb1 < 256 * 16 ? nb1 : 256 * 16), g2 = (int)(nb2 < 256 * 16 ? nb2 : 256 * 16);
+    const ERing ec{0, ncell, ncell, 1}, en{0, mesh.n, ncell, 1};   // whole mesh in one launch, plain addressing
     if (mesh.kind == PPH_CELL_QUAD) {
       hipLaunchKernelGGL(k_elem_rows<2>, dim3(g1), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p, mesh.cy.p,
-                         mesh.cz.p, mesh.erows.p, ncell);
+                         mesh.cz.p, mesh.erows.p, ncell, ec);
       if (mesh.px >= 3 && mesh.py >= 3)
         hipLaunchKernelGGL((k_gather_rows<2, false, true>), dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
-                           mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, mesh.nx, mesh.ny, 0, mesh.px, mesh.py, mesh.n, FuseArgs{});
+                           mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, mesh.nx, mesh.ny, 0, mesh.px, mesh.py, mesh.n, FuseArgs{}, en);
       else
         hipLaunchKernelGGL((k_gather_rows<2, false, false>), dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
-                           mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, mesh.nx, mesh.ny, 0, mesh.px, mesh.py, mesh.n, FuseArgs{});
+                           mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, mesh.nx, mesh.ny, 0, mesh.px, mesh.py, mesh.n, FuseArgs{}, en);
     } else {
       hipLaunchKernelGGL(k_elem_rows<3>, dim3(g1), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p, mesh.cy.p,
-                         mesh.cz.p, mesh.erows.p, ncell);
+                         mesh.cz.p, mesh.erows.p, ncell, ec);
       if (mesh.px >= 3 && mesh.py >= 3 && mesh.nzl >= 2)
         hipLaunchKernelGGL((k_gather_rows<3, false, true>), dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
                            mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, mesh.nx, mesh.ny, mesh.nzl, mesh.px, mesh.py,
-                           mesh.n, FuseArgs{});
+                           mesh.n, FuseArgs{}, en);
       else
         hipLaunchKernelGGL((k_gather_rows<3, false, false>), dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
                            mesh.rowptr.p, mesh.col.p, mesh.K.p, mesh.M.p, mesh.nx, mesh.ny, mesh.nzl, mesh.px, mesh.py,
-                           mesh.n, FuseArgs{});
+                           mesh.n, FuseArgs{}, en);
     }
     PPH_HIP(ctx, hipGetLastError());
     return PPH_OK;
@@ -1393,10 +1407,6 @@ bool pph_can_fuse_assembly(const pph_ctx* ctx) {
 // element rows (multilinear cells) + the fused node-centred pass on any level mesh
 int pph_launch_fused_kernels(pph_ctx* ctx, MeshData& mesh, const FuseArgs& fa, double* Kp, double* Mp) {
   const bool multilinear = (mesh.kind == PPH_CELL_QUAD || mesh.kind == PPH_CELL_HEX);
-  if (multilinear) PPH_TRY(mesh.erows.alloc(ctx, (size_t)mesh.ncell * mesh.m * 2 * mesh.m));
-  const int cpb = 256 / mesh.m;
-  int64_t nb1 = ceil_div64(mesh.ncell, cpb), nb2 = ceil_div64(mesh.n, cpb);
-  int g1 = (int)(nb1 < 256 * 16 ? nb1 : 256 * 16), g2 = (int)(nb2 < 256 * 16 ? nb2 : 256 * 16);
   if (!multilinear) {
     int64_t nbs = ceil_div64(mesh.n, 256);
     const int gs = (int)(nbs < 256 * 32 ? nbs : 256 * 32);
@@ -1408,24 +1418,56 @@ int pph_launch_fused_kernels(pph_ctx* ctx, MeshData& mesh, const FuseArgs& fa, d
       hipLaunchKernelGGL((k_asm_simplex_gather<3, true>), dim3(gs), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p,
                          mesh.cy.p, mesh.cz.p, mesh.rowptr.p, mesh.col.p, Kp, Mp, mesh.nx, mesh.ny, mesh.nzl, mesh.px,
                          mesh.py, mesh.n, fa);
-  } else if (mesh.kind == PPH_CELL_QUAD) {
-    hipLaunchKernelGGL(k_elem_rows<2>, dim3(g1), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p, mesh.cy.p, mesh.cz.p,
-                       mesh.erows.p, mesh.ncell);
-    if (mesh.px >= 3 && mesh.py >= 3)
-      hipLaunchKernelGGL((k_gather_rows<2, true, true>), dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
-                         mesh.rowptr.p, mesh.col.p, Kp, Mp, mesh.nx, mesh.ny, 0, mesh.px, mesh.py, mesh.n, fa);
-    else
-      hipLaunchKernelGGL((k_gather_rows<2, true, false>), dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
-                         mesh.rowptr.p, mesh.col.p, Kp, Mp, mesh.nx, mesh.ny, 0, mesh.px, mesh.py, mesh.n, fa);
-  } else {
-    hipLaunchKernelGGL(k_elem_rows<3>, dim3(g1), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p, mesh.cy.p, mesh.cz.p,
-                       mesh.erows.p, mesh.ncell);
-    if (mesh.px >= 3 && mesh.py >= 3 && mesh.nzl >= 2)
-      hipLaunchKernelGGL((k_gather_rows<3, true, true>), dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
-                         mesh.rowptr.p, mesh.col.p, Kp, Mp, mesh.nx, mesh.ny, mesh.nzl, mesh.px, mesh.py, mesh.n, fa);
-    else
-      hipLaunchKernelGGL((k_gather_rows<3, true, false>), dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
-                         mesh.rowptr.p, mesh.col.p, Kp, Mp, mesh.nx, mesh.ny, mesh.nzl, mesh.px, mesh.py, mesh.n, fa);
+    PPH_HIP(ctx, hipGetLastError());
+    return PPH_OK;
+  }
+  const int cpb = 256 / mesh.m;
+  // Optional layered schedule (3D, `asm_ring` > 0): element pass on L cell layers, then the node planes they
+  // complete, with a ring of L + 1 layers of element rows meant to stay in the memory-side cache.  Measured at 256^3:
+  // 62 ms with one layer (64 K cells) per launch (514 short dependent launches), 35 / 24 / 19 / 18 ms with 4 / 8 / 16 /
+  // 32 layers per launch, against 16.8 ms for the whole mesh in two launches - the default.
+  const int64_t layer_cells = (mesh.dim == 3) ? (int64_t)mesh.nx * mesh.ny : mesh.ncell;
+  const int64_t plane = (mesh.dim == 3) ? (int64_t)mesh.px * mesh.py : mesh.n;
+  const int layers = (mesh.dim == 3) ? mesh.nzl : 1;
+  int L = (int)ceil_div64((int64_t)ctx->asm_ring, layer_cells);   // asm_ring: cells per launch
+  if (L < 1) L = 1;
+  // (a workgroup batch of the element pass must not straddle two layers: their ring slots need not be adjacent)
+  const bool ringed = ctx->asm_ring && mesh.dim == 3 && L + 1 < layers && layer_cells % cpb == 0;
+  if (!ringed) L = layers;
+  const int ring = ringed ? L + 1 : 1;
+  const int64_t ring_cells = ringed ? (int64_t)ring * layer_cells : mesh.ncell;
+  PPH_TRY(mesh.erows.alloc(ctx, (size_t)ring_cells * mesh.m * 2 * mesh.m));
+  const int nplanes = (mesh.dim == 3) ? mesh.pzl : 1;
+  for (int k0 = 0; k0 < nplanes; k0 += L) {
+    // cells of layers [k0, k0 + L) (none left for the topmost node plane), then node planes [k0, k0 + L)
+    const int k1 = (k0 + L < layers) ? k0 + L : layers;
+    const int p1 = (k0 + L < nplanes) ? k0 + L : nplanes;
+    ERing ec{(int64_t)k0 * layer_cells, (int64_t)k1 * layer_cells, layer_cells, ringed ? ring : 1};
+    ERing en{(int64_t)k0 * plane, (int64_t)p1 * plane, layer_cells, ringed ? ring : 1};
+    if (!ringed) { ec = ERing{0, mesh.ncell, mesh.ncell, 1}; en = ERing{0, mesh.n, mesh.ncell, 1}; }
+    const int64_t nb1 = ceil_div64(ec.end - ec.begin, cpb), nb2 = ceil_div64(en.end - en.begin, cpb);
+    const int g1 = (int)(nb1 < 256 * 16 ? nb1 : 256 * 16), g2 = (int)(nb2 < 256 * 16 ? nb2 : 256 * 16);
+    if (mesh.kind == PPH_CELL_QUAD) {
+      hipLaunchKernelGGL(k_elem_rows<2>, dim3(g1), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p, mesh.cy.p, mesh.cz.p,
+                         mesh.erows.p, mesh.ncell, ec);
+      if (mesh.px >= 3 && mesh.py >= 3)
+        hipLaunchKernelGGL((k_gather_rows<2, true, true>), dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
+                           mesh.rowptr.p, mesh.col.p, Kp, Mp, mesh.nx, mesh.ny, 0, mesh.px, mesh.py, mesh.n, fa, en);
+      else
+        hipLaunchKernelGGL((k_gather_rows<2, true, false>), dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
+                           mesh.rowptr.p, mesh.col.p, Kp, Mp, mesh.nx, mesh.ny, 0, mesh.px, mesh.py, mesh.n, fa, en);
+    } else {
+      if (ec.end > ec.begin)
+        hipLaunchKernelGGL(k_elem_rows<3>, dim3(g1), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p, mesh.cy.p,
+                           mesh.cz.p, mesh.erows.p, mesh.ncell, ec);
+      if (mesh.px >= 3 && mesh.py >= 3 && mesh.nzl >= 2)
+        hipLaunchKernelGGL((k_gather_rows<3, true, true>), dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
+                           mesh.rowptr.p, mesh.col.p, Kp, Mp, mesh.nx, mesh.ny, mesh.nzl, mesh.px, mesh.py, mesh.n, fa, en);
+      else
+        hipLaunchKernelGGL((k_gather_rows<3, true, false>), dim3(g2), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.erows.p,
+                           mesh.rowptr.p, mesh.col.p, Kp, Mp, mesh.nx, mesh.ny, mesh.nzl, mesh.px, mesh.py, mesh.n, fa, en);
+    }
+    if (!ringed) break;
   }
   PPH_HIP(ctx, hipGetLastError());
   return PPH_OK;

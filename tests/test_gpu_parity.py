@@ -834,10 +834,12 @@ def test_option_paths_agree(gpu_ctx_factory):
     single-workgroup device CG, software-pipelined SpMV (17) vs the default kernel."""
     f = _ffi()
     ref = None
-    for opts in ({}, {"coarse_on_device": 0}, {"spmv_kernel": 17}, {"spmv_kernel": 1}):
+    for opts in ({}, {"coarse_on_device": 0}, {"spmv_kernel": 17}, {"spmv_kernel": 1}, {"asm_ring": 200}):
         ctx, om, osys = _setup(gpu_ctx_factory, 3, o.CELL_HEX, 12, 8, 16)
         for k, v in opts.items():
             ctx.set_option(k, v)
+        if "asm_ring" in opts:        # layered assembly schedule: takes effect at the next assembly
+            ctx.assemble(P.k1, P.k2, P.beta, P.mu, monolithic=True)
         xs, info, _ = ctx.solve(_cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_MG, inner_rtol=1e-10,
                                      inner_reduction=1e-1, inner_norm=1, mg_smooth=1, picard_rtol=1e-9))
         assert info.converged
