@@ -951,3 +951,44 @@ def test_default_path_is_bitwise_reproducible(gpu_ctx_factory, kind):
     np.testing.assert_array_equal(a[1], b[1])
     np.testing.assert_array_equal(a[2], b[2])
     assert a[3:] == b[3:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hexa,shape", [(True, (77, 45, 53)), (False, (31, 47, 29)), (True, (130, 6, 34))])
+def test_odd_mid_size_shapes_match_cpu_port(gpu_ctx_factory, hexa, shape):
+    """Shapes that are no multiple of any batch size (tails of every kernel) at a size only the C port reaches:
+    blocks and right-hand side entry for entry, and the Jacobi-CG Picard solve against the C port's solution
+    (odd meshes have no coarser level: the comparison uses the Jacobi-preconditioned block solves of both)."""
+    from oracle import dpp_cpu as cpu
+
+    f = _ffi()
+    nx, ny, nz = shape
+    kind = f.CELL_HEX if hexa else f.CELL_TET
+    S = cpu.CpuSystem(3, kind, nx, ny, nz)
+    ctx = gpu_ctx_factory()
+    ctx.mesh_build(3, kind, nx, ny, nz)
+    import perphil_amd.fd as fdm
+
+    mesh = fdm.UnitCubeMesh(nx, ny, nz, hexahedral=hexa)
+    b = mesh.boundary_nodes()
+    e1, e2 = o.exact_pressures(mesh.node_coordinates(b), P)
+    for tgt in (S, ctx):
+        tgt.set_dirichlet(0, b, e1)
+        tgt.set_dirichlet(1, b, e2)
+    S.assemble(P.k1, P.k2, P.beta, P.mu)
+    ctx.assemble(P.k1, P.k2, P.beta, P.mu, monolithic=False)
+    for wc, wg in ((cpu.MAT_A11, f.MAT_A11), (cpu.MAT_A22, f.MAT_A22), (cpu.MAT_A12, f.MAT_A12), (cpu.MAT_A21, f.MAT_A21)):
+        ref, got = S.csr(wc), ctx.csr(wg)
+        np.testing.assert_array_equal(got.indptr, ref.indptr)
+        np.testing.assert_array_equal(got.indices, ref.indices)
+        np.testing.assert_allclose(got.data, ref.data, rtol=0, atol=1e-12 * np.abs(ref.data).max())
+    r_ref, _ = S.rhs()
+    r, _ = ctx.rhs()
+    np.testing.assert_allclose(r, r_ref, rtol=0, atol=1e-12 * np.abs(r_ref).max())
+    S.mg_setup()
+    x_ref, sweeps, inner, res = S.picard(pc=cpu.PC_JACOBI, inner_rtol=1e-10, reduction=0.0, inner_norm=0, rtol=1e-9)
+    xs, info, _ = ctx.solve(_cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_JACOBI, inner_rtol=1e-10,
+                                 picard_rtol=1e-9, picard_max_it=100))
+    assert info.converged and sweeps > 0
+    assert info.iterations == sweeps
+    assert np.abs(xs - x_ref).max() <= 1e-7 * np.abs(x_ref).max()
