@@ -21,12 +21,13 @@ def _free_port():
 @pytest.mark.parametrize("world,cells,kind,pc,solver", [(2, 16, "hex", "mg", "picard"), (4, 16, "hex", "mg", "picard"),
                                                          (2, 16, "tet", "mg", "picard"), (2, 8, "hex", "jacobi", "picard"),
                                                          (2, 16, "tet", "mg", "gmres_fs"), (2, 8, "hex", "mg", "cg_block2"),
-                                                         (4, 8, "hex", "mg", "gmres_jacobi")])
+                                                         (4, 8, "hex", "mg", "gmres_jacobi"),
+                                                         (4, 32, "hex", "mg", "picard-inexact"), (2, 32, "tet", "mg", "picard-inexact")])
 def test_slab_runs_match_single_context(world, cells, kind, pc, solver):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tools", "slab_check.py"), "--cells", str(cells), "--backend", "gloo", "--kind", kind,
-           "--inner-pc", pc, "--solver", solver]
+           "--inner-pc", pc, "--solver", solver.split("-")[0]] + (["--inexact"] if solver.endswith("inexact") else [])
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=280)
     line = [l for l in r.stdout.splitlines() if l.startswith("world=")]
     assert r.returncode == 0, (line, r.stdout[-2000:], r.stderr[-2000:])

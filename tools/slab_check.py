@@ -15,6 +15,8 @@ ap.add_argument("--backend", default="gloo")
 ap.add_argument("--kind", default="hex")
 ap.add_argument("--inner-pc", default="mg")
 ap.add_argument("--solver", default="picard", choices=["picard", "gmres_fs", "cg_block2", "gmres_jacobi"])
+ap.add_argument("--inexact", action="store_true",
+                help="the benchmark's Picard settings: V(1,1), block solves to a tenfold drop of the unpreconditioned residual")
 args = ap.parse_args()
 
 from perphil_amd import _ffi  # noqa: E402  (before torch: the library binds the system HIP runtime first)
@@ -32,7 +34,11 @@ dist.init_process_group(backend=args.backend)
 kind = _ffi.CELL_HEX if args.kind == "hex" else _ffi.CELL_TET
 pc = _ffi.PC_MG if args.inner_pc == "mg" else _ffi.PC_JACOBI
 k1, k2, beta, mu = 1.0, 1e-2, 1.0, 1.0
-solver = SlabSolver(args.cells, world, rank, device, k1, k2, beta, mu, kind=kind, inner_pc=pc)
+if args.inexact:
+    solver = SlabSolver(args.cells, world, rank, device, k1, k2, beta, mu, kind=kind, inner_pc=pc, smooth=1,
+                        inner_reduction=0.1, inner_norm=1)
+else:
+    solver = SlabSolver(args.cells, world, rank, device, k1, k2, beta, mu, kind=kind, inner_pc=pc)
 mono = args.solver != "picard"
 if mono:
     solver.cfg.picard = 0
