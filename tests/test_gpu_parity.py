@@ -671,6 +671,7 @@ def test_hip_matches_cpu_port_mid_size(gpu_ctx_factory, hexa, N, norm, red):
     of CG iterations, same solution)."""
     from oracle import dpp_cpu as cpu
 
+    cpu.set_threads(8)     # fixed reduction order of the C port, whatever the host offers
     f = _ffi()
     kind = f.CELL_HEX if hexa else f.CELL_TET
     S = cpu.CpuSystem(3, kind, N, N, N)
@@ -961,6 +962,7 @@ def test_odd_mid_size_shapes_match_cpu_port(gpu_ctx_factory, hexa, shape):
     (odd meshes have no coarser level: the comparison uses the Jacobi-preconditioned block solves of both)."""
     from oracle import dpp_cpu as cpu
 
+    cpu.set_threads(8)     # fixed reduction order of the C port, whatever the host offers
     f = _ffi()
     nx, ny, nz = shape
     kind = f.CELL_HEX if hexa else f.CELL_TET
