@@ -204,6 +204,34 @@ extern "C" int pph_comm_selftest(pph_ctx* ctx) {
   PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int i = 0; i < n; ++i)
     PPH_REQUIRE(ctx, g[(size_t)i] == h[(size_t)i], "RCCL self send/recv returned wrong data at %d", i);
+  if (ctx->world > 1) {
+    // the halo pattern itself: one grouped exchange with both slab neighbours, received data verified
+    DevBuf<double> lo, hi;
+    PPH_TRY(lo.alloc(ctx, n));
+    PPH_TRY(hi.alloc(ctx, n));
+    const bool has_lo = ctx->rank > 0, has_hi = ctx->rank + 1 < ctx->world;
+    RCCL_TRY(ctx, g_rccl.GroupStart());
+    if (has_lo) {
+      RCCL_TRY(ctx, g_rccl.Send(a.p, (size_t)n, RCCL_DOUBLE, ctx->rank - 1, ctx->nccl_comm, ctx->stream));
+      RCCL_TRY(ctx, g_rccl.Recv(lo.p, (size_t)n, RCCL_DOUBLE, ctx->rank - 1, ctx->nccl_comm, ctx->stream));
+    }
+    if (has_hi) {
+      RCCL_TRY(ctx, g_rccl.Send(a.p, (size_t)n, RCCL_DOUBLE, ctx->rank + 1, ctx->nccl_comm, ctx->stream));
+      RCCL_TRY(ctx, g_rccl.Recv(hi.p, (size_t)n, RCCL_DOUBLE, ctx->rank + 1, ctx->nccl_comm, ctx->stream));
+    }
+    RCCL_TRY(ctx, g_rccl.GroupEnd());
+    for (int side = 0; side < 2; ++side) {
+      if (!(side == 0 ? has_lo : has_hi)) continue;
+      const int peer = side == 0 ? ctx->rank - 1 : ctx->rank + 1;
+      PPH_HIP(ctx, hipMemcpyAsync(g.data(), side == 0 ? lo.p : hi.p, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream));
+      PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      for (int i = 0; i < n; ++i)
+        PPH_REQUIRE(ctx, g[(size_t)i] == 1000.0 * peer + i, "RCCL neighbour exchange with rank %d returned wrong data at %d",
+                    peer, i);
+    }
+    lo.release();
+    hi.release();
+  }
   double v[3] = {1.0, (double)(ctx->rank + 1), 0.5};
   PPH_TRY(comm_allreduce_host(ctx, v, 3));
   const double w = (double)ctx->world;

@@ -44,7 +44,9 @@ def init_rccl(ctx: _ffi.Context, group=None) -> None:
     path = _loaded_rccl_path()
     ident = np.zeros(128, dtype=np.uint8)
     if rank == 0:
-        ctx._check(_ffi.lib.pph_rccl_unique_id(path, ident.ctypes.data_as(C.c_void_p)))
+        # a failure here must still reach the broadcast below, or the other ranks would wait for it forever
+        if _ffi.lib.pph_rccl_unique_id(path, ident.ctypes.data_as(C.c_void_p)) != _ffi.PPH_OK:
+            ident[:] = 0
     t = torch.from_numpy(ident)
     if dist.get_backend(group) == "nccl":
         d = t.cuda()
@@ -53,6 +55,8 @@ def init_rccl(ctx: _ffi.Context, group=None) -> None:
     else:
         dist.broadcast(t, 0, group=group)
     ident = np.ascontiguousarray(ident)
+    if not ident.any():
+        raise RuntimeError("rank 0 could not draw an RCCL unique id (librccl not loadable?)")
     ctx._check(_ffi.lib.pph_comm_init_rccl(ctx._h, rank, world, ident.ctypes.data_as(C.c_void_p), path))
     ctx._check(_ffi.lib.pph_comm_selftest(ctx._h))
 
@@ -157,12 +161,26 @@ class SlabSolver:
             transport = "rccl" if self.comm.backend == "nccl" else "torch"
         self.transport = transport
         if transport == "rccl":
+            ok = 1
             try:
                 init_rccl(self.ctx, group)
             except Exception as e:
+                ok = 0
                 if world > 1:
-                    print(f"[perphil_amd.distributed] RCCL transport unavailable on rank {rank} ({e!r}); "
-                          "falling back to torch.distributed callbacks", flush=True)
+                    print(f"[perphil_amd.distributed] RCCL transport unavailable on rank {rank} ({e!r})", flush=True)
+            # every rank must end up on the same transport: one failed self-test sends all of them to the callbacks
+            if world > 1:
+                import torch
+                import torch.distributed as dist
+
+                flag = torch.tensor([float(ok)])
+                if self.comm.backend == "nccl":
+                    flag = flag.cuda()
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+                ok = int(flag.item())
+            if not ok:
+                if world > 1 and rank == 0:
+                    print("[perphil_amd.distributed] falling back to torch.distributed callbacks on all ranks", flush=True)
                 self.transport = "torch"
         if self.transport == "torch":
             self.comm.attach(self.ctx)
