@@ -202,9 +202,18 @@ int pph_comm_set_callbacks(pph_ctx* ctx, int rank, int world, pph_halo_fn halo, 
  * dlopen (`libpath` may be NULL/empty: default search, then /opt/rocm/lib).  Rank 0 draws the 128-byte
  * unique id, the launcher broadcasts it, every rank calls pph_comm_init_rccl; pph_comm_selftest verifies
  * a send/recv to self and an all-reduce on the context stream. */
+int pph_rccl_available(const char* libpath);   /* 0 when librccl loads with every entry point used here: every rank
+                                                * checks (and the launcher agrees on the result) BEFORE any rank enters
+                                                * ncclCommInitRank */
 int pph_rccl_unique_id(const char* libpath, uint8_t* id128);
 int pph_comm_init_rccl(pph_ctx* ctx, int rank, int world, const uint8_t* id128, const char* libpath);
+/* straight-line self-test: every rank issues all three phases (to self, both slab neighbours, all-reduce) whatever
+ * fails on the way, and reports afterwards; ranks_seen (optional) = world size observed by the all-reduce */
 int pph_comm_selftest(pph_ctx* ctx);
+int pph_comm_selftest2(pph_ctx* ctx, int* ranks_seen);
+/* halo exchanges and all-reduces of the last solve, and the sticky communication status: after the first failed
+ * exchange / reduction on a context every solve returns PPH_ERR_COMM until the transport is set up again */
+int pph_comm_stats(pph_ctx* ctx, int64_t* halo_exchanges, int64_t* allreduces, int* status);
 
 /* ---- stats ---------------------------------------------------------------------------------
  * replaces: PETSc -log_view event times scraped by reference src/perphil/experiments/petsc_profiling.py:302-447.

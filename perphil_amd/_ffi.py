@@ -33,7 +33,8 @@ EXPORTS = [
     "pph_solve", "pph_solve_device", "pph_get_solution",
     "pph_csr_sizes", "pph_get_csr", "pph_get_rhs", "pph_spmv", "pph_spmv_bench",
     "pph_get_timers", "pph_set_option", "pph_comm_set_callbacks",
-    "pph_rccl_unique_id", "pph_comm_init_rccl", "pph_comm_selftest", "pph_error_norms_mms", "pph_bw_probe",
+    "pph_rccl_available", "pph_rccl_unique_id", "pph_comm_init_rccl", "pph_comm_selftest", "pph_comm_selftest2",
+    "pph_comm_stats", "pph_error_norms_mms", "pph_bw_probe",
     "pph_darcy_velocity",
 ]
 
@@ -126,6 +127,9 @@ def _load() -> C.CDLL:
         "pph_rccl_unique_id": ([C.c_char_p, C.c_void_p], C.c_int),
         "pph_comm_init_rccl": ([p, C.c_int, C.c_int, C.c_void_p, C.c_char_p], C.c_int),
         "pph_comm_selftest": ([p], C.c_int),
+        "pph_comm_selftest2": ([p, C.POINTER(C.c_int)], C.c_int),
+        "pph_comm_stats": ([p, i64p, i64p, C.POINTER(C.c_int)], C.c_int),
+        "pph_rccl_available": ([C.c_char_p], C.c_int),
         "pph_bw_probe": ([p, C.c_int64, C.c_int, C.c_int, f64p], C.c_int),
         "pph_error_norms_mms": ([p, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, f64p,
                                  f64p], C.c_int),
@@ -293,6 +297,11 @@ class Context:
         out = np.empty((self.n, self.dim), dtype=np.float64)
         self._check(lib.pph_darcy_velocity(self._h, _ptr(nodal), float(conductivity), _ptr(out)))
         return out
+
+    def comm_stats(self) -> dict:
+        h, a, st = C.c_int64(), C.c_int64(), C.c_int()
+        self._check(lib.pph_comm_stats(self._h, C.byref(h), C.byref(a), C.byref(st)))
+        return {"halo_exchanges": h.value, "allreduces": a.value, "status": st.value}
 
     def timers(self) -> dict:
         t = np.zeros(14, dtype=np.float64)

@@ -94,6 +94,8 @@ int pph_ctx_create(int device, pph_ctx** out) {
 // the assembled system is stale (parameters / boundary data changed): buffers are kept for re-use
 static void release_system(pph_ctx* ctx) {
   ctx->asm_ok = false;
+  ctx->ell_ok = false;
+  ctx->csr_ok = false;
   ctx->mono_ok = false;
   ctx->mg_ok = false;
 }
@@ -101,6 +103,7 @@ static void release_system(pph_ctx* ctx) {
 // the mesh goes away: free everything that was sized by it
 static void free_system(pph_ctx* ctx) {
   ctx->A11.release(); ctx->A22.release(); ctx->A12.release(); ctx->A21.release();
+  ctx->E11.release(); ctx->E22.release(); ctx->E12.release(); ctx->E21.release();
   ctx->rhs.release(); ctx->u0.release(); ctx->sol.release();
   ctx->mrowptr.release(); ctx->mcol.release(); ctx->mval.release();
   mg_release(ctx);
@@ -115,6 +118,7 @@ int pph_ctx_destroy(pph_ctx* ctx) {
   ctx->mesh.release_all();
   for (int f = 0; f < 2; ++f) { ctx->bcmask[f].release(); ctx->g[f].release(); }
   ctx->rownear.release();
+  ctx->sell_tmp.release();
   ctx->dinv0[0].release(); ctx->dinv0[1].release(); ctx->lam0.release();
   comm_release(ctx);
   for (auto& w : ctx->work) w.release();
@@ -325,12 +329,23 @@ static int select_csr(pph_ctx* ctx, int which, Csr* A) {
       }
       A->val = (which == 1) ? m.K.p : m.M.p;
       return PPH_OK;
-    case 3: PPH_REQUIRE(ctx, ctx->asm_ok, "blocks not assembled"); A->val = ctx->A11.p; return PPH_OK;
-    case 4: PPH_REQUIRE(ctx, ctx->asm_ok, "blocks not assembled"); A->val = ctx->A22.p; return PPH_OK;
-    case 5: PPH_REQUIRE(ctx, ctx->asm_ok, "blocks not assembled"); A->val = ctx->A12.p; return PPH_OK;
-    case 6: PPH_REQUIRE(ctx, ctx->asm_ok, "blocks not assembled"); A->val = ctx->A21p(); return PPH_OK;
+    case 3: case 4: case 5: case 6:
+      PPH_REQUIRE(ctx, ctx->asm_ok, "blocks not assembled");
+      PPH_TRY(pph_ensure_csr_blocks(ctx));   // the fused assembly keeps the blocks in stencil-ELL form only
+      A->val = (which == 3) ? ctx->A11.p : (which == 4) ? ctx->A22.p : (which == 5) ? ctx->A12.p : ctx->A21p();
+      return PPH_OK;
     default: pph_set_error(ctx, "unknown matrix selector %d", which); return PPH_ERR_INVALID;
   }
+}
+
+// scalar-block selectors of pph_spmv / pph_spmv_bench run on a stencil-ELL copy when op_format is 1
+static int attach_sell(pph_ctx* ctx, int which, Csr* A) {
+  if (ctx->op_format != 1 || which == 0) return PPH_OK;
+  if (which >= 3 && ctx->ell_ok) {
+    A->ell = (which == 3) ? ctx->S11 : (which == 4) ? ctx->S22 : (which == 5) ? ctx->S12 : ctx->S21;
+    return PPH_OK;
+  }
+  return sell_from_csr(ctx, ctx->mesh, A->val, ctx->sell_tmp, &A->ell);
 }
 
 int pph_csr_sizes(const pph_ctx* cctx, int which, int64_t* nrows, int64_t* nnz) {
@@ -370,6 +385,7 @@ int pph_spmv(pph_ctx* ctx, int which, const double* x_host, double* y_host) {
   PPH_HIP(ctx, hipSetDevice(ctx->device));
   Csr A;
   PPH_TRY(select_csr(ctx, which, &A));
+  PPH_TRY(attach_sell(ctx, which, &A));
   DevBuf<double> x, y;
   PPH_TRY(x.alloc(ctx, (size_t)A.nrows));
   PPH_TRY(y.alloc(ctx, (size_t)A.nrows));
@@ -400,6 +416,7 @@ int pph_spmv_bench(pph_ctx* ctx, int which, int reps, double* avg_ms) {
   PPH_TRY(select_csr(ctx, which, &A));
   A.lanes = pph_pick_lanes(ctx, A.nnz, A.nrows);
   if (ctx->spmv_kernel == 16) return la_padded_experiment(ctx, A, reps, avg_ms);  // padded-row experiment
+  PPH_TRY(attach_sell(ctx, which, &A));
   DevBuf<double> x, y;
   PPH_TRY(x.alloc(ctx, (size_t)A.nrows));
   PPH_TRY(y.alloc(ctx, (size_t)A.nrows));
@@ -482,6 +499,15 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
     return PPH_OK;
   }
   if (!strcmp(name, "spmv_blocks")) { ctx->spmv_blocks = (int)value; return PPH_OK; }
+  if (!strcmp(name, "device_scalars")) { ctx->device_scalars = value != 0.0 ? 1 : 0; return PPH_OK; }
+  if (!strcmp(name, "op_format")) {
+    PPH_REQUIRE(ctx, value == 0.0 || value == 1.0, "op_format: 0 CSR, 1 stencil-ELL");
+    ctx->op_format = (int)value;
+    return PPH_OK;
+  }
+  if (!strcmp(name, "sell_rpt")) { ctx->sell_rpt = (int)value; return PPH_OK; }
+  if (!strcmp(name, "sell_blocks")) { ctx->sell_blocks = (int)value; return PPH_OK; }
+  if (!strcmp(name, "sell_group")) { ctx->sell_group = (int)value; return PPH_OK; }
   if (!strcmp(name, "asm_fused")) { ctx->asm_fused = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "asm_ring")) { ctx->asm_ring = value > 0.0 ? (int)value : 0; return PPH_OK; }
   if (!strcmp(name, "asm_keep_km")) { ctx->asm_keep_km = value != 0.0 ? 1 : 0; return PPH_OK; }
@@ -511,6 +537,7 @@ int pph_comm_set_callbacks(pph_ctx* ctx, int rank, int world, pph_halo_fn halo, 
   ctx->halo_cb = halo;
   ctx->allreduce_cb = allreduce;
   ctx->comm_user = user;
+  ctx->comm_status = PPH_OK;
   mg_release(ctx);
   ctx->mg_ok = false;
   return PPH_OK;

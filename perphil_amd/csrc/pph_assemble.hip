@@ -660,7 +660,31 @@ struct FuseArgs {
   unsigned long long* lam;         // [2] max_i sum_j |a_ij| / |a_ii| as the bit pattern of a non-negative double
   int keep_km;                     // also store K and M
   int same;                        // both fields carry the same Dirichlet set (one mask gather per entry)
+  // ld > 0: A11 .. A21 are stencil-ELL arrays (pph_sell.hip): entry (row, column row + (dx,dy,dz)) is stored at
+  // [slot_of[(dz+1)*9 + (dy+1)*3 + (dx+1)] * ld + row]; ld == 0: CSR value arrays addressed by the pattern position
+  int64_t ld;
+  int8_t slot_of[27];
 };
+
+static void fuse_set_format(FuseArgs& fa, int kind, int64_t ld) {
+  fa.ld = ld;
+  for (int q = 0; q < 27; ++q) fa.slot_of[q] = -1;
+  const Stencil st = make_stencil(kind);
+  for (int s = 0; s < st.count; ++s) fa.slot_of[(st.d[s][2] + 1) * 9 + (st.d[s][1] + 1) * 3 + (st.d[s][0] + 1)] = (int8_t)s;
+}
+
+// output position of the entry (node, column j): the CSR position k or the stencil-ELL address
+__device__ __forceinline__ int64_t fuse_out_index(const FuseArgs& fa, int64_t k, int64_t node, int32_t j, int px, int py) {
+  if (fa.ld == 0) return k;
+  const int i0 = (int)(node % px);
+  const int64_t t0 = node / px;
+  const int j0 = (int)(t0 % py), k0 = (int)(t0 / py);
+  const int i1 = (int)(j % px);
+  const int64_t t1 = (int64_t)j / px;
+  const int j1 = (int)(t1 % py), k1 = (int)(t1 / py);
+  const int s = fa.slot_of[(k1 - k0 + 1) * 9 + (j1 - j0 + 1) * 3 + (i1 - i0 + 1)];
+  return (int64_t)s * fa.ld + node;
+}
 // A12 / A21 null: coupling blocks not wanted; rhs null: no lifting (multigrid coarse levels: g1, g2, u0 unused)
 
 template <int DIM, bool FUSED = false, bool CLOSED = false>
@@ -813,10 +837,11 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__
             o12 = (r1 != 0 || c2) ? 0.0 : -fa.b * mv;
             o21 = (r2 != 0 || c1) ? 0.0 : -fa.b * mv;
           }
-          fa.A11[k] = o11;
-          fa.A22[k] = o22;
-          if (fa.A12) fa.A12[k] = o12;
-          if (fa.A21) fa.A21[k] = o21;
+          const int64_t ko = fuse_out_index(fa, k, node, j, px, py);
+          fa.A11[ko] = o11;
+          fa.A22[ko] = o22;
+          if (fa.A12) fa.A12[ko] = o12;
+          if (fa.A21) fa.A21[ko] = o21;
           s11 += fabs(o11); s22 += fabs(o22);
           if (diag) { d11 = o11; d22 = o22; }
         }
@@ -1002,10 +1027,11 @@ __global__ __launch_bounds__(256) void k_asm_simplex_gather(const int32_t* __res
             o12 = (r1 != 0 || c2) ? 0.0 : -fa.b * mv;
             o21 = (r2 != 0 || c1) ? 0.0 : -fa.b * mv;
           }
-          fa.A11[s + q] = o11;
-          fa.A22[s + q] = o22;
-          if (fa.A12) fa.A12[s + q] = o12;
-          if (fa.A21) fa.A21[s + q] = o21;
+          const int64_t ko = fuse_out_index(fa, s + q, node, jc, px, py);
+          fa.A11[ko] = o11;
+          fa.A22[ko] = o22;
+          if (fa.A12) fa.A12[ko] = o12;
+          if (fa.A21) fa.A21[ko] = o21;
           s11 += fabs(o11); s22 += fabs(o22);
           if (diag) { d11 = o11; d22 = o22; }
         }
@@ -1329,11 +1355,27 @@ __global__ __launch_bounds__(256) void k_mono_fill(const int64_t* __restrict__ r
 }
 
 // buffers of the eliminated system and everything that depends on the Dirichlet sets only
-static int blocks_prepare(pph_ctx* ctx) {
-  const int64_t n = ctx->n, nnzb = ctx->nnzb;
+static int blocks_alloc_csr(pph_ctx* ctx) {
+  const int64_t nnzb = ctx->nnzb;
   PPH_TRY(ctx->A11.alloc(ctx, (size_t)nnzb));
   PPH_TRY(ctx->A22.alloc(ctx, (size_t)nnzb));
   PPH_TRY(ctx->A12.alloc(ctx, (size_t)nnzb));
+  if (ctx->a21_alias) ctx->A21.release();
+  else PPH_TRY(ctx->A21.alloc(ctx, (size_t)nnzb));
+  return PPH_OK;
+}
+
+static int blocks_alloc_sell(pph_ctx* ctx) {
+  PPH_TRY(sell_alloc(ctx, ctx->mesh, ctx->E11, &ctx->S11));
+  PPH_TRY(sell_alloc(ctx, ctx->mesh, ctx->E22, &ctx->S22));
+  PPH_TRY(sell_alloc(ctx, ctx->mesh, ctx->E12, &ctx->S12));
+  if (ctx->a21_alias) { ctx->E21.release(); ctx->S21 = ctx->S12; }
+  else PPH_TRY(sell_alloc(ctx, ctx->mesh, ctx->E21, &ctx->S21));
+  return PPH_OK;
+}
+
+static int blocks_prepare(pph_ctx* ctx, bool want_csr) {
+  const int64_t n = ctx->n;
   // same Dirichlet set on both fields (every reference configuration): A21 == A12, stored once
   if (ctx->bc_dirty) {
     int* flag = reinterpret_cast<int*>(ctx->scal.p + (PPH_MAX_SCAL - 200));
@@ -1349,8 +1391,7 @@ static int blocks_prepare(pph_ctx* ctx) {
                        ctx->mesh.col.p, ctx->bcmask[0].p, ctx->bcmask[1].p, n, ctx->rownear.p);
     ctx->bc_dirty = false;
   }
-  if (ctx->a21_alias) ctx->A21.release();
-  else PPH_TRY(ctx->A21.alloc(ctx, (size_t)nnzb));
+  if (want_csr) PPH_TRY(blocks_alloc_csr(ctx));
   PPH_TRY(ctx->rhs.alloc(ctx, (size_t)(2 * n)));
   PPH_TRY(ctx->u0.alloc(ctx, (size_t)(2 * n)));
   PPH_TRY(ctx->sol.alloc(ctx, (size_t)(2 * n)));
@@ -1363,6 +1404,7 @@ static int blocks_mono(pph_ctx* ctx, int monolithic) {
   int grid = (int)(nb < 256 * 16 ? nb : 256 * 16);
   ctx->mono_ok = false;
   if (monolithic) {
+    PPH_TRY(pph_ensure_csr_blocks(ctx));
     PPH_REQUIRE(ctx, 4 * nnzb < (int64_t)2147483647 * 4 && 2 * n < (int64_t)2147483647,
                 "monolithic system too large for int32 columns");
     PPH_TRY(ctx->mrowptr.alloc(ctx, (size_t)(2 * n + 1)));
@@ -1378,9 +1420,22 @@ static int blocks_mono(pph_ctx* ctx, int monolithic) {
   return PPH_OK;
 }
 
+// CSR values of the blocks from their stencil-ELL copies (export, monolithic CSR, Jacobi / 2x2-block preconditioners)
+int pph_ensure_csr_blocks(pph_ctx* ctx) {
+  if (ctx->csr_ok) return PPH_OK;
+  PPH_REQUIRE(ctx, ctx->ell_ok, "blocks not assembled");
+  PPH_TRY(blocks_alloc_csr(ctx));
+  PPH_TRY(sell_to_csr(ctx, ctx->mesh, ctx->S11, ctx->A11.p));
+  PPH_TRY(sell_to_csr(ctx, ctx->mesh, ctx->S22, ctx->A22.p));
+  PPH_TRY(sell_to_csr(ctx, ctx->mesh, ctx->S12, ctx->A12.p));
+  if (!ctx->a21_alias) PPH_TRY(sell_to_csr(ctx, ctx->mesh, ctx->S21, ctx->A21.p));
+  ctx->csr_ok = true;
+  return PPH_OK;
+}
+
 int pph_launch_blocks(pph_ctx* ctx, int monolithic) {
   const int64_t n = ctx->n;
-  PPH_TRY(blocks_prepare(ctx));
+  PPH_TRY(blocks_prepare(ctx, true));
   int64_t nb = ceil_div64(n * BC_LANES, 256);
   int grid = (int)(nb < 256 * 16 ? nb : 256 * 16);
   hipLaunchKernelGGL(k_lift_rhs, dim3(grid), dim3(256), 0, ctx->stream, ctx->mesh.rowptr.p, ctx->mesh.col.p, ctx->mesh.K.p,
@@ -1391,6 +1446,17 @@ int pph_launch_blocks(pph_ctx* ctx, int monolithic) {
                      ctx->A12.p, ctx->a21_alias ? nullptr : ctx->A21.p);
   PPH_HIP(ctx, hipGetLastError());
   ctx->diag0_valid = false;
+  ctx->csr_ok = true;
+  ctx->ell_ok = false;
+  if (ctx->op_format == 1) {
+    // the block solves run on stencil-ELL copies
+    PPH_TRY(sell_from_csr(ctx, ctx->mesh, ctx->A11.p, ctx->E11, &ctx->S11));
+    PPH_TRY(sell_from_csr(ctx, ctx->mesh, ctx->A22.p, ctx->E22, &ctx->S22));
+    PPH_TRY(sell_from_csr(ctx, ctx->mesh, ctx->A12.p, ctx->E12, &ctx->S12));
+    if (ctx->a21_alias) { ctx->E21.release(); ctx->S21 = ctx->S12; }
+    else PPH_TRY(sell_from_csr(ctx, ctx->mesh, ctx->A21.p, ctx->E21, &ctx->S21));
+    ctx->ell_ok = true;
+  }
   return blocks_mono(ctx, monolithic);
 }
 
@@ -1477,8 +1543,9 @@ int pph_launch_fused_kernels(pph_ctx* ctx, MeshData& mesh, const FuseArgs& fa, d
 // rows, with the smoother's diagonal inverses and spectral bounds (no K/M, no coupling blocks, no lifting)
 int pph_launch_level_operators(pph_ctx* ctx, MeshData& mesh, const uint8_t* m1, const uint8_t* m2, const uint8_t* near,
                                int same, double coefK1, double coefK2, double coefM, double* A1, double* A2,
-                               double* dinv1, double* dinv2, unsigned long long* lam) {
+                               double* dinv1, double* dinv2, unsigned long long* lam, int64_t ell_ld) {
   FuseArgs fa;
+  fuse_set_format(fa, mesh.kind, ell_ld);
   fa.m1 = m1; fa.m2 = m2; fa.near = near;
   fa.g1 = nullptr; fa.g2 = nullptr;
   fa.a = coefK1; fa.b = coefM; fa.c = coefK2;
@@ -1500,7 +1567,9 @@ void pph_launch_row_near(pph_ctx* ctx, const MeshData& mesh, const uint8_t* m1, 
 int pph_launch_assemble_fused(pph_ctx* ctx, int monolithic) {
   MeshData& mesh = ctx->mesh;
   const int64_t n = ctx->n;
-  PPH_TRY(blocks_prepare(ctx));
+  const bool ell = ctx->op_format == 1;
+  PPH_TRY(blocks_prepare(ctx, !ell));
+  if (ell) PPH_TRY(blocks_alloc_sell(ctx));
   if (ctx->asm_keep_km) {
     PPH_TRY(mesh.K.alloc(ctx, (size_t)mesh.nnzb));
     PPH_TRY(mesh.M.alloc(ctx, (size_t)mesh.nnzb));
@@ -1513,7 +1582,12 @@ int pph_launch_assemble_fused(pph_ctx* ctx, int monolithic) {
   fa.m1 = ctx->bcmask[0].p; fa.m2 = ctx->bcmask[1].p; fa.near = ctx->rownear.p;
   fa.g1 = ctx->g[0].p; fa.g2 = ctx->g[1].p;
   fa.a = ctx->a; fa.b = ctx->b; fa.c = ctx->c;
-  fa.A11 = ctx->A11.p; fa.A22 = ctx->A22.p; fa.A12 = ctx->A12.p; fa.A21 = ctx->a21_alias ? nullptr : ctx->A21.p;
+  if (ell) {
+    fa.A11 = ctx->E11.p; fa.A22 = ctx->E22.p; fa.A12 = ctx->E12.p; fa.A21 = ctx->a21_alias ? nullptr : ctx->E21.p;
+  } else {
+    fa.A11 = ctx->A11.p; fa.A22 = ctx->A22.p; fa.A12 = ctx->A12.p; fa.A21 = ctx->a21_alias ? nullptr : ctx->A21.p;
+  }
+  fuse_set_format(fa, mesh.kind, ell ? ctx->S11.ld : 0);
   fa.rhs = ctx->rhs.p; fa.u0 = ctx->u0.p;
   fa.dinv1 = ctx->dinv0[0].p; fa.dinv2 = ctx->dinv0[1].p;
   fa.lam = ctx->lam0.p;
@@ -1524,6 +1598,8 @@ int pph_launch_assemble_fused(pph_ctx* ctx, int monolithic) {
   PPH_HIP(ctx, hipGetLastError());
   mesh.km_valid = ctx->asm_keep_km != 0;
   ctx->diag0_valid = true;
+  ctx->ell_ok = ell;
+  ctx->csr_ok = !ell;
   return blocks_mono(ctx, monolithic);
 }
 

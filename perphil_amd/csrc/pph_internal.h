@@ -55,6 +55,52 @@ struct DevBuf {
 struct Seg { int64_t off1, len1, off2, len2; };
 
 struct MeshData;
+
+// Stencil-ELL ("SELL") operator storage of a scalar block on a structured level: val[s * ld + row], slot s = the
+// s-th offset of the cell kind's stencil in ascending (dz,dy,dx) order - the column order of the CSR pattern -
+// and an explicit 0 where the neighbour lies outside the local box.  No column indices and no row pointers:
+// col = row + dx + px * (dy + py * dz).  8 B per stored entry instead of 12 B, every load coalesced across rows.
+struct Sell {
+  const double* val = nullptr;
+  int64_t ld = 0;            // leading dimension: rows rounded up to a multiple of 64
+  int kind = -1;             // PPH_CELL_*
+  int px = 0, py = 0, pz = 0;  // node dims of the local box
+};
+static inline int sell_slots(int kind) {
+  return kind == PPH_CELL_QUAD ? 9 : kind == PPH_CELL_TRI ? 7 : kind == PPH_CELL_HEX ? 27 : 15;
+}
+static inline int64_t sell_ld(int64_t n) { return (n + 63) & ~(int64_t)63; }
+
+// neighbour offsets of a row of the scalar pattern, in ascending (dz,dy,dx) = ascending column order
+struct Stencil {
+  int count;
+  int8_t d[27][3];
+};
+
+static inline Stencil make_stencil(int kind) {
+  Stencil s;
+  s.count = 0;
+  auto push = [&](int dx, int dy, int dz) {
+    s.d[s.count][0] = (int8_t)dx; s.d[s.count][1] = (int8_t)dy; s.d[s.count][2] = (int8_t)dz; s.count++;
+  };
+  if (kind == PPH_CELL_QUAD) {
+    for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) push(dx, dy, 0);
+  } else if (kind == PPH_CELL_TRI) {
+    // edges: x, y and the "left" diagonal (-1,+1)
+    push(0, -1, 0); push(1, -1, 0); push(-1, 0, 0); push(0, 0, 0); push(1, 0, 0); push(-1, 1, 0); push(0, 1, 0);
+  } else if (kind == PPH_CELL_HEX) {
+    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) push(dx, dy, dz);
+  } else {
+    // Kuhn edges: x, y, z, x+y, x+z, y+z, x+y+z (both signs) + self
+    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
+      bool pos = dx >= 0 && dy >= 0 && dz >= 0;
+      bool neg = dx <= 0 && dy <= 0 && dz <= 0;
+      if (pos || neg) push(dx, dy, dz);
+    }
+  }
+  return s;
+}
+
 struct Csr {  // device CSR view (no ownership)
   const int64_t* rowptr = nullptr;
   const int32_t* col = nullptr;
@@ -65,6 +111,7 @@ struct Csr {  // device CSR view (no ownership)
   const MeshData* geom = nullptr;  // slab geometry of the rows (halo exchange of x before the product); may be null
   int lanes = 8;    // lanes per row used by the CSR-vector SpMV kernel
   int max_row = 0;  // longest row (0: unknown) - selects the CSR-stream kernel geometry
+  Sell ell;         // when ell.val is set the product runs on the stencil-ELL copy of the same matrix
 };
 
 // one structured mesh level (local box): geometry, cell->dof map, scalar pattern, K and M
@@ -99,6 +146,8 @@ struct MgLevel {
   int64_t n = 0, nnz = 0;
   int px = 0, py = 0, pz = 0;
   DevBuf<double> own_val[2];     // storage of val[] on coarse levels
+  DevBuf<double> own_ell[2];     // stencil-ELL storage of the level operators (op_format 1; level 0 aliases the context's)
+  Sell ell[2];                   // views used by the products when ell[f].val is set
   DevBuf<float> val32[2];        // fp32 copies of val[] for the smoother / residual SpMVs of the V-cycle
   DevBuf<double> dinv[2];
   DevBuf<uint8_t> mask[2];       // per field: non-zero where the dof is constrained
@@ -138,6 +187,12 @@ struct pph_ctx {
   DevBuf<double> A11, A22, A12, A21;    // eliminated blocks on the scalar pattern
   bool a21_alias = false;               // both fields share one Dirichlet set: A21 == A12, A21 not stored
   const double* A21p() const { return a21_alias ? A12.p : A21.p; }
+  // stencil-ELL copies of the blocks (op_format 1).  The fused assembly writes ONLY these; the CSR arrays above are
+  // then materialised on demand (pph_ensure_csr_blocks: export, monolithic CSR, Jacobi / 2x2-block preconditioners)
+  DevBuf<double> E11, E22, E12, E21;
+  Sell S11, S22, S12, S21;              // views of E* (S21 == S12 when a21_alias)
+  bool ell_ok = false;                  // S* hold the assembled blocks
+  bool csr_ok = false;                  // A11 .. A21 hold the assembled blocks
   DevBuf<double> rhs, u0, sol;          // length 2n
   DevBuf<int64_t> mrowptr;              // monolithic CSR
   DevBuf<int32_t> mcol;
@@ -154,6 +209,9 @@ struct pph_ctx {
   std::vector<double> h_stage;          // host staging for vector all-reduces
   bool comm_suspended = false;          // true while working on replicated (non-distributed) coarse levels
   int64_t n_halo = 0;                   // halo exchanges of the last solve
+  int64_t n_allreduce = 0;              // all-reduces (scalars and replicated-level vectors) of the last solve
+  int comm_status = 0;                  // sticky: PPH_ERR_COMM after the first failed exchange / reduction (pph_comm.hip)
+  std::string comm_error;               // its message
 
   // solver workspace
   DevBuf<double> scal;                  // device scalars / reduction partials
@@ -179,12 +237,17 @@ struct pph_ctx {
   size_t ev_used = 0;                   // pairs recorded since the last harvest
   int spmv_lanes_override = 0;          // 0: pick from the mean row length
   int spmv_blocks = 0;                  // 0: default persistent grid (1024 workgroups)
+  int device_scalars = 0;               // 1: the device-scalar CG branch also over the callback transport (tests)
   int coarse_on_device = 1;             // coarsest multigrid level (<= 4096 rows): CG inside one workgroup, no host round trips
   int spmv_bench_mode = 0;              // pph_spmv_bench protocol: 0 back-to-back, 1-3 interleaved (see pph_api.hip)
   int64_t mg_replicate_below = 40000;   // slabs: multigrid levels with at most this many global nodes are replicated
   int mg_fp32 = 0;                      // 1: V-cycle SpMVs read fp32 copies of the operator values (8 instead of 12 B per non-zero)
   int asm_kernel = 2;                   // multilinear cells: 2 two-pass (element rows + node gather, default), 1 one-pass node gather, 0 cell-centred atomic scatter-add
   int spmv_kernel = 3;                  // 3: aligned-wide CSR-vector (default); 0,1,2,4..8,10: variants kept for A/B runs
+  // operator format of the scalar blocks inside the block solves / Picard sweeps: 1 stencil-ELL (pph_sell.hip), 0 CSR
+  int op_format = 1;
+  int sell_rpt = 2, sell_blocks = 0, sell_group = 0;   // SELL SpMV tuning: rows per thread, grid cap, XCD chunk group
+  DevBuf<double> sell_tmp;              // SELL copy of the matrix last selected by pph_spmv / pph_spmv_bench
 };
 
 // lanes per row of the CSR-vector SpMV for a matrix with the given mean row length
@@ -203,10 +266,12 @@ int pph_launch_pattern(pph_ctx* ctx, int dim, int kind, int px, int py, int pz, 
 int pph_launch_assemble_KM(pph_ctx* ctx, MeshData& mesh);
 int pph_launch_blocks(pph_ctx* ctx, int monolithic);
 bool pph_can_fuse_assembly(const pph_ctx* ctx);
+int pph_ensure_csr_blocks(pph_ctx* ctx);   // CSR values of A11, A22, A12 (, A21) from the stencil-ELL copies when missing
 int pph_launch_assemble_fused(pph_ctx* ctx, int monolithic);
+// A1, A2: CSR value arrays (ell_ld == 0) or stencil-ELL arrays with leading dimension ell_ld
 int pph_launch_level_operators(pph_ctx* ctx, MeshData& mesh, const uint8_t* m1, const uint8_t* m2, const uint8_t* near,
                                int same, double coefK1, double coefK2, double coefM, double* A1, double* A2,
-                               double* dinv1, double* dinv2, unsigned long long* lam);
+                               double* dinv1, double* dinv2, unsigned long long* lam, int64_t ell_ld);
 void pph_launch_row_near(pph_ctx* ctx, const MeshData& mesh, const uint8_t* m1, const uint8_t* m2, uint8_t* out);
 
 // linear algebra on the context stream; all results that feed control flow go through ctx->scal
@@ -257,6 +322,13 @@ void comm_release(pph_ctx* ctx);
 // adds the elapsed times of all event pairs recorded since the last call to ctx->t_spmv (synchronises)
 void la_harvest_spmv_times(pph_ctx* ctx);
 void la_reset_spmv_stats(pph_ctx* ctx);
+
+// stencil-ELL operator format (pph_sell.hip)
+int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x, const double* b, const double* dinv,
+              double w, double* y, double* part);
+int sell_alloc(pph_ctx* ctx, const MeshData& mesh, DevBuf<double>& buf, Sell* out);
+int sell_from_csr(pph_ctx* ctx, const MeshData& mesh, const double* csr_val, DevBuf<double>& buf, Sell* out);
+int sell_to_csr(pph_ctx* ctx, const MeshData& mesh, const Sell& E, double* csr_val);
 
 // block values + Dirichlet elimination on any level: out = (row constrained) ? I : coefK*K + coefM*M with
 // constrained columns zeroed

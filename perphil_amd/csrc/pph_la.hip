@@ -761,6 +761,16 @@ static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const doub
   }
   int grid = 8;
   double bytes_per_nnz = 12.0;
+  if (A.ell.val) {
+    // stencil-ELL copy of the operator (pph_sell.hip): 8 B per stored entry, no index arrays
+    grid = sell_spmv(ctx, A.ell, A.nrows, DOT ? 2 : (bvec ? 1 : 0), x, bvec, nullptr, 0.0, y, part);
+    if (ev) (void)hipEventRecord(ev->e1, ctx->stream);
+    const double bytes = 8.0 * sell_slots(A.ell.kind) * (double)A.nrows + 16.0 * (double)A.nrows;
+    ctx->n_spmv[variant]++;
+    ctx->spmv_bytes[variant] += bytes;
+    if (A.nrows >= ctx->mesh.n) { ctx->n_spmv_fine++; ctx->spmv_bytes_fine += bytes; }
+    return grid;
+  }
   if (A.val32) {
     // fp32-valued operator (multigrid levels): aligned-wide kernel, 8 lanes per row
     const int G = (A.max_row > 0 && A.max_row + 3 <= 16) ? 4 : 8;
@@ -1179,10 +1189,14 @@ void la_extract_diag_inv(pph_ctx* ctx, const Csr& A, double* dinv) {
 // those read them from ctx->scal, the host has to see one number per iteration (the residual norm for the
 // convergence test) instead of three.  Possible on a single context and with the RCCL transport (sums are
 // all-reduced on the stream); the callback transport reduces on the host and keeps the host-scalar path.
-bool la_device_scalars(const pph_ctx* ctx) { return ctx->world == 1 || ctx->comm_suspended || ctx->nccl_comm != nullptr; }
+// (option "device_scalars" = 1 runs the same branch over the callback transport - the all-reduce then stages through
+// the host - so that the multi-rank tests on one GPU cover the code the RCCL run executes)
+bool la_device_scalars(const pph_ctx* ctx) {
+  return ctx->world == 1 || ctx->comm_suspended || ctx->nccl_comm != nullptr || ctx->device_scalars;
+}
 
 int la_reduce_device(pph_ctx* ctx, int slot, int count) {
-  if (ctx->world > 1 && !ctx->comm_suspended && ctx->nccl_comm) return comm_allreduce_device(ctx, ctx->scal.p + slot, count);
+  if (ctx->world > 1 && !ctx->comm_suspended) return comm_allreduce_device(ctx, ctx->scal.p + slot, count);
   return PPH_OK;
 }
 
@@ -1191,6 +1205,7 @@ int la_fetch_raw(pph_ctx* ctx, int slot, int count) {
   PPH_HIP(ctx, hipMemcpyAsync(ctx->h_scal + slot, ctx->scal.p + slot, sizeof(double) * (size_t)count,
                               hipMemcpyDeviceToHost, ctx->stream));
   PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->comm_status != PPH_OK) { ctx->err = ctx->comm_error; return ctx->comm_status; }
   return PPH_OK;
 }
 
@@ -1242,6 +1257,8 @@ int la_fetch(pph_ctx* ctx, int slot, int count) {
                               hipMemcpyDeviceToHost, ctx->stream));
   PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (reduce && !ctx->nccl_comm) PPH_TRY(comm_allreduce_host(ctx, ctx->h_scal + slot, (int64_t)count));
+  // a halo exchange or vector all-reduce that failed since the last fetch (their callers cannot return a status)
+  if (ctx->comm_status != PPH_OK) { ctx->err = ctx->comm_error; return ctx->comm_status; }
   return PPH_OK;
 }
 

@@ -63,35 +63,6 @@ __global__ void k_dofmap(int32_t* __restrict__ cells, int kind, int nx, int ny, 
 // sparsity pattern: fixed stencil per cell kind, listed in ascending (dz,dy,dx) order so that the
 // columns of a row come out sorted
 // ------------------------------------------------------------------------------------------------
-struct Stencil {
-  int count;
-  int8_t d[27][3];
-};
-
-static Stencil make_stencil(int kind) {
-  Stencil s;
-  s.count = 0;
-  auto push = [&](int dx, int dy, int dz) {
-    s.d[s.count][0] = (int8_t)dx; s.d[s.count][1] = (int8_t)dy; s.d[s.count][2] = (int8_t)dz; s.count++;
-  };
-  if (kind == PPH_CELL_QUAD) {
-    for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) push(dx, dy, 0);
-  } else if (kind == PPH_CELL_TRI) {
-    // edges: x, y and the "left" diagonal (-1,+1)
-    push(0, -1, 0); push(1, -1, 0); push(-1, 0, 0); push(0, 0, 0); push(1, 0, 0); push(-1, 1, 0); push(0, 1, 0);
-  } else if (kind == PPH_CELL_HEX) {
-    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) push(dx, dy, dz);
-  } else {
-    // Kuhn edges: x, y, z, x+y, x+z, y+z, x+y+z (both signs) + self
-    for (int dz = -1; dz <= 1; ++dz) for (int dy = -1; dy <= 1; ++dy) for (int dx = -1; dx <= 1; ++dx) {
-      bool pos = dx >= 0 && dy >= 0 && dz >= 0;
-      bool neg = dx <= 0 && dy <= 0 && dz <= 0;
-      if (pos || neg) push(dx, dy, dz);
-    }
-  }
-  return s;
-}
-
 __global__ void k_row_count(int32_t* __restrict__ cnt, Stencil st, int px, int py, int pz, int64_t n) {
   for (int64_t id = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; id < n;
        id += (int64_t)gridDim.x * blockDim.x) {

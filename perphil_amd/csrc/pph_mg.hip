@@ -272,6 +272,7 @@ static Csr level_csr(const pph_ctx* ctx, const MgLevel& L, int which, bool lowp 
   Csr A;
   A.rowptr = L.rowptr; A.col = L.col; A.val = L.val[which]; A.nrows = L.n; A.nnz = L.nnz;
   if (lowp && ctx->mg_fp32 && L.val32[which].p) A.val32 = L.val32[which].p;
+  else A.ell = L.ell[which];
   A.max_row = ctx->mesh.max_row;
   A.geom = (ctx->world > 1 && !L.replicated) ? L.geom : nullptr;
   A.lanes = pph_pick_lanes(ctx, A.nnz, A.nrows);
@@ -290,7 +291,10 @@ void mg_release(pph_ctx* ctx) {
   for (size_t l = 0; l < ctx->mg.size(); ++l) {
     MgLevel& L = ctx->mg[l];
     if (l > 0) L.mesh.release_all();
-    for (int f = 0; f < 2; ++f) { L.own_val[f].release(); L.dinv[f].release(); L.mask[f].release(); L.val32[f].release(); }
+    for (int f = 0; f < 2; ++f) {
+      L.own_val[f].release(); L.own_ell[f].release(); L.dinv[f].release(); L.mask[f].release(); L.val32[f].release();
+      L.ell[f] = Sell();
+    }
     L.x.release(); L.b.release(); L.r.release(); L.d.release(); L.t.release(); L.w.release();
   }
   ctx->mg.clear();
@@ -364,12 +368,18 @@ int mg_setup(pph_ctx* ctx) {
   PPH_TRY(lamdev.alloc(ctx, (size_t)(2 * nlev)));   // spectral bounds of all levels: read back once after the loop
   PPH_HIP(ctx, hipMemsetAsync(lamdev.p, 0, 2 * nlev * sizeof(unsigned long long), ctx->stream));
   const double coefK[2] = {ctx->a, ctx->c};
+  // operator format of the levels: stencil-ELL (default) or CSR; the fp32 option keeps CSR values
+  const bool use_ell = ctx->op_format == 1 && !ctx->mg_fp32;
+  if (!use_ell || !ctx->ell_ok) PPH_TRY(pph_ensure_csr_blocks(ctx));
   for (int l = 0; l < nlev; ++l) {
     MgLevel& L = ctx->mg[l];
     bool level_fused = false;   // dinv / spectral bound of this level already produced by the fused pass
     L.replicated = dist && l >= ndist;
     if (l == 0) {
-      L.rowptr = fm.rowptr.p; L.col = fm.col.p; L.val[0] = ctx->A11.p; L.val[1] = ctx->A22.p;
+      L.rowptr = fm.rowptr.p; L.col = fm.col.p;
+      L.val[0] = ctx->csr_ok ? ctx->A11.p : nullptr; L.val[1] = ctx->csr_ok ? ctx->A22.p : nullptr;
+      L.ell[0] = (use_ell && ctx->ell_ok) ? ctx->S11 : Sell();
+      L.ell[1] = (use_ell && ctx->ell_ok) ? ctx->S22 : Sell();
       L.n = fm.n; L.nnz = fm.nnzb; L.px = fm.px; L.py = fm.py; L.pz = fm.pzl;
       L.maskp[0] = ctx->bcmask[0].p; L.maskp[1] = ctx->bcmask[1].p;
       L.geom = &ctx->mesh;
@@ -406,10 +416,17 @@ int mg_setup(pph_ctx* ctx) {
                              m.plane(), m.glo, m.ghi);
         }
       }
+      const bool ell_only = use_ell && fuse_lv;   // the fused pass writes the stencil-ELL arrays directly
       for (int f = 0; f < 2; ++f) {
         L.maskp[f] = L.mask[f].p;
-        PPH_TRY(L.own_val[f].alloc(ctx, (size_t)L.nnz));
-        L.val[f] = L.own_val[f].p;
+        L.ell[f] = Sell();
+        if (ell_only) {
+          PPH_TRY(sell_alloc(ctx, m, L.own_ell[f], &L.ell[f]));
+          L.val[f] = nullptr;
+        } else {
+          PPH_TRY(L.own_val[f].alloc(ctx, (size_t)L.nnz));
+          L.val[f] = L.own_val[f].p;
+        }
       }
       if (fuse_lv) {
         if (masks_stale) {
@@ -418,11 +435,15 @@ int mg_setup(pph_ctx* ctx) {
         }
         for (int f = 0; f < 2; ++f) PPH_TRY(L.dinv[f].alloc(ctx, (size_t)L.n));
         PPH_TRY(pph_launch_level_operators(ctx, m, L.maskp[0], L.maskp[1], L.rownear.p, ctx->a21_alias ? 1 : 0, coefK[0],
-                                           coefK[1], ctx->b, L.own_val[0].p, L.own_val[1].p, L.dinv[0].p, L.dinv[1].p,
-                                           lamdev.p + 2 * l));
+                                           coefK[1], ctx->b, ell_only ? L.own_ell[0].p : L.own_val[0].p,
+                                           ell_only ? L.own_ell[1].p : L.own_val[1].p, L.dinv[0].p, L.dinv[1].p,
+                                           lamdev.p + 2 * l, ell_only ? L.ell[0].ld : 0));
         level_fused = true;
       } else {
-        for (int f = 0; f < 2; ++f) pph_launch_scalar_block(ctx, m, L.maskp[f], coefK[f], ctx->b, L.own_val[f].p);
+        for (int f = 0; f < 2; ++f) {
+          pph_launch_scalar_block(ctx, m, L.maskp[f], coefK[f], ctx->b, L.own_val[f].p);
+          if (use_ell) PPH_TRY(sell_from_csr(ctx, m, L.own_val[f].p, L.own_ell[f], &L.ell[f]));
+        }
       }
       L.bc_epoch = ctx->bc_epoch;
     }
@@ -568,6 +589,58 @@ __global__ __launch_bounds__(1024) void k_coarse_cg(const int64_t* __restrict__ 
   }
 }
 
+// the same solve on a stencil-ELL operator (no CSR values exist on a level the fused pass wrote in that form)
+__global__ __launch_bounds__(1024) void k_coarse_cg_sell(const double* __restrict__ val, int64_t ld, Stencil st, int px,
+                                                         int py, int pz, const double* __restrict__ dinv,
+                                                         const double* __restrict__ b, double* __restrict__ x,
+                                                         double* __restrict__ r, double* __restrict__ p,
+                                                         double* __restrict__ q, int n, double rtol, int max_it) {
+  __shared__ double lds[16];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  double zz = 0.0, rz = 0.0;
+  for (int i = tid; i < n; i += nt) {
+    const double ri = b[i], zi = dinv[i] * ri;
+    x[i] = 0.0; r[i] = ri; p[i] = zi;
+    zz += zi * zi; rz += ri * zi;
+  }
+  zz = coarse_block_sum(zz, lds);
+  rz = coarse_block_sum(rz, lds);
+  const double tol = rtol * sqrt(zz);
+  if (!(sqrt(zz) > tol)) return;
+  for (int it = 0; it < max_it; ++it) {
+    __syncthreads();
+    double pq = 0.0;
+    for (int i = tid; i < n; i += nt) {
+      const int ii = i % px, t = i / px, jj = t % py, kk = t / py;
+      double s = 0.0;
+      for (int sl = 0; sl < st.count; ++sl) {
+        const int a = ii + st.d[sl][0], bb = jj + st.d[sl][1], c = kk + st.d[sl][2];
+        if (a >= 0 && a < px && bb >= 0 && bb < py && c >= 0 && c < pz)
+          s += val[(int64_t)sl * ld + i] * p[a + px * (bb + py * c)];
+      }
+      q[i] = s;
+      pq += p[i] * s;
+    }
+    pq = coarse_block_sum(pq, lds);
+    if (!(pq > 0.0)) return;
+    const double alpha = rz / pq;
+    double zz2 = 0.0, rz2 = 0.0;
+    for (int i = tid; i < n; i += nt) {
+      x[i] += alpha * p[i];
+      const double ri = r[i] - alpha * q[i], zi = dinv[i] * ri;
+      r[i] = ri;
+      zz2 += zi * zi; rz2 += ri * zi;
+    }
+    zz2 = coarse_block_sum(zz2, lds);
+    rz2 = coarse_block_sum(rz2, lds);
+    if (sqrt(zz2) <= tol) return;
+    const double beta = rz2 / rz;
+    __syncthreads();
+    for (int i = tid; i < n; i += nt) p[i] = dinv[i] * r[i] + beta * p[i];
+    rz = rz2;
+  }
+}
+
 void mg_vcycle(pph_ctx* ctx, int which, const double* rin, double* zout, int nsmooth) {
   std::vector<MgLevel>& mg = ctx->mg;
   const int nlev = (int)mg.size();
@@ -604,7 +677,11 @@ void mg_vcycle(pph_ctx* ctx, int which, const double* rin, double* zout, int nsm
     MgLevel& C = mg[nlev - 1];
     int its = 0;
     ctx->comm_suspended = C.replicated;
-    if ((!dist || C.replicated) && C.n <= 4096 && ctx->coarse_on_device)
+    if ((!dist || C.replicated) && C.n <= 4096 && ctx->coarse_on_device && C.ell[which].val)
+      hipLaunchKernelGGL(k_coarse_cg_sell, dim3(1), dim3(C.n <= 256 ? 256 : 1024), 0, ctx->stream, C.ell[which].val,
+                         C.ell[which].ld, make_stencil(ctx->mesh.kind), C.px, C.py, C.pz, C.dinv[which].p, C.b.p, C.x.p,
+                         C.r.p, C.d.p, C.t.p, (int)C.n, 1e-12, 500);
+    else if ((!dist || C.replicated) && C.n <= 4096 && ctx->coarse_on_device)
       hipLaunchKernelGGL(k_coarse_cg, dim3(1), dim3(C.n <= 256 ? 256 : 1024), 0, ctx->stream, C.rowptr, C.col, C.val[which],
                          C.dinv[which].p, C.b.p, C.x.p, C.r.p, C.d.p, C.t.p, (int)C.n, 1e-12, 500);
     else

@@ -1,0 +1,258 @@
+// Stencil-ELL ("SELL") operator format of the scalar blocks and its SpMV.
+//
+// Every scalar block of this path (A11, A22, A12 and the multigrid level operators) lives on a structured box whose
+// CSR pattern is a fixed stencil (27 / 15 / 9 / 7 neighbours, ascending columns).  SELL stores the same matrix as
+// val[slot][row]: no column indices, no row pointers (8 B instead of 12 B per stored entry, 20 B per row less),
+// every matrix load AND every x load is coalesced across consecutive rows, and the x window of a row block is shared
+// through the vector L1.  It replaces PETSc's MatMult (seqaij) on the blocks of the Picard / field-split solves
+// (reference src/perphil/solvers/solver.py:71 -> KSPSolve); the CSR arrays remain the export format
+// (pph_get_csr, reference src/perphil/solvers/conditioning.py:82-85) and the format of the monolithic Krylov path.
+//
+// Algorithmic bytes per product: 8 S nrows (values, S = stencil size, pad zeros on the box boundary included)
+// + 16 nrows (x read once, y written once).
+#include "pph_internal.h"
+
+// stencil of a cell kind as (dy,dz) lines with a 3-bit mask of the dx in {-1,0,+1} present, lines in ascending
+// (dz,dy) order: slot numbering = ascending (dz,dy,dx) = the CSR column order (make_stencil)
+template <int KIND> struct SellSt;
+template <> struct SellSt<PPH_CELL_QUAD> {
+  static constexpr int NL = 3, S = 9;
+  __host__ __device__ static constexpr int dy(int l) { return l - 1; }
+  __host__ __device__ static constexpr int dz(int) { return 0; }
+  __host__ __device__ static constexpr int mask(int) { return 7; }
+};
+template <> struct SellSt<PPH_CELL_TRI> {
+  static constexpr int NL = 3, S = 7;
+  __host__ __device__ static constexpr int dy(int l) { return l - 1; }
+  __host__ __device__ static constexpr int dz(int) { return 0; }
+  __host__ __device__ static constexpr int mask(int l) { return l == 0 ? 6 : (l == 1 ? 7 : 3); }
+};
+template <> struct SellSt<PPH_CELL_HEX> {
+  static constexpr int NL = 9, S = 27;
+  __host__ __device__ static constexpr int dy(int l) { return l % 3 - 1; }
+  __host__ __device__ static constexpr int dz(int l) { return l / 3 - 1; }
+  __host__ __device__ static constexpr int mask(int) { return 7; }
+};
+template <> struct SellSt<PPH_CELL_TET> {
+  static constexpr int NL = 9, S = 15;
+  __host__ __device__ static constexpr int dy(int l) { return l % 3 - 1; }
+  __host__ __device__ static constexpr int dz(int l) { return l / 3 - 1; }
+  // (dz,dy): (-1,-1) (-1,0) (-1,1) (0,-1) (0,0) (0,1) (1,-1) (1,0) (1,1)
+  __host__ __device__ static constexpr int mask(int l) {
+    return (l == 0 || l == 1 || l == 3) ? 3 : (l == 4 ? 7 : ((l == 5 || l == 7 || l == 8) ? 6 : 0));
+  }
+};
+
+__device__ inline double sell_wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+
+// MODE 0: y = A x      1: y = b - A x      2: y = A x and per-workgroup partial sums of x.y
+// MODE 3: y = x + w * dinv .* (b - A x)   (one damped-Jacobi / one-step Chebyshev sweep, out of place)
+// One thread owns RPT consecutive rows; a workgroup a chunk of 256 RPT rows.  Chunks are dealt to the XCDs in groups
+// of `group` consecutive chunks (group 1 = plain grid-stride order); workgroups with equal blockIdx % 8 share an XCD.
+template <int KIND, int MODE, int RPT, bool CLAMP>
+__device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_t ld, const double* __restrict__ x,
+                                          const double* __restrict__ b, const double* __restrict__ dinv, double w,
+                                          double* __restrict__ y, int64_t n, int px, int64_t pxy, int64_t r0,
+                                          double& dotacc) {
+  using ST = SellSt<KIND>;
+  double acc[RPT];
+  double bv[RPT], xr[RPT], dv[RPT];
+  bool act[RPT];
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    acc[i] = 0.0; bv[i] = 0.0; xr[i] = 0.0; dv[i] = 0.0;
+    act[i] = !CLAMP || (r0 + i < n);
+    // operands of the epilogue are requested before the matrix stream, not after the sums
+    if (act[i]) {
+      if (MODE == 1 || MODE == 3) bv[i] = b[r0 + i];
+      if (MODE == 2 || MODE == 3) xr[i] = x[r0 + i];
+      if (MODE == 3) dv[i] = dinv[r0 + i];
+    }
+  }
+  int slot = 0;
+#pragma unroll
+  for (int l = 0; l < ST::NL; ++l) {
+    const int mask = ST::mask(l);
+    if (mask == 0) continue;
+    const int64_t L = r0 + (int64_t)ST::dy(l) * px + (int64_t)ST::dz(l) * pxy;
+    double xs[RPT + 2];
+#pragma unroll
+    for (int e = 0; e < RPT + 2; ++e) {
+      bool need = false;
+#pragma unroll
+      for (int i = 0; i < RPT; ++i)
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+          if (((mask >> d) & 1) && i + d == e) need = true;
+      xs[e] = 0.0;
+      if (need) {
+        int64_t idx = L + e - 1;
+        if (CLAMP) idx = idx < 0 ? 0 : (idx > n - 1 ? n - 1 : idx);
+        xs[e] = x[idx];
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if (!((mask >> d) & 1)) continue;
+      const double* vp = val + (int64_t)slot * ld + r0;
+      double v[RPT];
+      if constexpr (RPT == 1) {
+        v[0] = act[0] ? vp[0] : 0.0;
+      } else {
+        // r0 and ld are multiples of RPT and the array is 256-byte aligned: 16-byte loads; rows beyond n fall into the
+        // zero padding up to ld (n odd) or are masked
+#pragma unroll
+        for (int i = 0; i < RPT; i += 2) {
+          double2 t = make_double2(0.0, 0.0);
+          if (act[i]) t = *reinterpret_cast<const double2*>(vp + i);
+          v[i] = t.x; v[i + 1] = t.y;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) acc[i] += v[i] * xs[i + d];
+      ++slot;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    if (!act[i]) continue;
+    const int64_t r = r0 + i;
+    if (MODE == 0) y[r] = acc[i];
+    else if (MODE == 1) y[r] = bv[i] - acc[i];
+    else if (MODE == 2) { y[r] = acc[i]; dotacc += acc[i] * xr[i]; }
+    else y[r] = xr[i] + w * dv[i] * (bv[i] - acc[i]);
+  }
+}
+
+template <int KIND, int MODE, int RPT>
+__global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ val, int64_t ld,
+                                                   const double* __restrict__ x, const double* __restrict__ b,
+                                                   const double* __restrict__ dinv, double w, double* __restrict__ y,
+                                                   int64_t n, int px, int64_t pxy, int64_t halo, int64_t nchunks,
+                                                   int group, double* __restrict__ part) {
+  constexpr int CH = 256 * RPT;
+  const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, bpx = gridDim.x >> 3;   // launcher keeps gridDim.x a multiple of 8
+  double dotacc = 0.0;
+  for (int64_t q = bx;; q += bpx) {
+    const int64_t base = ((q / group) * 8 + xcd) * (int64_t)group;
+    if (base >= nchunks) break;
+    const int64_t chunk = base + q % group;
+    if (chunk >= nchunks) continue;
+    const int64_t c0 = chunk * CH;
+    const int64_t r0 = c0 + (int64_t)threadIdx.x * RPT;
+    // a chunk whose rows and x window lie inside [0, n) needs no index clamps and no row masks (all but the first
+    // and last few chunks)
+    if (c0 >= halo && c0 + CH + halo <= n)
+      sell_rows<KIND, MODE, RPT, false>(val, ld, x, b, dinv, w, y, n, px, pxy, r0, dotacc);
+    else
+      sell_rows<KIND, MODE, RPT, true>(val, ld, x, b, dinv, w, y, n, px, pxy, r0, dotacc);
+  }
+  if (MODE == 2) {
+    __shared__ double lds[4];
+    dotacc = sell_wave_sum(dotacc);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = dotacc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+  }
+}
+
+template <int KIND, int RPT>
+static void sell_launch_mode(pph_ctx* ctx, int mode, int grid, const Sell& E, const double* x, const double* b,
+                             const double* dinv, double w, double* y, int64_t n, int64_t nchunks, int group,
+                             double* part) {
+  const int64_t pxy = (int64_t)E.px * E.py;
+  const int64_t halo = (E.pz > 1 ? pxy : 0) + E.px + 2;   // reach of the x window of a row (2D: no z lines)
+#define PPH_SELL_GO(MM)                                                                                              \
+  hipLaunchKernelGGL((k_spmv_sell<KIND, MM, RPT>), dim3(grid), dim3(256), 0, ctx->stream, E.val, E.ld, x, b, dinv, w, \
+                     y, n, E.px, pxy, halo, nchunks, group, part)
+  switch (mode) {
+    case 0: PPH_SELL_GO(0); break;
+    case 1: PPH_SELL_GO(1); break;
+    case 2: PPH_SELL_GO(2); break;
+    default: PPH_SELL_GO(3); break;
+  }
+#undef PPH_SELL_GO
+}
+
+// launches the product; returns the grid (= number of partial sums written in mode 2)
+int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x, const double* b, const double* dinv,
+              double w, double* y, double* part) {
+  const int rpt = (ctx->sell_rpt == 1) ? 1 : 2;
+  const int64_t nchunks = ceil_div64(n, 256 * rpt);
+  const int cap = (ctx->sell_blocks >= 8 && ctx->sell_blocks <= 8192) ? (ctx->sell_blocks / 8) * 8 : 2048;
+  int64_t g = nchunks < cap ? nchunks : cap;
+  g = ((g + 7) / 8) * 8;
+  const int grid = (int)g;
+  int group = ctx->sell_group > 0 ? ctx->sell_group : 1;
+#define PPH_SELL_KIND(KK)                                                                                     \
+  if (rpt == 1) sell_launch_mode<KK, 1>(ctx, mode, grid, E, x, b, dinv, w, y, n, nchunks, group, part);        \
+  else sell_launch_mode<KK, 2>(ctx, mode, grid, E, x, b, dinv, w, y, n, nchunks, group, part)
+  switch (E.kind) {
+    case PPH_CELL_QUAD: PPH_SELL_KIND(PPH_CELL_QUAD); break;
+    case PPH_CELL_TRI: PPH_SELL_KIND(PPH_CELL_TRI); break;
+    case PPH_CELL_HEX: PPH_SELL_KIND(PPH_CELL_HEX); break;
+    default: PPH_SELL_KIND(PPH_CELL_TET); break;
+  }
+#undef PPH_SELL_KIND
+  return grid;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CSR <-> SELL (values only; the pattern is the closed-form stencil pattern of pph_mesh.hip)
+// ------------------------------------------------------------------------------------------------
+template <bool TO_SELL>
+__global__ __launch_bounds__(256) void k_sell_convert(const int64_t* __restrict__ rowptr, double* __restrict__ csr,
+                                                      double* __restrict__ ell, int64_t ld, Stencil st, int px, int py,
+                                                      int pz, int64_t n) {
+  for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < n; row += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(row % px);
+    const int64_t t = row / px;
+    const int j = (int)(t % py), k = (int)(t / py);
+    int64_t o = rowptr[row];
+    for (int s = 0; s < st.count; ++s) {
+      const int ii = i + st.d[s][0], jj = j + st.d[s][1], kk = k + st.d[s][2];
+      const bool in = ii >= 0 && ii < px && jj >= 0 && jj < py && kk >= 0 && kk < pz;
+      if (TO_SELL) ell[(int64_t)s * ld + row] = in ? csr[o] : 0.0;
+      else if (in) csr[o] = ell[(int64_t)s * ld + row];
+      o += in ? 1 : 0;
+    }
+  }
+}
+
+static inline int sell_grid(int64_t n) {
+  int64_t b = ceil_div64(n, 256);
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+// (re)allocates `buf` for a SELL operator on `mesh` with the padding rows [n, ld) zeroed, returns the view
+int sell_alloc(pph_ctx* ctx, const MeshData& mesh, DevBuf<double>& buf, Sell* out) {
+  const int S = sell_slots(mesh.kind);
+  const int64_t ld = sell_ld(mesh.n);
+  const size_t want = (size_t)S * (size_t)ld;
+  if (buf.n != want || !buf.p) {
+    PPH_TRY(buf.alloc(ctx, want));
+    PPH_HIP(ctx, hipMemsetAsync(buf.p, 0, want * sizeof(double), ctx->stream));   // padding rows stay zero for good
+  }
+  out->val = buf.p; out->ld = ld; out->kind = mesh.kind; out->px = mesh.px; out->py = mesh.py; out->pz = mesh.pzl;
+  return PPH_OK;
+}
+
+int sell_from_csr(pph_ctx* ctx, const MeshData& mesh, const double* csr_val, DevBuf<double>& buf, Sell* out) {
+  PPH_TRY(sell_alloc(ctx, mesh, buf, out));
+  hipLaunchKernelGGL(k_sell_convert<true>, dim3(sell_grid(mesh.n)), dim3(256), 0, ctx->stream, mesh.rowptr.p,
+                     const_cast<double*>(csr_val), buf.p, out->ld, make_stencil(mesh.kind), mesh.px, mesh.py, mesh.pzl,
+                     mesh.n);
+  PPH_HIP(ctx, hipGetLastError());
+  return PPH_OK;
+}
+
+int sell_to_csr(pph_ctx* ctx, const MeshData& mesh, const Sell& E, double* csr_val) {
+  hipLaunchKernelGGL(k_sell_convert<false>, dim3(sell_grid(mesh.n)), dim3(256), 0, ctx->stream, mesh.rowptr.p, csr_val,
+                     const_cast<double*>(E.val), E.ld, make_stencil(mesh.kind), mesh.px, mesh.py, mesh.pzl, mesh.n);
+  PPH_HIP(ctx, hipGetLastError());
+  return PPH_OK;
+}

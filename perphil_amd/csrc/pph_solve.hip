@@ -45,9 +45,14 @@ struct KspOut {
   double bnorm = 0.0;  // ||P^-1 b|| the tolerance was relative to
 };
 
-static Csr block_csr(pph_ctx* ctx, const double* val) {
+// which: 0 A11, 1 A22, 2 A12, 3 A21.  The product runs on the stencil-ELL copy when the blocks have one
+static Csr block_csr(pph_ctx* ctx, int which) {
   Csr A;
-  A.rowptr = ctx->mesh.rowptr.p; A.col = ctx->mesh.col.p; A.val = val; A.nrows = ctx->n; A.nnz = ctx->nnzb;
+  const double* vals[4] = {ctx->A11.p, ctx->A22.p, ctx->A12.p, ctx->A21p()};
+  const Sell* ells[4] = {&ctx->S11, &ctx->S22, &ctx->S12, &ctx->S21};
+  A.rowptr = ctx->mesh.rowptr.p; A.col = ctx->mesh.col.p; A.val = ctx->csr_ok ? vals[which] : nullptr;
+  A.nrows = ctx->n; A.nnz = ctx->nnzb;
+  if (ctx->ell_ok && ctx->op_format == 1) A.ell = *ells[which];
   A.max_row = ctx->mesh.max_row;
   A.geom = (ctx->world > 1) ? &ctx->mesh : nullptr;
   A.lanes = pph_pick_lanes(ctx, A.nnz, A.nrows);
@@ -396,13 +401,21 @@ struct BlockSolver {
   double* last_resid = nullptr;          // recurrence residual rhs - A z of the last CG solve (work vector)
 
   int setup() {
-    A[0] = block_csr(ctx, ctx->A11.p);
-    A[1] = block_csr(ctx, ctx->A22.p);
+    A[0] = block_csr(ctx, 0);
+    A[1] = block_csr(ctx, 1);
     if (cfg->inner_pc_type == PPH_PC_JACOBI) {
-      PPH_TRY(work(ctx, W_DINV_1, (size_t)ctx->n, &dinv[0]));
-      PPH_TRY(work(ctx, W_DINV_2, (size_t)ctx->n, &dinv[1]));
-      la_extract_diag_inv(ctx, A[0], dinv[0]);
-      la_extract_diag_inv(ctx, A[1], dinv[1]);
+      if (ctx->diag0_valid) {   // the fused assembly produced 1 / a_ii of both diagonal blocks
+        dinv[0] = ctx->dinv0[0].p;
+        dinv[1] = ctx->dinv0[1].p;
+      } else {
+        PPH_TRY(pph_ensure_csr_blocks(ctx));
+        A[0] = block_csr(ctx, 0);
+        A[1] = block_csr(ctx, 1);
+        PPH_TRY(work(ctx, W_DINV_1, (size_t)ctx->n, &dinv[0]));
+        PPH_TRY(work(ctx, W_DINV_2, (size_t)ctx->n, &dinv[1]));
+        la_extract_diag_inv(ctx, A[0], dinv[0]);
+        la_extract_diag_inv(ctx, A[1], dinv[1]);
+      }
     } else if (cfg->inner_pc_type == PPH_PC_MG) {
       PPH_TRY(mg_setup(ctx));
     } else if (cfg->inner_pc_type != PPH_PC_NONE) {
@@ -480,6 +493,8 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
   const int64_t n = ctx->n, N = 2 * n;
   la_reset_spmv_stats(ctx);
   ctx->n_halo = 0;
+  ctx->n_allreduce = 0;
+  if (ctx->comm_status != PPH_OK) { ctx->err = ctx->comm_error; return ctx->comm_status; }
   PPH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
 
   pph_solve_info inf;
@@ -492,7 +507,7 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
   PPH_TRY(work(ctx, W_DU, (size_t)N, &du));
   BlockSolver bs;
   bs.ctx = ctx; bs.cfg = cfg;
-  const Csr A12 = block_csr(ctx, ctx->A12.p), A21 = block_csr(ctx, ctx->A21p());
+  const Csr A12 = block_csr(ctx, 2), A21 = block_csr(ctx, 3);
   int status = PPH_OK;
 
   if (cfg->picard) {
@@ -584,6 +599,7 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
       pc = [&, dinv](const double* in, double* o) { la_pointwise_mult(ctx, o, dinv, in, N); };
     } else if (cfg->pc_type == PPH_PC_BLOCK2) {
       double* binv;
+      PPH_TRY(pph_ensure_csr_blocks(ctx));
       PPH_TRY(work(ctx, W_BINV, (size_t)(4 * n), &binv));
       int grid = (int)(ceil_div64(n, 256) < 2048 ? ceil_div64(n, 256) : 2048);
       hipLaunchKernelGGL(k_block2_build, dim3(grid), dim3(256), 0, ctx->stream, ctx->mesh.rowptr.p, ctx->mesh.col.p,
@@ -638,6 +654,7 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
   la_harvest_spmv_times(ctx);
   PPH_HIP(ctx, hipGetLastError());
   if (info) *info = inf;
+  if (ctx->comm_status != PPH_OK) { ctx->err = ctx->comm_error; return ctx->comm_status; }
   if (status == PPH_ERR_DIVERGED)
     pph_set_error(ctx, "solver did not converge: %d iterations, residual %.3e", inf.iterations, inf.resnorm);
   return status;
