@@ -2,19 +2,22 @@
 """
 Headline benchmark of the DPP hot path (BASELINE.json): DoF/s over assemble + solve on the 3D
 UnitCube Q1 two-pressure problem, solved by block Picard (fixed-stress) sweeps whose block solves
-are multigrid-preconditioned CG on the CSR blocks.
+are multigrid-preconditioned CG.
 
-One "step" = one pass of the hot path on inputs resident in HBM: integrate K and M (cell kernels +
-scatter-add), eliminate Dirichlet dofs / form the DPP blocks and the lifted right-hand side, run the
-Picard solve to snes_rtol 1e-8.  The mesh connectivity / CSR pattern and the boundary data are built
-before the timed region, like the mesh construction that precedes the reference's timing window
-(reference src/perphil/experiments/petsc_profiling_3d.py:57 vs :82-86).
+One "step" = one pass of the hot path on inputs resident in HBM: integrate the element matrices and
+form the Dirichlet-eliminated DPP blocks + lifted right-hand side (fused assembly), refresh the
+multigrid operators, run the Picard solve to snes_rtol 1e-8.  NOT in the timed step: the mesh
+connectivity / sparsity pattern, the upload of the boundary data and the allocation of the operator
+and multigrid buffers (the reference's timed `solve_dpp` call allocates its matrix inside the window,
+reference src/perphil/solvers/solver.py:65-69 under experiments/petsc_profiling_3d.py:82-86; here
+that one-off cost is reported beside the step as `config.setup_ms` and `config.cold_step_ms`).
 
     python bench.py --gpus 1 --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
-Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (CSR SpMV kernel,
-HIP events per launch on the solver's stream, algorithmic bytes 12 nnz + 20 nrows) and
-`cpu_baseline` (the NumPy/SciPy oracle of the same algorithm on a bounded sample, 1 core).
+Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (the SpMV kernel of the
+block solves on the stencil-ELL operator format, HIP events per launch on the solver's stream, algorithmic
+bytes 8 S nrows + 16 nrows; the CSR kernel's figures - 12 nnz + 20 nrows - beside it under `roofline.csr`)
+and `cpu_baseline` (oracle/dpp_cpu.c, the C/OpenMP restatement of the same step, on the host's cores).
 """
 import argparse
 import json
@@ -173,6 +176,10 @@ def main():
     ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
                     help="extra pph_set_option settings for A/B runs (e.g. spmv_kernel=8)")
     ap.add_argument("--skip-fine-bench", action="store_true", help="omit the isolated fine-level SpMV loop (PMC passes)")
+    ap.add_argument("--skip-csr", action="store_true", help="omit the extra untimed step on the CSR operator format")
+    ap.add_argument("--allow-fallback", action="store_true",
+                    help="N > 1: continue on the torch.distributed callback transport when the RCCL transport fails its "
+                         "self-test (default: exit non-zero - no silent downgrade of a scaling run)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -201,11 +208,16 @@ def main():
     N = args.cells
     k1, k2, beta, mu = 1.0, 1e-2, 1.0, 1.0
 
+    transport, ranks_seen = "none", 1
+    t_setup0 = time.perf_counter()
     if world > 1:
         from perphil_amd.distributed import SlabSolver
 
+        # raises (non-zero exit) when the RCCL transport was asked for and failed, unless --allow-fallback
         solver = SlabSolver(N, world, rank, device, k1, k2, beta, mu, inner_rtol=args.inner_rtol, smooth=args.smooth,
-                            inner_reduction=args.inner_reduction, inner_norm=args.inner_norm)
+                            inner_reduction=args.inner_reduction, inner_norm=args.inner_norm,
+                            allow_fallback=args.allow_fallback)
+        transport, ranks_seen = solver.transport_label, solver.ranks_seen
         solver.ctx.set_option("asm_kernel", args.asm_kernel)
         for kv in args.set:
             solver.ctx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
@@ -239,8 +251,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    ctx.synchronize()
+    setup_ms = 1e3 * (time.perf_counter() - t_setup0)   # mesh + pattern + boundary data (host-side MMS evaluation included)
+    cold_ms = None
+    for w in range(args.warmup):
+        tc = time.perf_counter()
         step()
+        if w == 0:
+            ctx.synchronize()
+            cold_ms = 1e3 * (time.perf_counter() - tc)   # first step: allocates operators + multigrid hierarchy
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -254,47 +273,81 @@ def main():
     tm = ctx.timers()
 
     # ---- roofline of the dominant kernel: one more (untimed) step with an event pair around every
-    # SpMV launch on the solver's stream; bytes are algorithmic (12 nnz + 20 nrows per launch) --------
-    ctx.set_option("time_spmv", 1)
-    step()
-    ctx.synchronize()
-    tr = ctx.timers()
-    ctx.set_option("time_spmv", 0)
-    launches = tr["spmv_launches"] + tr["spmv_dot_launches"]
-    ms = tr["spmv_ms"] + tr["spmv_dot_ms"]
-    byts = tr["spmv_bytes"] + tr["spmv_dot_bytes"]
+    # SpMV launch on the solver's stream; bytes are algorithmic (stencil-ELL: 8 S nrows + 16 nrows per
+    # launch; CSR: 12 nnz + 20 nrows) ------------------------------------------------------------------
+    def instrumented_step():
+        ctx.set_option("time_spmv", 1)
+        step()
+        ctx.synchronize()
+        t = ctx.timers()
+        ctx.set_option("time_spmv", 0)
+        launches = t["spmv_launches"] + t["spmv_dot_launches"]
+        ms = t["spmv_ms"] + t["spmv_dot_ms"]
+        byts = t["spmv_bytes"] + t["spmv_dot_bytes"]
+        return t, launches, ms, byts
+
+    def fine_block(fmt_bytes, reps=200):
+        if args.skip_fine_bench:
+            return None
+        ms1 = ctx.spmv_bench(_ffi.MAT_A11, reps)
+        return {"avg_launch_ms": round(ms1, 4), "algorithmic_bytes": fmt_bytes,
+                "achieved": round(fmt_bytes / 1e9 / (ms1 / 1e3), 1),
+                "frac": round(fmt_bytes / 1e9 / (ms1 / 1e3) / HBM_PEAK_GBS, 4)}
+
+    def in_solver(t):
+        if not (t["spmv_fine_launches"] and t["spmv_fine_ms"] > 0):
+            return None
+        fa = t["spmv_fine_bytes"] / 1e9 / (t["spmv_fine_ms"] / 1e3)
+        return {"launches_per_step": t["spmv_fine_launches"],
+                "avg_launch_ms": round(t["spmv_fine_ms"] / t["spmv_fine_launches"], 4),
+                "achieved": round(fa, 1), "frac": round(fa / HBM_PEAK_GBS, 4)}
+
+    sell = not any(kv.split("=")[0] == "op_format" and float(kv.split("=")[1]) == 0 for kv in args.set)
+    tr, launches, ms, byts = instrumented_step()
     achieved = (byts / 1e9) / (ms / 1e3) if ms > 0 else 0.0
-    # fine-level scalar-block SpMV alone (the inner loop the 50 % target is stated on)
-    fine_bytes = 12.0 * ctx.nnzb + 20.0 * ctx.n
-    fine_ms = float("nan") if args.skip_fine_bench else ctx.spmv_bench(_ffi.MAT_A11, 200)
-    # HBM traffic of the same kernel mix from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB),
-    # measured offline with tools/pmc_summarize.py and committed under profiles/ (cannot be sampled in-process)
+    S = 27
+    sell_bytes = 8.0 * S * ctx.n + 16.0 * ctx.n
+    csr_bytes = 12.0 * ctx.nnzb + 20.0 * ctx.n
+    # HBM traffic of the same kernel mix from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB), taken
+    # offline with tools/pmc_summarize.py and committed under profiles/ (PMC cannot be sampled in-process).  The
+    # file is stamped with the kernel and the launch count it was taken on: anything else reports null.
     traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_spmv_bench256.json")
-    defaults = (args.inner_norm == 1 and args.inner_reduction == 1e-1 and args.smooth == 1 and args.inner_rtol == 1e-10
-                and args.asm_kernel == 2 and not args.set)
-    if os.path.exists(pmc_file) and N == 256 and world == 1 and defaults:
+    pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_spmv_bench256.json")
+    if os.path.exists(pmc_file) and N == 256 and world == 1 and sell:
         try:
             with open(pmc_file) as f:
-                traffic = json.load(f).get("traffic_bytes_per_launch")
+                pmc = json.load(f)
+            if int(pmc.get("launches_per_step", -1)) == int(launches) and pmc.get("kernel") == "k_spmv_sell":
+                traffic = pmc.get("traffic_bytes_per_launch")
         except (OSError, ValueError):
             traffic = None
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-        "kernel": "k_spmv_wide<8,*,2> (aligned-wide CSR-vector SpMV, all multigrid levels of one step)",
+        "kernel": ("k_spmv_sell<kind,mode,2> (stencil-ELL SpMV, 8 B per stored entry, all multigrid levels of one step)"
+                   if sell else "k_spmv_wide<8,*,2> (aligned-wide CSR-vector SpMV, all multigrid levels of one step)"),
+        "format": "stencil-ELL" if sell else "CSR",
         "launches_per_step": int(launches), "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
         "algorithmic_bytes_per_launch": round(byts / max(launches, 1), 0),
-        "fine_level": {"avg_launch_ms": round(fine_ms, 4) if fine_ms == fine_ms else None, "algorithmic_bytes": fine_bytes,
-                       "achieved": round(fine_bytes / 1e9 / (fine_ms / 1e3), 1) if fine_ms == fine_ms else None,
-                       "frac": round(fine_bytes / 1e9 / (fine_ms / 1e3) / HBM_PEAK_GBS, 4) if fine_ms == fine_ms else None},
+        "fine_level": fine_block(sell_bytes if sell else csr_bytes),
+        "fine_level_in_solver": in_solver(tr),
     }
-    if tr["spmv_fine_launches"] and tr["spmv_fine_ms"] > 0:
-        # the fine-level launches of the instrumented step itself (cold x, operators alternating), beside the isolated loop
-        fa = tr["spmv_fine_bytes"] / 1e9 / (tr["spmv_fine_ms"] / 1e3)
-        roofline["fine_level_in_solver"] = {"launches_per_step": tr["spmv_fine_launches"],
-                                            "avg_launch_ms": round(tr["spmv_fine_ms"] / tr["spmv_fine_launches"], 4),
-                                            "achieved": round(fa, 1), "frac": round(fa / HBM_PEAK_GBS, 4)}
+    if sell and not args.skip_csr:
+        # the same step on the CSR operator format (the north-star's "CSR SpMV inner loop"): untimed, for the record
+        ctx.set_option("op_format", 0)
+        step()                                   # re-assembles into CSR arrays, rebuilds the level operators
+        tc, lc, msc, bc = instrumented_step()
+        t0c = time.perf_counter()
+        step()
+        ctx.synchronize()
+        csr_step_ms = 1e3 * (time.perf_counter() - t0c)
+        ac = (bc / 1e9) / (msc / 1e3) if msc > 0 else 0.0
+        roofline["csr"] = {"kernel": "k_spmv_wide<8,*,2> (aligned-wide CSR-vector SpMV)", "achieved": round(ac, 1),
+                           "frac": round(ac / HBM_PEAK_GBS, 4), "launches_per_step": int(lc),
+                           "algorithmic_bytes_per_launch": round(bc / max(lc, 1), 0), "ms_per_step": round(csr_step_ms, 3),
+                           "fine_level": fine_block(csr_bytes), "fine_level_in_solver": in_solver(tc)}
+        ctx.set_option("op_format", 1)
+    cs = ctx.comm_stats()
 
     out = {
         "metric": "DoF/s (assemble+solve), 3D UnitCube Q1 DPP, Picard-split",
@@ -315,12 +368,18 @@ def main():
                         f"CG + geometric multigrid (Chebyshev-Jacobi V({args.smooth},{args.smooth})) on CSR blocks, each to a "
                         f"reduction of the {'unpreconditioned' if args.inner_norm else 'preconditioned'} residual by "
                         f"{args.inner_reduction:g} (or rtol {args.inner_rtol:g})",
+            "preallocation": "outside the timed step: mesh, sparsity pattern, boundary-data upload (setup_ms) and the first "
+                             "step's buffer / multigrid-hierarchy allocation (cold_step_ms = that first step)",
+            "setup_ms": round(setup_ms, 2), "cold_step_ms": None if cold_ms is None else round(cold_ms, 2),
+            "operator_format": "stencil-ELL" if sell else "CSR",
+            "transport": transport, "ranks_seen": int(ranks_seen),
+            "allreduces_per_step": int(cs["allreduces"]),
             "cells": N ** 3, "dofs": int(dofs_global), "parallelism": f"slab{world}" if world > 1 else "single",
             "picard_sweeps": int(info.iterations), "inner_cg_iterations": int(info.inner_iterations),
             "picard_ms_per_sweep": round(tm["solve_ms"] / max(int(info.iterations), 1), 3),
             "assemble_ms": round(tm["assemble_ms"] + tm["bc_blocks_ms"], 3), "solve_ms": round(tm["solve_ms"], 3),
             "final_residual": float(info.resnorm), "rhs_norm": float(info.rhs_norm),
-            "halo_exchanges_per_step": int(tm.get("halo_exchanges", 0)),
+            "halo_exchanges_per_step": int(cs["halo_exchanges"]),
         },
         "roofline": roofline,
     }

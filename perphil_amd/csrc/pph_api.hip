@@ -511,6 +511,8 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
   if (!strcmp(name, "asm_fused")) { ctx->asm_fused = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "asm_ring")) { ctx->asm_ring = value > 0.0 ? (int)value : 0; return PPH_OK; }
   if (!strcmp(name, "asm_keep_km")) { ctx->asm_keep_km = value != 0.0 ? 1 : 0; return PPH_OK; }
+  if (!strcmp(name, "mg_fused")) { ctx->mg_fused = value != 0.0 ? 1 : 0; return PPH_OK; }
+  if (!strcmp(name, "mg_tail_rows")) { ctx->mg_tail_rows = (int64_t)value; return PPH_OK; }
   if (!strcmp(name, "coarse_on_device")) { ctx->coarse_on_device = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "spmv_bench_mode")) { ctx->spmv_bench_mode = (int)value; return PPH_OK; }
   if (!strcmp(name, "time_spmv")) { ctx->time_spmv = value != 0.0; return PPH_OK; }

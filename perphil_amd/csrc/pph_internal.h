@@ -71,6 +71,37 @@ static inline int sell_slots(int kind) {
 }
 static inline int64_t sell_ld(int64_t n) { return (n + 63) & ~(int64_t)63; }
 
+// stencil of a cell kind as (dy,dz) lines with a 3-bit mask of the dx in {-1,0,+1} present, lines in ascending
+// (dz,dy) order: slot numbering = ascending (dz,dy,dx) = the CSR column order (make_stencil)
+template <int KIND> struct SellSt;
+template <> struct SellSt<PPH_CELL_QUAD> {
+  static constexpr int NL = 3, S = 9;
+  __host__ __device__ static constexpr int dy(int l) { return l - 1; }
+  __host__ __device__ static constexpr int dz(int) { return 0; }
+  __host__ __device__ static constexpr int mask(int) { return 7; }
+};
+template <> struct SellSt<PPH_CELL_TRI> {
+  static constexpr int NL = 3, S = 7;
+  __host__ __device__ static constexpr int dy(int l) { return l - 1; }
+  __host__ __device__ static constexpr int dz(int) { return 0; }
+  __host__ __device__ static constexpr int mask(int l) { return l == 0 ? 6 : (l == 1 ? 7 : 3); }
+};
+template <> struct SellSt<PPH_CELL_HEX> {
+  static constexpr int NL = 9, S = 27;
+  __host__ __device__ static constexpr int dy(int l) { return l % 3 - 1; }
+  __host__ __device__ static constexpr int dz(int l) { return l / 3 - 1; }
+  __host__ __device__ static constexpr int mask(int) { return 7; }
+};
+template <> struct SellSt<PPH_CELL_TET> {
+  static constexpr int NL = 9, S = 15;
+  __host__ __device__ static constexpr int dy(int l) { return l % 3 - 1; }
+  __host__ __device__ static constexpr int dz(int l) { return l / 3 - 1; }
+  // (dz,dy): (-1,-1) (-1,0) (-1,1) (0,-1) (0,0) (0,1) (1,-1) (1,0) (1,1)
+  __host__ __device__ static constexpr int mask(int l) {
+    return (l == 0 || l == 1 || l == 3) ? 3 : (l == 4 ? 7 : ((l == 5 || l == 7 || l == 8) ? 6 : 0));
+  }
+};
+
 // neighbour offsets of a row of the scalar pattern, in ascending (dz,dy,dx) = ascending column order
 struct Stencil {
   int count;
@@ -238,6 +269,9 @@ struct pph_ctx {
   int spmv_lanes_override = 0;          // 0: pick from the mean row length
   int spmv_blocks = 0;                  // 0: default persistent grid (1024 workgroups)
   int device_scalars = 0;               // 1: the device-scalar CG branch also over the callback transport (tests)
+  int mg_fused = 1;                     // V(1,1) cycles on stencil-ELL levels: fused smoother / transfer kernels and the
+                                        // single-workgroup tail (pph_mg.hip); 0: the general kernel-per-operation cycle
+  int64_t mg_tail_rows = 5000;          // levels with at most this many rows are handled inside the tail kernel
   int coarse_on_device = 1;             // coarsest multigrid level (<= 4096 rows): CG inside one workgroup, no host round trips
   int spmv_bench_mode = 0;              // pph_spmv_bench protocol: 0 back-to-back, 1-3 interleaved (see pph_api.hip)
   int64_t mg_replicate_below = 40000;   // slabs: multigrid levels with at most this many global nodes are replicated
@@ -277,6 +311,7 @@ void pph_launch_row_near(pph_ctx* ctx, const MeshData& mesh, const uint8_t* m1, 
 // linear algebra on the context stream; all results that feed control flow go through ctx->scal
 void la_spmv(pph_ctx* ctx, const Csr& A, const double* x, double* y);
 void la_spmv_resid(pph_ctx* ctx, const Csr& A, const double* x, const double* b, double* y);  // y = b - A x
+void la_spmv_jacobi(pph_ctx* ctx, const Csr& A, const double* x, const double* b, const double* dinv, double w, double* y);
 // y = A x and partial sums of dot(x, y) -> scal slot
 void la_spmv_dot(pph_ctx* ctx, const Csr& A, const double* x, double* y, int slot);
 void la_set(pph_ctx* ctx, double* x, double v, int64_t n);

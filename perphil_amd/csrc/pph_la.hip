@@ -738,8 +738,10 @@ static int stream_T(int max_row) {
 }
 
 // returns the grid used (number of partial sums written when DOT)
+// jdinv != null (stencil-ELL operators only): y = x + jw * jdinv .* (bvec - A x), one damped-Jacobi sweep out of place
 template <bool DOT>
-static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const double* bvec, double* y, double* part) {
+static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const double* bvec, double* y, double* part,
+                         const double* jdinv = nullptr, double jw = 0.0) {
   const int variant = DOT ? 1 : 0;
   if (A.geom) {  // ghost planes of x <- owners (slabs only); field-major mixed vectors carry two fields
     (void)la_halo(ctx, *A.geom, const_cast<double*>(x));
@@ -763,7 +765,7 @@ static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const doub
   double bytes_per_nnz = 12.0;
   if (A.ell.val) {
     // stencil-ELL copy of the operator (pph_sell.hip): 8 B per stored entry, no index arrays
-    grid = sell_spmv(ctx, A.ell, A.nrows, DOT ? 2 : (bvec ? 1 : 0), x, bvec, nullptr, 0.0, y, part);
+    grid = sell_spmv(ctx, A.ell, A.nrows, jdinv ? 3 : (DOT ? 2 : (bvec ? 1 : 0)), x, bvec, jdinv, jw, y, part);
     if (ev) (void)hipEventRecord(ev->e1, ctx->stream);
     const double bytes = 8.0 * sell_slots(A.ell.kind) * (double)A.nrows + 16.0 * (double)A.nrows;
     ctx->n_spmv[variant]++;
@@ -935,6 +937,12 @@ void la_spmv(pph_ctx* ctx, const Csr& A, const double* x, double* y) {
 // y = b - A x
 void la_spmv_resid(pph_ctx* ctx, const Csr& A, const double* x, const double* b, double* y) {
   spmv_dispatch<false>(ctx, A, x, b, y, nullptr);
+}
+
+// y = x + w * dinv .* (b - A x): one damped-Jacobi (one-step Chebyshev) sweep, out of place (y != x); A must carry a
+// stencil-ELL copy
+void la_spmv_jacobi(pph_ctx* ctx, const Csr& A, const double* x, const double* b, const double* dinv, double w, double* y) {
+  spmv_dispatch<false>(ctx, A, x, b, y, nullptr, dinv, w);
 }
 
 void la_spmv_dot(pph_ctx* ctx, const Csr& A, const double* x, double* y, int slot) {

@@ -89,8 +89,10 @@ __global__ void k_mask_from_double(uint8_t* __restrict__ m, const double* __rest
 }
 
 // b_c[C] = sum_d w_d r_f[2C + d]   (0 on constrained coarse dofs and on coarse planes of other ranks)
+// (xc != null: also the coarse level's pre-smoothing from a zero guess, x_c = dinv_c .* b_c * wc, in the same pass)
 __global__ void k_restrict(double* __restrict__ bc, const double* __restrict__ rf, TStencil st,
-                           const uint8_t* __restrict__ mc, const uint8_t* __restrict__ mf, TGeom g) {
+                           const uint8_t* __restrict__ mc, const uint8_t* __restrict__ mf, TGeom g,
+                           double* __restrict__ xc, const double* __restrict__ dinvc, double wc) {
   const int64_t nc = (int64_t)g.pxc * g.pyc * g.pzc;
   NODE_LOOP(id, nc) {
     const int I = (int)(id % g.pxc);
@@ -107,6 +109,7 @@ __global__ void k_restrict(double* __restrict__ bc, const double* __restrict__ r
       }
     }
     bc[id] = s;
+    if (xc) xc[id] = dinvc[id] * s * wc;
   }
 }
 
@@ -116,7 +119,8 @@ __global__ void k_restrict(double* __restrict__ bc, const double* __restrict__ r
 template <int DIM>
 __global__ __launch_bounds__(256) void k_restrict_q1(double* __restrict__ bc, const double* __restrict__ rf,
                                                      const uint8_t* __restrict__ mc, const uint8_t* __restrict__ mf,
-                                                     TGeom g) {
+                                                     TGeom g, double* __restrict__ xc, const double* __restrict__ dinvc,
+                                                     double wc) {
   const int64_t nc = (int64_t)g.pxc * g.pyc * g.pzc;
   NODE_LOOP(id, nc) {
     const int I = (int)(id % g.pxc);
@@ -154,6 +158,7 @@ __global__ __launch_bounds__(256) void k_restrict_q1(double* __restrict__ bc, co
           }
     }
     bc[id] = s;
+    if (xc) xc[id] = dinvc[id] * s * wc;
   }
 }
 
@@ -162,6 +167,41 @@ __global__ __launch_bounds__(256) void k_restrict_q1(double* __restrict__ bc, co
 //   Q1 (TK 0)         : the 2^|o| coarse nodes c + s, s <= o component-wise, weight 2^-|o|
 //   Kuhn P1 (TK 1)    : 1/2 (x_c[c] + x_c[c + o])                         (o != 0)
 //   left-diag P1 (TK 2): o = (1,1): 1/2 (x_c[c + x] + x_c[c + y]), else as Kuhn
+// out of place: xout = xf + P xc (constrained fine dofs: xout = xf); the post-smoothing sweep then reads xout and
+// writes xf (la_spmv_jacobi)
+template <int TK>
+__global__ __launch_bounds__(256) void k_prolong_to(double* __restrict__ xout, const double* __restrict__ xf,
+                                                    const double* __restrict__ xc, const uint8_t* __restrict__ mf,
+                                                    TGeom g) {
+  const int64_t nf = (int64_t)g.pxf * g.pyf * g.pzf;
+  NODE_LOOP(id, nf) {
+    const double x0 = xf[id];
+    if (mf[id] != 0) { xout[id] = x0; continue; }
+    const int i = (int)(id % g.pxf);
+    const int64_t t = id / g.pxf;
+    const int j = (int)(t % g.pyf), kg = (int)(t / g.pyf) + g.gzf;
+    const int ox = i & 1, oy = j & 1, oz = kg & 1;
+    const int64_t sx = 1, sy = g.pxc, sz = (int64_t)g.pxc * g.pyc;
+    const int64_t c = (i >> 1) + sy * (j >> 1) + sz * ((kg >> 1) - g.gzc);
+    double s;
+    if (TK == 0) {
+      const int64_t ex = ox ? sx : 0, ey = oy ? sy : 0, ez = oz ? sz : 0;
+      const double c000 = xc[c], c100 = xc[c + ex], c010 = xc[c + ey], c110 = xc[c + ey + ex];
+      const double c001 = xc[c + ez], c101 = xc[c + ez + ex], c011 = xc[c + ez + ey], c111 = xc[c + ez + ey + ex];
+      const double v00 = 0.5 * (c000 + c100), v10 = 0.5 * (c010 + c110), v01 = 0.5 * (c001 + c101),
+                   v11 = 0.5 * (c011 + c111);
+      if (oy && oz) s = 0.25 * (v00 + v10 + v01 + v11);
+      else if (oy | oz) s = 0.5 * (v00 + (oy ? v10 : v01));
+      else s = v00;
+    } else {
+      const int64_t o = ox * sx + oy * sy + oz * sz;
+      if (TK == 2 && ox && oy) s = 0.5 * (xc[c + sx] + xc[c + sy]);
+      else s = (o == 0) ? xc[c] : 0.5 * (xc[c] + xc[c + o]);
+    }
+    xout[id] = x0 + s;
+  }
+}
+
 template <int TK>
 __global__ __launch_bounds__(256) void k_prolong_add(double* __restrict__ xf, const double* __restrict__ xc,
                                                      const uint8_t* __restrict__ mf, TGeom g) {
@@ -641,7 +681,364 @@ __global__ __launch_bounds__(1024) void k_coarse_cg_sell(const double* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tail of the V(1,1) cycle in ONE workgroup: the coarsest levels (from the first one with at most 1024 rows: 9^3
+// and coarser in 3D) are swept inside a single launch, entirely on-chip - every vector of every tail level lives
+// in LDS, the operator row of the largest tail level in the registers of the thread that owns the row, the smaller
+// operators in LDS - with workgroup barriers between the phases instead of a kernel launch per operation and
+// a global-memory round trip per phase.  Pre-smoothing, residual and restriction on the way down, the coarsest
+// Jacobi-CG, interpolation and post-smoothing on the way up: the arithmetic of the kernel-per-operation cycle
+// (same stencil orders, same smoother).  A 256^3 cycle has 3 such levels = 16 of its launches; a 64^3 step spends
+// a third of its time in them.
+// ------------------------------------------------------------------------------------------------
+#define MG_TAIL_MAX 4
+#define MG_TAIL_ROWS 1024          // rows of the largest tail level = threads of the workgroup
+#define MG_TAIL_MATPOOL 6144       // doubles of LDS for the operators of tail levels 1..
+struct TailLevel {
+  const double* A;        // stencil-ELL operator
+  int64_t ld;
+  const double* dinv;
+  const uint8_t* mask;
+  int px, py, pz, n;
+  double w;               // 1 / theta of the one-step Chebyshev smoother
+};
+struct TailArgs {
+  int nl;
+  TailLevel L[MG_TAIL_MAX];
+  const double* b0;       // right-hand side of tail level 0 (global)
+  double* x0;             // its solution (global)
+};
+
+// row i of A v with the operator row in a[] (stride astride between slots: 1 for registers, n for an LDS operator
+// stored slot-major) and v in LDS; neighbours outside the box carry a zero entry, their index is clamped
+template <int KIND>
+__device__ __forceinline__ double tail_row(const double* a, int astride, const double* v, int i, int px, int pxy, int n) {
+  using ST = SellSt<KIND>;
+  double s = 0.0;
+  int slot = 0;
+#pragma unroll
+  for (int l = 0; l < ST::NL; ++l) {
+    const int mask = ST::mask(l);
+    if (mask == 0) continue;
+    const int L = i + ST::dy(l) * px + ST::dz(l) * pxy;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if (!((mask >> d) & 1)) continue;
+      int idx = L + d - 1;
+      idx = idx < 0 ? 0 : (idx > n - 1 ? n - 1 : idx);
+      s += a[slot * astride] * v[idx];
+      ++slot;
+    }
+  }
+  return s;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(1024) void k_mg_tail(TailArgs ta, TStencil ts, int tk, double cg_rtol, int cg_max_it) {
+  using ST = SellSt<KIND>;
+  extern __shared__ double sm[];
+  __shared__ double red[16];
+  const int tid = threadIdx.x;
+  const int nl = ta.nl;
+  // LDS layout: per level x, b, t (t = residual on the way down, interpolated iterate on the way up); the coarsest
+  // level also p, q of its CG; then the operators of levels 1.. (slot-major), then the masks as bytes
+  double *X[MG_TAIL_MAX], *B[MG_TAIL_MAX], *T[MG_TAIL_MAX], *M[MG_TAIL_MAX];
+  int off = 0;
+  for (int l = 0; l < nl; ++l) {
+    const int n = ta.L[l].n;
+    X[l] = sm + off; B[l] = X[l] + n; T[l] = B[l] + n;
+    off += 3 * n;
+  }
+  double* P = sm + off; double* Q = P + ta.L[nl - 1].n;
+  off += 2 * ta.L[nl - 1].n;
+  M[0] = nullptr;
+  for (int l = 1; l < nl; ++l) { M[l] = sm + off; off += ST::S * ta.L[l].n; }
+  uint8_t* MK[MG_TAIL_MAX];
+  {
+    uint8_t* mb = reinterpret_cast<uint8_t*>(sm + off);
+    for (int l = 0; l < nl; ++l) { MK[l] = mb; mb += (ta.L[l].n + 7) & ~7; }
+  }
+  // ---- load: operator row of level 0 into registers, the other operators, the masks and b0 into LDS
+  double a0[ST::S];
+  double dv[MG_TAIL_MAX];
+  {
+    const TailLevel& F = ta.L[0];
+    const bool in = tid < F.n;
+#pragma unroll
+    for (int s = 0; s < ST::S; ++s) a0[s] = in ? F.A[(int64_t)s * F.ld + tid] : 0.0;
+    if (in) B[0][tid] = ta.b0[tid];
+  }
+  for (int l = 0; l < nl; ++l) {
+    const TailLevel& F = ta.L[l];
+    dv[l] = (tid < F.n) ? F.dinv[tid] : 0.0;
+    if (tid < F.n) MK[l][tid] = F.mask[tid];
+    if (l > 0)
+      for (int e = tid; e < ST::S * F.n; e += blockDim.x) M[l][e] = F.A[(int64_t)(e / F.n) * F.ld + e % F.n];
+  }
+  __syncthreads();
+  // ---- downward leg
+  for (int l = 0; l + 1 < nl; ++l) {
+    const TailLevel& F = ta.L[l];
+    const TailLevel& C = ta.L[l + 1];
+    const int n = F.n, pxy = F.px * F.py;
+    const bool in = tid < n;
+    if (in) X[l][tid] = dv[l] * B[l][tid] * F.w;                 // pre-smoothing from a zero guess
+    __syncthreads();
+    if (in) {                                                     // residual
+      const double ax = (l == 0) ? tail_row<KIND>(a0, 1, X[l], tid, F.px, pxy, n)
+                                 : tail_row<KIND>(M[l] + tid, n, X[l], tid, F.px, pxy, n);
+      T[l][tid] = B[l][tid] - ax;
+    }
+    __syncthreads();
+    if (tid < C.n) {                                              // restriction (order of k_restrict)
+      const int I = tid % C.px, t = tid / C.px, J = t % C.py, K = t / C.py;
+      double s = 0.0;
+      if (MK[l + 1][tid] == 0) {
+        for (int q = 0; q < ts.count; ++q) {
+          const int i = 2 * I + ts.d[q][0], j = 2 * J + ts.d[q][1], k = 2 * K + ts.d[q][2];
+          if (i >= 0 && i < F.px && j >= 0 && j < F.py && k >= 0 && k < F.pz) {
+            const int f = i + F.px * (j + F.py * k);
+            if ((MK[l][f] & 1) == 0) s += ts.w[q] * T[l][f];
+          }
+        }
+      }
+      B[l + 1][tid] = s;
+    }
+    __syncthreads();
+  }
+  // ---- coarsest level: Jacobi-preconditioned CG (the algorithm of k_coarse_cg), vectors in LDS
+  {
+    const int lc = nl - 1;
+    const TailLevel& C = ta.L[lc];
+    const int n = C.n, pxy = C.px * C.py;
+    const bool in = tid < n;
+    double* x = X[lc]; double* r = T[lc]; const double* b = B[lc];
+    double ri = 0.0, zi = 0.0;
+    if (in) { ri = b[tid]; zi = dv[lc] * ri; x[tid] = 0.0; r[tid] = ri; P[tid] = zi; }
+    double zz = coarse_block_sum(zi * zi, red);
+    double rz = coarse_block_sum(ri * zi, red);
+    const double tol = cg_rtol * sqrt(zz);
+    bool go = sqrt(zz) > tol;
+    for (int it = 0; go && it < cg_max_it; ++it) {
+      __syncthreads();
+      double s = 0.0, pi = 0.0;
+      if (in) {
+        s = (lc == 0) ? tail_row<KIND>(a0, 1, P, tid, C.px, pxy, n) : tail_row<KIND>(M[lc] + tid, n, P, tid, C.px, pxy, n);
+        pi = P[tid];
+        Q[tid] = s;
+      }
+      const double pq = coarse_block_sum(pi * s, red);
+      if (!(pq > 0.0)) break;
+      const double alpha = rz / pq;
+      double r2 = 0.0, z2 = 0.0;
+      if (in) {
+        x[tid] += alpha * pi;
+        r2 = r[tid] - alpha * s;
+        z2 = dv[lc] * r2;
+        r[tid] = r2;
+      }
+      const double zz2 = coarse_block_sum(z2 * z2, red);
+      const double rz2 = coarse_block_sum(r2 * z2, red);
+      if (sqrt(zz2) <= tol) break;
+      const double beta = rz2 / rz;
+      __syncthreads();   // every thread has read P of this iteration's product
+      if (in) P[tid] = z2 + beta * pi;
+      rz = rz2;
+    }
+  }
+  __syncthreads();
+  // ---- upward leg
+  for (int l = nl - 2; l >= 0; --l) {
+    const TailLevel& F = ta.L[l];
+    const TailLevel& C = ta.L[l + 1];
+    const int n = F.n, pxy = F.px * F.py;
+    const bool in = tid < n;
+    if (in) {                                                     // t = x + P x_c (k_prolong_to)
+      const double x0 = X[l][tid];
+      double s = 0.0;
+      if (MK[l][tid] == 0) {
+        const int i = tid % F.px, t = tid / F.px, j = t % F.py, kg = t / F.py;
+        const int ox = i & 1, oy = j & 1, oz = kg & 1;
+        const int sx = 1, sy = C.px, sz = C.px * C.py;
+        const int c = (i >> 1) + sy * (j >> 1) + sz * (kg >> 1);
+        const double* xc = X[l + 1];
+        if (tk == 0) {
+          const int ex = ox ? sx : 0, ey = oy ? sy : 0, ez = oz ? sz : 0;
+          const double c000 = xc[c], c100 = xc[c + ex], c010 = xc[c + ey], c110 = xc[c + ey + ex];
+          const double c001 = xc[c + ez], c101 = xc[c + ez + ex], c011 = xc[c + ez + ey], c111 = xc[c + ez + ey + ex];
+          const double v00 = 0.5 * (c000 + c100), v10 = 0.5 * (c010 + c110), v01 = 0.5 * (c001 + c101),
+                       v11 = 0.5 * (c011 + c111);
+          if (oy && oz) s = 0.25 * (v00 + v10 + v01 + v11);
+          else if (oy | oz) s = 0.5 * (v00 + (oy ? v10 : v01));
+          else s = v00;
+        } else {
+          const int o = ox * sx + oy * sy + oz * sz;
+          if (tk == 2 && ox && oy) s = 0.5 * (xc[c + sx] + xc[c + sy]);
+          else s = (o == 0) ? xc[c] : 0.5 * (xc[c] + xc[c + o]);
+        }
+      }
+      T[l][tid] = x0 + s;
+    }
+    __syncthreads();
+    if (in) {                                                     // post-smoothing (la_spmv_jacobi)
+      const double at = (l == 0) ? tail_row<KIND>(a0, 1, T[l], tid, F.px, pxy, n)
+                                 : tail_row<KIND>(M[l] + tid, n, T[l], tid, F.px, pxy, n);
+      X[l][tid] = T[l][tid] + dv[l] * (B[l][tid] - at) * F.w;
+    }
+    __syncthreads();
+  }
+  if (tid < ta.L[0].n) ta.x0[tid] = X[0][tid];
+}
+
+// LDS bytes of the tail kernel for the given level sizes; 0 when the levels do not fit its limits
+static size_t mg_tail_lds(const int* n, int nl, int S) {
+  if (nl < 1 || nl > MG_TAIL_MAX || n[0] > MG_TAIL_ROWS) return 0;
+  size_t d = 0, mat = 0, mk = 0;
+  for (int l = 0; l < nl; ++l) { d += 3 * (size_t)n[l]; mk += ((size_t)n[l] + 7) & ~(size_t)7; if (l > 0) mat += (size_t)S * n[l]; }
+  d += 2 * (size_t)n[nl - 1];
+  if (mat > MG_TAIL_MATPOOL) return 0;
+  return (d + mat) * sizeof(double) + mk;
+}
+
+static inline double cheb_w(const MgLevel& L, int which) {
+  const double hi = L.lam[which], lo = MG_CHEB_LOWER * hi;
+  return 1.0 / (0.5 * (hi + lo));
+}
+
+// first level of the tail (nlev: no tail): from there on every level holds a stencil-ELL operator, is not
+// distributed and the levels fit the kernel's limits (rows of the first one, LDS of the others)
+static int mg_tail_begin(const pph_ctx* ctx, int which) {
+  const std::vector<MgLevel>& mg = ctx->mg;
+  const int nlev = (int)mg.size();
+  if (!ctx->coarse_on_device) return nlev;
+  const int64_t cap = ctx->mg_tail_rows < MG_TAIL_ROWS ? ctx->mg_tail_rows : MG_TAIL_ROWS;
+  int lt = nlev;
+  for (int l = nlev - 1; l >= 1; --l) {
+    const MgLevel& L = mg[l];
+    if (L.n > cap || !L.ell[which].val || (ctx->world > 1 && !L.replicated)) break;
+    int n[MG_TAIL_MAX];
+    const int nl = nlev - l;
+    if (nl > MG_TAIL_MAX) break;
+    for (int q = 0; q < nl; ++q) n[q] = (int)mg[l + q].n;
+    if (mg_tail_lds(n, nl, sell_slots(ctx->mesh.kind)) == 0) break;
+    lt = l;
+  }
+  return lt;
+}
+
+static bool mg_can_fuse(const pph_ctx* ctx, int which, int nsmooth) {
+  if (!ctx->mg_fused || nsmooth != 1 || ctx->mg.size() < 2) return false;
+  for (const MgLevel& L : ctx->mg)
+    if (!L.ell[which].val) return false;
+  return true;
+}
+
+// V(1,1) on stencil-ELL levels: per level two SpMV launches (residual; post-smoothing sweep with the Jacobi update in
+// its epilogue) and two transfer launches (restriction fused with the coarse level's pre-smoothing; interpolation),
+// then the tail kernel.  Same operations as the general cycle below.
+static void mg_vcycle_fused(pph_ctx* ctx, int which, const double* rin, double* zout) {
+  std::vector<MgLevel>& mg = ctx->mg;
+  const int nlev = (int)mg.size();
+  const bool dist = ctx->world > 1;
+  const int kind = ctx->mesh.kind;
+  const TStencil st = make_transfer_stencil(kind);
+  const int lt = mg_tail_begin(ctx, which);
+  const int top = (lt < nlev) ? lt : nlev - 1;   // levels [0, top) are swept by full-chip kernels
+  for (int l = 0; l < top; ++l) {
+    MgLevel& L = mg[l];
+    MgLevel& C = mg[l + 1];
+    const double* b = (l == 0) ? rin : L.b.p;
+    double* x = (l == 0) ? zout : L.x.p;
+    ctx->comm_suspended = L.replicated;
+    if (l == 0)   // coarser levels: done by the restriction that produced their right-hand side
+      hipLaunchKernelGGL(k_cheb_init, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, x, L.d.p, b, L.dinv[which].p,
+                         cheb_w(L, which), 1, 0, L.n);
+    la_spmv_resid(ctx, level_csr(ctx, L, which), x, b, L.r.p);
+    if (dist && !L.replicated) (void)la_halo(ctx, *L.geom, L.r.p);
+    // the coarse level's pre-smoothing rides along unless the tail kernel (or the coarsest solve) does it itself
+    const bool init_c = (l + 1 < top);
+    double* xc = init_c ? C.x.p : nullptr;
+    const double* dc = init_c ? C.dinv[which].p : nullptr;
+    const double wc = init_c ? cheb_w(C, which) : 0.0;
+    const bool sum_c = dist && C.replicated && !L.replicated;   // partial right-hand sides are summed first
+    if (sum_c) { xc = nullptr; }
+    if (kind == PPH_CELL_HEX)
+      hipLaunchKernelGGL(k_restrict_q1<3>, dim3(mg_grid(C.n)), dim3(256), 0, ctx->stream, C.b.p, L.r.p, C.maskp[which],
+                         L.maskp[which], tgeom(L, C), xc, dc, wc);
+    else if (kind == PPH_CELL_QUAD)
+      hipLaunchKernelGGL(k_restrict_q1<2>, dim3(mg_grid(C.n)), dim3(256), 0, ctx->stream, C.b.p, L.r.p, C.maskp[which],
+                         L.maskp[which], tgeom(L, C), xc, dc, wc);
+    else
+      hipLaunchKernelGGL(k_restrict, dim3(mg_grid(C.n)), dim3(256), 0, ctx->stream, C.b.p, L.r.p, st, C.maskp[which],
+                         L.maskp[which], tgeom(L, C), xc, dc, wc);
+    if (sum_c) {
+      (void)la_allreduce_vec(ctx, C.b.p, C.n);
+      if (init_c)
+        hipLaunchKernelGGL(k_cheb_init, dim3(mg_grid(C.n)), dim3(256), 0, ctx->stream, C.x.p, C.d.p, C.b.p,
+                           C.dinv[which].p, cheb_w(C, which), 1, 0, C.n);
+    }
+  }
+  if (lt < nlev) {
+    TailArgs ta;
+    int ns[MG_TAIL_MAX];
+    ta.nl = nlev - lt;
+    for (int q = 0; q < ta.nl; ++q) {
+      MgLevel& L = mg[lt + q];
+      TailLevel& T = ta.L[q];
+      T.A = L.ell[which].val; T.ld = L.ell[which].ld; T.dinv = L.dinv[which].p; T.mask = L.maskp[which];
+      T.px = L.px; T.py = L.py; T.pz = L.pz; T.n = (int)L.n;
+      T.w = cheb_w(L, which);
+      ns[q] = (int)L.n;
+    }
+    ta.b0 = mg[lt].b.p;
+    ta.x0 = mg[lt].x.p;
+    const int tk = (kind == PPH_CELL_QUAD || kind == PPH_CELL_HEX) ? 0 : (kind == PPH_CELL_TET ? 1 : 2);
+    int threads = (int)((mg[lt].n + 63) / 64) * 64;
+    if (threads < 64) threads = 64;
+    const size_t lds = mg_tail_lds(ns, ta.nl, sell_slots(kind));
+#define PPH_TAIL_GO(KK) \
+  hipLaunchKernelGGL(k_mg_tail<KK>, dim3(1), dim3(threads), lds, ctx->stream, ta, st, tk, 1e-12, 500)
+    switch (kind) {
+      case PPH_CELL_QUAD: PPH_TAIL_GO(PPH_CELL_QUAD); break;
+      case PPH_CELL_TRI: PPH_TAIL_GO(PPH_CELL_TRI); break;
+      case PPH_CELL_HEX: PPH_TAIL_GO(PPH_CELL_HEX); break;
+      default: PPH_TAIL_GO(PPH_CELL_TET); break;
+    }
+#undef PPH_TAIL_GO
+  } else {
+    // no tail (coarsest level too large or distributed): the host-driven / single-level solve of the general cycle
+    MgLevel& C = mg[nlev - 1];
+    int its = 0;
+    ctx->comm_suspended = C.replicated;
+    if ((!dist || C.replicated) && C.n <= 4096 && ctx->coarse_on_device)
+      hipLaunchKernelGGL(k_coarse_cg_sell, dim3(1), dim3(C.n <= 256 ? 256 : 1024), 0, ctx->stream, C.ell[which].val,
+                         C.ell[which].ld, make_stencil(kind), C.px, C.py, C.pz, C.dinv[which].p, C.b.p, C.x.p, C.r.p,
+                         C.d.p, C.t.p, (int)C.n, 1e-12, 500);
+    else
+      pph_cg_jacobi(ctx, level_csr(ctx, C, which), C.b.p, C.x.p, C.dinv[which].p, 1e-12, 0.0, 500, C.r.p, C.d.p, C.t.p,
+                    C.w.p, &its);
+  }
+  for (int l = top - 1; l >= 0; --l) {
+    MgLevel& L = mg[l];
+    MgLevel& C = mg[l + 1];
+    const double* b = (l == 0) ? rin : L.b.p;
+    double* x = (l == 0) ? zout : L.x.p;
+    ctx->comm_suspended = L.replicated;
+    if (dist && !C.replicated) (void)la_halo(ctx, *C.geom, C.x.p);
+    const TGeom tg = tgeom(L, C);
+    if (kind == PPH_CELL_QUAD || kind == PPH_CELL_HEX)
+      hipLaunchKernelGGL(k_prolong_to<0>, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, L.t.p, x, C.x.p, L.maskp[which], tg);
+    else if (kind == PPH_CELL_TET)
+      hipLaunchKernelGGL(k_prolong_to<1>, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, L.t.p, x, C.x.p, L.maskp[which], tg);
+    else
+      hipLaunchKernelGGL(k_prolong_to<2>, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, L.t.p, x, C.x.p, L.maskp[which], tg);
+    la_spmv_jacobi(ctx, level_csr(ctx, L, which), L.t.p, b, L.dinv[which].p, cheb_w(L, which), x);
+  }
+  ctx->comm_suspended = false;
+}
+
 void mg_vcycle(pph_ctx* ctx, int which, const double* rin, double* zout, int nsmooth) {
+  if (mg_can_fuse(ctx, which, nsmooth)) { mg_vcycle_fused(ctx, which, rin, zout); return; }
   std::vector<MgLevel>& mg = ctx->mg;
   const int nlev = (int)mg.size();
   const TStencil st = make_transfer_stencil(ctx->mesh.kind);
@@ -663,13 +1060,13 @@ void mg_vcycle(pph_ctx* ctx, int which, const double* rin, double* zout, int nsm
     if (dist && !L.replicated) (void)la_halo(ctx, *L.geom, L.r.p);  // restriction reads one fine plane beyond the owned ones
     if (ctx->mesh.kind == PPH_CELL_HEX)
       hipLaunchKernelGGL(k_restrict_q1<3>, dim3(mg_grid(C.n)), dim3(256), 0, ctx->stream, C.b.p, L.r.p, C.maskp[which],
-                         L.maskp[which], tgeom(L, C));
+                         L.maskp[which], tgeom(L, C), (double*)nullptr, (const double*)nullptr, 0.0);
     else if (ctx->mesh.kind == PPH_CELL_QUAD)
       hipLaunchKernelGGL(k_restrict_q1<2>, dim3(mg_grid(C.n)), dim3(256), 0, ctx->stream, C.b.p, L.r.p, C.maskp[which],
-                         L.maskp[which], tgeom(L, C));
+                         L.maskp[which], tgeom(L, C), (double*)nullptr, (const double*)nullptr, 0.0);
     else
       hipLaunchKernelGGL(k_restrict, dim3(mg_grid(C.n)), dim3(256), 0, ctx->stream, C.b.p, L.r.p, st, C.maskp[which],
-                         L.maskp[which], tgeom(L, C));
+                         L.maskp[which], tgeom(L, C), (double*)nullptr, (const double*)nullptr, 0.0);
     if (dist && C.replicated && !L.replicated) (void)la_allreduce_vec(ctx, C.b.p, C.n);
   }
   // coarsest level: Jacobi-CG to 1e-12 (a handful of unknowns)

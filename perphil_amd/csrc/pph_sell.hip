@@ -12,37 +12,6 @@
 // + 16 nrows (x read once, y written once).
 #include "pph_internal.h"
 
-// stencil of a cell kind as (dy,dz) lines with a 3-bit mask of the dx in {-1,0,+1} present, lines in ascending
-// (dz,dy) order: slot numbering = ascending (dz,dy,dx) = the CSR column order (make_stencil)
-template <int KIND> struct SellSt;
-template <> struct SellSt<PPH_CELL_QUAD> {
-  static constexpr int NL = 3, S = 9;
-  __host__ __device__ static constexpr int dy(int l) { return l - 1; }
-  __host__ __device__ static constexpr int dz(int) { return 0; }
-  __host__ __device__ static constexpr int mask(int) { return 7; }
-};
-template <> struct SellSt<PPH_CELL_TRI> {
-  static constexpr int NL = 3, S = 7;
-  __host__ __device__ static constexpr int dy(int l) { return l - 1; }
-  __host__ __device__ static constexpr int dz(int) { return 0; }
-  __host__ __device__ static constexpr int mask(int l) { return l == 0 ? 6 : (l == 1 ? 7 : 3); }
-};
-template <> struct SellSt<PPH_CELL_HEX> {
-  static constexpr int NL = 9, S = 27;
-  __host__ __device__ static constexpr int dy(int l) { return l % 3 - 1; }
-  __host__ __device__ static constexpr int dz(int l) { return l / 3 - 1; }
-  __host__ __device__ static constexpr int mask(int) { return 7; }
-};
-template <> struct SellSt<PPH_CELL_TET> {
-  static constexpr int NL = 9, S = 15;
-  __host__ __device__ static constexpr int dy(int l) { return l % 3 - 1; }
-  __host__ __device__ static constexpr int dz(int l) { return l / 3 - 1; }
-  // (dz,dy): (-1,-1) (-1,0) (-1,1) (0,-1) (0,0) (0,1) (1,-1) (1,0) (1,1)
-  __host__ __device__ static constexpr int mask(int l) {
-    return (l == 0 || l == 1 || l == 3) ? 3 : (l == 4 ? 7 : ((l == 5 || l == 7 || l == 8) ? 6 : 0));
-  }
-};
-
 __device__ inline double sell_wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -124,7 +93,7 @@ __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_
     if (MODE == 0) y[r] = acc[i];
     else if (MODE == 1) y[r] = bv[i] - acc[i];
     else if (MODE == 2) { y[r] = acc[i]; dotacc += acc[i] * xr[i]; }
-    else y[r] = xr[i] + w * dv[i] * (bv[i] - acc[i]);
+    else y[r] = xr[i] + dv[i] * (bv[i] - acc[i]) * w;   // the order of k_cheb_init: dinv * r / theta
   }
 }
 

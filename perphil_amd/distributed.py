@@ -34,17 +34,40 @@ def _loaded_rccl_path() -> bytes:
     return b""
 
 
-def init_rccl(ctx: _ffi.Context, group=None) -> None:
-    """Create the context's RCCL communicator: rank 0 draws the unique id, torch.distributed broadcasts
-    it (any backend), every rank joins; then the library's self-test runs on the context stream."""
+def _agree(ok: bool, group=None) -> bool:
+    """Logical AND of a per-rank flag over the torch.distributed group (any backend)."""
+    import torch
+    import torch.distributed as dist
+
+    flag = torch.tensor([1.0 if ok else 0.0])
+    if dist.get_backend(group) == "nccl":
+        flag = flag.cuda()
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(flag.item() == 1.0)
+
+
+def init_rccl(ctx: _ffi.Context, group=None) -> int:
+    """Create the context's RCCL communicator and run the library's self-test; returns the world size the
+    self-test's all-reduce observed.  Collective over the torch.distributed group, and written so that a failure
+    on ONE rank can never leave the others waiting inside an RCCL call:
+
+    1. every rank checks that librccl loads (``pph_rccl_available``) and the ranks agree on that (torch-level MIN)
+       BEFORE anyone enters ``ncclCommInitRank``;
+    2. rank 0 draws the unique id; a failed draw travels as an all-zero id in the same broadcast;
+    3. every rank joins the communicator, then runs the straight-line self-test (all three phases are always
+       issued, failures are reported afterwards), and the ranks agree on the verdict.
+
+    Raises RuntimeError on every rank when any rank failed."""
     import torch
     import torch.distributed as dist
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     path = _loaded_rccl_path()
+    loadable = _ffi.lib.pph_rccl_available(path) == _ffi.PPH_OK
+    if not _agree(loadable, group):
+        raise RuntimeError("librccl is not loadable on every rank" + ("" if loadable else f" (rank {rank}: missing)"))
     ident = np.zeros(128, dtype=np.uint8)
     if rank == 0:
-        # a failure here must still reach the broadcast below, or the other ranks would wait for it forever
         if _ffi.lib.pph_rccl_unique_id(path, ident.ctypes.data_as(C.c_void_p)) != _ffi.PPH_OK:
             ident[:] = 0
     t = torch.from_numpy(ident)
@@ -55,10 +78,16 @@ def init_rccl(ctx: _ffi.Context, group=None) -> None:
     else:
         dist.broadcast(t, 0, group=group)
     ident = np.ascontiguousarray(ident)
-    if not ident.any():
-        raise RuntimeError("rank 0 could not draw an RCCL unique id (librccl not loadable?)")
-    ctx._check(_ffi.lib.pph_comm_init_rccl(ctx._h, rank, world, ident.ctypes.data_as(C.c_void_p), path))
-    ctx._check(_ffi.lib.pph_comm_selftest(ctx._h))
+    if not ident.any():   # identical on every rank: all of them leave here together
+        raise RuntimeError("rank 0 could not draw an RCCL unique id")
+    st = _ffi.lib.pph_comm_init_rccl(ctx._h, rank, world, ident.ctypes.data_as(C.c_void_p), path)
+    seen = C.c_int(0)
+    if st == _ffi.PPH_OK:
+        st = _ffi.lib.pph_comm_selftest2(ctx._h, C.byref(seen))
+    msg = (_ffi.lib.pph_last_error(ctx._h) or b"").decode() if st != _ffi.PPH_OK else ""
+    if not _agree(st == _ffi.PPH_OK and seen.value == world, group):
+        raise RuntimeError(f"RCCL transport failed its self-test on at least one rank (rank {rank}: {msg or 'ok'})")
+    return int(seen.value)
 
 
 class _DevView:
@@ -143,7 +172,7 @@ class SlabSolver:
     def __init__(self, n_cells: int, world: int, rank: int, device: int, k1: float, k2: float, beta: float, mu: float,
                  inner_rtol: float = 1e-10, smooth: int = 2, kind: int = _ffi.CELL_HEX, group=None,
                  inner_pc: int = _ffi.PC_MG, transport: str = "auto", inner_reduction: float = 0.0,
-                 inner_norm: int = 0):
+                 inner_norm: int = 0, allow_fallback: bool = False):
         from .manufactured_solutions import exact_expressions_3d
         from .parameters import DPPParameters
         from . import fd
@@ -159,31 +188,29 @@ class SlabSolver:
         # the nccl backend), "torch" = callbacks into torch.distributed (needed for gloo rehearsals)
         if transport == "auto":
             transport = "rccl" if self.comm.backend == "nccl" else "torch"
+        self.transport_requested = transport
         self.transport = transport
+        self.ranks_seen = world if world == 1 else 0
         if transport == "rccl":
-            ok = 1
             try:
-                init_rccl(self.ctx, group)
-            except Exception as e:
-                ok = 0
-                if world > 1:
-                    print(f"[perphil_amd.distributed] RCCL transport unavailable on rank {rank} ({e!r})", flush=True)
-            # every rank must end up on the same transport: one failed self-test sends all of them to the callbacks
-            if world > 1:
-                import torch
-                import torch.distributed as dist
-
-                flag = torch.tensor([float(ok)])
-                if self.comm.backend == "nccl":
-                    flag = flag.cuda()
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-                ok = int(flag.item())
-            if not ok:
-                if world > 1 and rank == 0:
-                    print("[perphil_amd.distributed] falling back to torch.distributed callbacks on all ranks", flush=True)
+                self.ranks_seen = init_rccl(self.ctx, group)   # raises on EVERY rank when any rank failed
+            except RuntimeError as e:
+                # no silent downgrade: the callback transport synchronises the host on every exchange, so a scaling
+                # figure taken on it must say so (bench.py records config.transport) and has to be asked for
+                if not allow_fallback:
+                    raise RuntimeError(f"RCCL transport unavailable ({e}); pass allow_fallback=True (bench.py "
+                                       f"--allow-fallback) to run on the torch.distributed callbacks instead") from e
+                if rank == 0:
+                    print(f"[perphil_amd.distributed] {e}: falling back to torch.distributed callbacks on all ranks",
+                          flush=True)
                 self.transport = "torch"
         if self.transport == "torch":
             self.comm.attach(self.ctx)
+            if world > 1:
+                # the callback transport's own check: one all-reduce of 1 over the group
+                one = np.ones(1)
+                self.comm._allreduce(None, one.ctypes.data_as(C.c_void_p), 1)
+                self.ranks_seen = int(one[0])
         mesh = fd.UnitCubeMesh(n_cells, n_cells, n_cells, hexahedral=(kind == _ffi.CELL_HEX))
         loc, glob = s.boundary_local()
         X = mesh.node_coordinates(glob)
@@ -210,6 +237,13 @@ class SlabSolver:
         self.ctx.assemble(k1, k2, beta, mu, monolithic=self.monolithic)
         _, self.info, _ = self.ctx.solve(self.cfg, fetch=False)
         return self.info
+
+    @property
+    def transport_label(self) -> str:
+        """What carries the halo planes and reductions: "rccl" (library-issued ncclSend/Recv/AllReduce on the solver
+        stream), "torch-nccl" / "torch-gloo" (callbacks into torch.distributed, one host synchronisation per
+        exchange)."""
+        return "rccl" if self.transport == "rccl" else f"torch-{self.comm.backend}"
 
     def gather_solution(self) -> Optional[np.ndarray]:
         """Global field-major solution on rank 0 (tests / small runs only)."""

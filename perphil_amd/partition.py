@@ -1,7 +1,7 @@
 """
 Cell-slab decomposition of the structured unit cube along z (scheme "row-owned").
 
-Rank r of G owns the node planes [c_r, c_{r+1}) with c_r = r * nz / G (the last rank also the top plane
+Rank r of G owns the node planes [c_r, c_{r+1}) with c_r = floor(r * nz / G) (the last rank also the top plane
 nz) and builds a LOCAL box of cell layers [c_r - 1, c_{r+1}) (no extra layer for rank 0): every cell
 touching an owned node is local, so owned matrix rows are assembled completely without communication.
 The lowest local node plane of ranks > 0 and the highest of ranks < G-1 are GHOST planes: their rows are
@@ -78,10 +78,10 @@ class Slab:
 def make_slab(nx: int, ny: int, nz: int, world: int, rank: int) -> Slab:
     if world < 1 or not (0 <= rank < world):
         raise ValueError("bad rank/world")
-    if nz % world != 0 or nz // world < 2:
-        raise ValueError(f"nz = {nz} must be a multiple of the number of ranks ({world}) with >= 2 layers per rank")
-    per = nz // world
-    c0, c1 = rank * per, (rank + 1) * per
+    if nz // world < 2:
+        raise ValueError(f"nz = {nz} gives fewer than 2 cell layers per rank on {world} ranks")
+    # balanced split, also when nz is not a multiple of the number of ranks: rank r owns layers [r nz / G, (r+1) nz / G)
+    c0, c1 = (rank * nz) // world, ((rank + 1) * nz) // world
     glo, ghi = rank > 0, rank < world - 1
     zb = c0 - (1 if glo else 0)
     return Slab(nx, ny, nz, world, rank, zb, c1 - zb, glo, ghi)

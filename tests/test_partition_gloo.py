@@ -136,11 +136,12 @@ def test_slab_partition_reproduces_serial_oracle(world, n):
 def test_partition_invariants():
     from perphil_amd.partition import make_slab
 
-    for nz, world in ((8, 2), (16, 4), (256, 8)):
+    for nz, world in ((8, 2), (16, 4), (256, 8), (10, 4), (250, 8), (37, 3)):   # uneven splits included
         planes = []
         for r in range(world):
             s = make_slab(4, 6, nz, world, r)
             assert s.ghost_lo == (r > 0) and s.ghost_hi == (r < world - 1)
+            assert len(s.owned_planes) >= 2
             assert s.local_planes == len(s.owned_planes) + s.ghost_lo + s.ghost_hi
             assert (s.owned_local.stop - s.owned_local.start) == len(s.owned_planes) * s.plane
             planes += list(s.owned_planes)
@@ -148,4 +149,4 @@ def test_partition_invariants():
             assert np.all(glob - loc == s.z_begin * s.plane)
         assert planes == list(range(nz + 1))   # every node plane owned exactly once
     with pytest.raises(ValueError):
-        make_slab(4, 4, 10, 4, 0)
+        make_slab(4, 4, 7, 4, 0)     # fewer than 2 cell layers per rank
