@@ -79,10 +79,23 @@ int pph_ctx_create(int device, pph_ctx** out) {
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
   if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return fail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return fail("hipEventCreate", e);
-  if ((e = hipHostMalloc((void**)&ctx->h_scal, sizeof(double) * PPH_MAX_SCAL, hipHostMallocDefault)) != hipSuccess)
+  // host mirror of the reduction results: pinned, mapped and coherent, so that a one-wave kernel can publish results
+  // straight into it and the host can poll a sequence word instead of paying a stream synchronisation (la_fetch)
+  if ((e = hipHostMalloc((void**)&ctx->h_scal, sizeof(double) * (PPH_MAX_SCAL + 8),
+                         hipHostMallocMapped | hipHostMallocCoherent)) != hipSuccess)
     return fail("hipHostMalloc", e);
+  memset(ctx->h_scal, 0, sizeof(double) * (PPH_MAX_SCAL + 8));
+  if ((e = hipHostGetDevicePointer((void**)&ctx->h_scal_dev, ctx->h_scal, 0)) != hipSuccess)
+    return fail("hipHostGetDevicePointer", e);
+  ctx->h_seq = reinterpret_cast<unsigned long long*>(ctx->h_scal + PPH_MAX_SCAL);
+  ctx->h_seq_dev = reinterpret_cast<unsigned long long*>(ctx->h_scal_dev + PPH_MAX_SCAL);
   // reduction results + partial sums (32 slots x 2048 workgroups)
   if (ctx->scal.alloc(ctx, (size_t)PPH_MAX_SCAL + 32 * 2048) < 0) {
+    g_last_error = ctx->err;
+    delete ctx;
+    return PPH_ERR_NOMEM;
+  }
+  if (ctx->pub_ctr.alloc(ctx, 1) < 0 || hipMemset(ctx->pub_ctr.p, 0, sizeof(unsigned long long)) != hipSuccess) {
     g_last_error = ctx->err;
     delete ctx;
     return PPH_ERR_NOMEM;
@@ -124,6 +137,8 @@ int pph_ctx_destroy(pph_ctx* ctx) {
   for (auto& w : ctx->work) w.release();
   for (auto& p : ctx->ev_pool) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
   ctx->scal.release();
+  ctx->pub_ctr.release();
+  la_release_graphs(ctx);
   if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -467,6 +482,7 @@ int pph_spmv_bench(pph_ctx* ctx, int which, int reps, double* avg_ms) {
 
 int pph_set_option(pph_ctx* ctx, const char* name, double value) {
   if (!ctx || !name) return PPH_ERR_INVALID;
+  la_release_graphs(ctx);   // captured iteration bodies were recorded under the old settings
   if (!strcmp(name, "spmv_lanes")) {
     const int v = (int)value;
     PPH_REQUIRE(ctx, v == 0 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64, "spmv_lanes must be 0,4,8,16,32,64");
@@ -499,6 +515,8 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
     return PPH_OK;
   }
   if (!strcmp(name, "spmv_blocks")) { ctx->spmv_blocks = (int)value; return PPH_OK; }
+  if (!strcmp(name, "use_graphs")) { ctx->use_graphs = value != 0.0 ? 1 : 0; return PPH_OK; }
+  if (!strcmp(name, "fetch_spin")) { ctx->fetch_spin = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "device_scalars")) { ctx->device_scalars = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "op_format")) {
     PPH_REQUIRE(ctx, value == 0.0 || value == 1.0, "op_format: 0 CSR, 1 stencil-ELL");

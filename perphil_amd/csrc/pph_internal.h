@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -193,6 +194,19 @@ struct MgLevel {
   double lam[2] = {0, 0};        // upper bound of the spectrum of D^-1 A
 };
 
+// captured iteration bodies (pph_la.hip: la_run_graph): valid while every pointer baked into the kernels' arguments is
+struct GraphKey {
+  const void* p[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  int64_t n = 0;
+  int slot = 0, tag = 0;
+  uint64_t epoch = 0;
+  bool operator==(const GraphKey& o) const {
+    for (int i = 0; i < 8; ++i) if (p[i] != o.p[i]) return false;
+    return n == o.n && slot == o.slot && tag == o.tag && epoch == o.epoch;
+  }
+};
+struct GraphEntry { GraphKey key; hipGraphExec_t exec = nullptr; uint64_t used = 0; };
+
 struct pph_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -246,9 +260,29 @@ struct pph_ctx {
 
   // solver workspace
   DevBuf<double> scal;                  // device scalars / reduction partials
-  double* h_scal = nullptr;             // pinned host mirror
+  // optional by-products of the level-0 post-smoothing sweep of the fused V-cycle (set by the caller of mg_vcycle,
+  // cleared by it): partial dot product rin . zout over the owned rows -> scal[mg_dot_slot]
+  int mg_dot_slot = -1;
+  Seg mg_dot_seg = {0, 0, 0, 0};
+  bool mg_x0_ready = false;             // zout already holds the pre-smoothed first guess dinv .* rin * w (k_cg_update_dev)
+  double* h_scal = nullptr;             // pinned host mirror (mapped + coherent)
+  double* h_scal_dev = nullptr;         // its device-side address
+  unsigned long long* h_seq = nullptr;  // sequence word behind the mirror: number of the last published fetch
+  unsigned long long* h_seq_dev = nullptr;
+  unsigned long long pub_seq = 0;       // fetches published so far
+  DevBuf<unsigned long long> pub_ctr;   // device-side count of publications (k_publish), so that a publication can be
+                                        // replayed from a graph: the sequence number is not a kernel argument
+  int use_graphs = 1;                   // Krylov iteration bodies are captured into hipGraphs where possible
+  std::vector<GraphEntry> graphs;
+  uint64_t graph_clock = 0;
+  int64_t n_graph_launch = 0, n_graph_capture = 0;
+  int fetch_spin = 1;                   // 1: la_fetch publishes through the mapped mirror and polls (no stream synchronisation)
   std::vector<DevBuf<double>> work;     // named work vectors, grown on demand
   std::vector<MgLevel> mg;              // multigrid hierarchy (level 0 = fine)
+  DevBuf<double> mg_w;                  // [2 l + which]: 1 / theta of the one-step Chebyshev smoother of level l (device copy:
+                                        // kernels read it through a pointer, so captured graphs survive a re-assembly)
+  std::vector<double> mg_w_host;
+  uint64_t mg_epoch = 0;                // bumped whenever the hierarchy's buffers are (re)allocated: captured graphs die
   bool mg_ok = false;                   // hierarchy values (operators, masks, bounds) match the assembled system
   bool mg_struct_ok = false;            // hierarchy structure (level meshes, patterns, buffers) matches mesh + communicator
 
@@ -311,9 +345,18 @@ void pph_launch_row_near(pph_ctx* ctx, const MeshData& mesh, const uint8_t* m1, 
 // linear algebra on the context stream; all results that feed control flow go through ctx->scal
 void la_spmv(pph_ctx* ctx, const Csr& A, const double* x, double* y);
 void la_spmv_resid(pph_ctx* ctx, const Csr& A, const double* x, const double* b, double* y);  // y = b - A x
-void la_spmv_jacobi(pph_ctx* ctx, const Csr& A, const double* x, const double* b, const double* dinv, double w, double* y);
+// dot_slot >= 0: also scal[dot_slot] = b . y over the rows [dlo, dhi)
+void la_spmv_jacobi(pph_ctx* ctx, const Csr& A, const double* x, const double* b, const double* dinv,
+                    const double* w /* device */, double* y, int dot_slot = -1, int64_t dlo = 0, int64_t dhi = 0);
 // y = A x and partial sums of dot(x, y) -> scal slot
-void la_spmv_dot(pph_ctx* ctx, const Csr& A, const double* x, double* y, int slot);
+// (copy_src >= 0: scal[copy_dst] = scal[copy_src] is done by the final reduction's single workgroup)
+void la_spmv_dot(pph_ctx* ctx, const Csr& A, const double* x, double* y, int slot, int copy_src = -1, int copy_dst = -1);
+// publication of scal[slot .. slot + count) to the host mirror (enqueue) / wait for the last publication
+void la_publish(pph_ctx* ctx, int slot, int count);
+int la_wait_published(pph_ctx* ctx);
+// runs `body` (kernel launches on the context stream only) through a captured hipGraph cached under `key`
+int la_run_graph(pph_ctx* ctx, const GraphKey& key, const std::function<int()>& body);
+void la_release_graphs(pph_ctx* ctx);
 void la_set(pph_ctx* ctx, double* x, double v, int64_t n);
 void la_copy(pph_ctx* ctx, double* dst, const double* src, int64_t n);
 void la_axpy(pph_ctx* ctx, double* y, double alpha, const double* x, int64_t n);          // y += alpha x
@@ -325,7 +368,8 @@ bool la_device_scalars(const pph_ctx* ctx);
 int la_reduce_device(pph_ctx* ctx, int slot, int count);
 int la_fetch_raw(pph_ctx* ctx, int slot, int count);
 void la_cg_update_dev(pph_ctx* ctx, double* x, double* r, const double* p, const double* q, int slot_num, int slot_den,
-                      int64_t n, int slot_out, Seg sg);
+                      int64_t n, int slot_out, Seg sg, double* z0 = nullptr, const double* dinv0 = nullptr,
+                      const double* w0 = nullptr);
 void la_p_update_dev(pph_ctx* ctx, double* p, const double* z, int slot_num, int slot_den, int64_t n);
 void la_shift(pph_ctx* ctx, double* R, double* told, const double* tnew, double sign, int64_t n);  // R += sign (tnew - told); told = tnew
 void la_block2_apply(pph_ctx* ctx, double* z, const double* binv /*[4][n]*/, const double* r, int64_t n);
@@ -360,7 +404,7 @@ void la_reset_spmv_stats(pph_ctx* ctx);
 
 // stencil-ELL operator format (pph_sell.hip)
 int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x, const double* b, const double* dinv,
-              double w, double* y, double* part);
+              const double* w /* device */, double* y, double* part, int64_t dlo = 0, int64_t dhi = 0);
 int sell_alloc(pph_ctx* ctx, const MeshData& mesh, DevBuf<double>& buf, Sell* out);
 int sell_from_csr(pph_ctx* ctx, const MeshData& mesh, const double* csr_val, DevBuf<double>& buf, Sell* out);
 int sell_to_csr(pph_ctx* ctx, const MeshData& mesh, const Sell& E, double* csr_val);
@@ -377,6 +421,8 @@ int mg_setup(pph_ctx* ctx);
 void mg_release(pph_ctx* ctx);
 // z = Vcycle(r) for block `which` (0: A11, 1: A22); r and z have fine-level length n
 void mg_vcycle(pph_ctx* ctx, int which, const double* r, double* z, int nsmooth);
+bool mg_pre_smoother(pph_ctx* ctx, int which, int nsmooth, const double** dinv, const double** w /* device */,
+                     bool* launch_only);
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

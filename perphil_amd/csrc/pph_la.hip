@@ -713,8 +713,10 @@ __global__ __launch_bounds__(256) void k_spmv_stream(const int64_t* __restrict__
 }
 
 __global__ __launch_bounds__(256) void k_reduce_final(const double* __restrict__ part, int nblocks,
-                                                      double* __restrict__ out) {
+                                                      double* __restrict__ out, const double* copy_src = nullptr,
+                                                      double* copy_dst = nullptr) {
   __shared__ double lds[4];
+  if (copy_dst && blockIdx.x == 0 && threadIdx.x == 0) *copy_dst = *copy_src;
   const double* p = part + (int64_t)blockIdx.x * PART_STRIDE;
   double v = 0.0;
   for (int i = threadIdx.x; i < nblocks; i += 256) v += p[i];
@@ -741,7 +743,8 @@ static int stream_T(int max_row) {
 // jdinv != null (stencil-ELL operators only): y = x + jw * jdinv .* (bvec - A x), one damped-Jacobi sweep out of place
 template <bool DOT>
 static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const double* bvec, double* y, double* part,
-                         const double* jdinv = nullptr, double jw = 0.0) {
+                         const double* jdinv = nullptr, const double* jw = nullptr, bool jdot = false, int64_t dlo = 0,
+                         int64_t dhi = 0) {
   const int variant = DOT ? 1 : 0;
   if (A.geom) {  // ghost planes of x <- owners (slabs only); field-major mixed vectors carry two fields
     (void)la_halo(ctx, *A.geom, const_cast<double*>(x));
@@ -765,7 +768,8 @@ static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const doub
   double bytes_per_nnz = 12.0;
   if (A.ell.val) {
     // stencil-ELL copy of the operator (pph_sell.hip): 8 B per stored entry, no index arrays
-    grid = sell_spmv(ctx, A.ell, A.nrows, jdinv ? 3 : (DOT ? 2 : (bvec ? 1 : 0)), x, bvec, jdinv, jw, y, part);
+    grid = sell_spmv(ctx, A.ell, A.nrows, jdinv ? (jdot ? 4 : 3) : (DOT ? 2 : (bvec ? 1 : 0)), x, bvec, jdinv, jw, y,
+                     part ? part : partials(ctx), dlo, dhi);
     if (ev) (void)hipEventRecord(ev->e1, ctx->stream);
     const double bytes = 8.0 * sell_slots(A.ell.kind) * (double)A.nrows + 16.0 * (double)A.nrows;
     ctx->n_spmv[variant]++;
@@ -941,14 +945,20 @@ void la_spmv_resid(pph_ctx* ctx, const Csr& A, const double* x, const double* b,
 
 // y = x + w * dinv .* (b - A x): one damped-Jacobi (one-step Chebyshev) sweep, out of place (y != x); A must carry a
 // stencil-ELL copy
-void la_spmv_jacobi(pph_ctx* ctx, const Csr& A, const double* x, const double* b, const double* dinv, double w, double* y) {
-  spmv_dispatch<false>(ctx, A, x, b, y, nullptr, dinv, w);
+void la_spmv_jacobi(pph_ctx* ctx, const Csr& A, const double* x, const double* b, const double* dinv, const double* w,
+                    double* y, int dot_slot, int64_t dlo, int64_t dhi) {
+  const int grid = spmv_dispatch<false>(ctx, A, x, b, y, dot_slot >= 0 ? partials(ctx) : nullptr, dinv, w, dot_slot >= 0,
+                                        dlo, dhi);
+  if (dot_slot >= 0)
+    hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, ctx->stream, partials(ctx), grid, ctx->scal.p + dot_slot);
 }
 
-void la_spmv_dot(pph_ctx* ctx, const Csr& A, const double* x, double* y, int slot) {
+void la_spmv_dot(pph_ctx* ctx, const Csr& A, const double* x, double* y, int slot, int copy_src, int copy_dst) {
   double* part = partials(ctx);
   const int grid = spmv_dispatch<true>(ctx, A, x, nullptr, y, part);
-  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, ctx->stream, part, grid, ctx->scal.p + slot);
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, ctx->stream, part, grid, ctx->scal.p + slot,
+                     copy_src >= 0 ? (const double*)(ctx->scal.p + copy_src) : (const double*)nullptr,
+                     copy_src >= 0 ? ctx->scal.p + copy_dst : (double*)nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1208,27 +1218,142 @@ int la_reduce_device(pph_ctx* ctx, int slot, int count) {
   return PPH_OK;
 }
 
+// Reduction results -> host without a stream synchronisation: a one-wave kernel copies the scalars into the pinned,
+// mapped, coherent mirror and then stores a sequence number behind it; the host polls that word.  A D2H copy plus
+// hipStreamSynchronize left the GPU idle for about 26 us per fetch (wake-up of the waiting thread + the next launch);
+// polling sees the values about 2 us after the kernel wrote them.  Every Krylov iteration fetches once.
+__global__ __launch_bounds__(64) void k_publish(const double* __restrict__ src, double* __restrict__ hdst, int count,
+                                                unsigned long long* __restrict__ hseq, unsigned long long* ctr) {
+  for (int i = threadIdx.x; i < count; i += 64) hdst[i] = src[i];
+  __threadfence_system();   // the wave's stores have reached the host before the sequence word follows
+  if (threadIdx.x == 0) {
+    // the sequence number is counted on the device (one publication at a time on the stream), so that a publication
+    // replayed from a captured graph needs no new kernel argument
+    const unsigned long long seq = *ctr + 1;
+    *ctr = seq;
+    __hip_atomic_store(hseq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+void la_publish(pph_ctx* ctx, int slot, int count) {
+  ++ctx->pub_seq;
+  hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, ctx->scal.p + slot, ctx->h_scal_dev + slot, count,
+                     ctx->h_seq_dev, ctx->pub_ctr.p);
+}
+
+int la_wait_published(pph_ctx* ctx) {
+  const unsigned long long seq = ctx->pub_seq;
+  volatile unsigned long long* p = ctx->h_seq;
+  for (unsigned long spins = 1;; ++spins) {
+    if (*p >= seq) break;
+    if ((spins & 0x3FFFF) == 0) {
+      // every ~millisecond: is the stream still alive?  (a failed kernel would otherwise be polled for ever)
+      const hipError_t e = hipStreamQuery(ctx->stream);
+      if (e == hipSuccess) {
+        if (*p >= seq) break;
+        pph_set_error(ctx, "reduction results were not published (sequence %llu, expected %llu)", *p, seq);
+        return PPH_ERR_HIP;
+      }
+      if (e != hipErrorNotReady) {
+        pph_set_error(ctx, "stream failed while waiting for reduction results: %s", hipGetErrorString(e));
+        return PPH_ERR_HIP;
+      }
+    }
+    __builtin_ia32_pause();
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return PPH_OK;
+}
+
+static int fetch_to_host(pph_ctx* ctx, int slot, int count) {
+  if (!ctx->fetch_spin) {
+    PPH_HIP(ctx, hipMemcpyAsync(ctx->h_scal + slot, ctx->scal.p + slot, sizeof(double) * (size_t)count,
+                                hipMemcpyDeviceToHost, ctx->stream));
+    PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PPH_OK;
+  }
+  la_publish(ctx, slot, count);
+  return la_wait_published(ctx);
+}
+
+// ---- captured iteration bodies ------------------------------------------------------------------------
+void la_release_graphs(pph_ctx* ctx) {
+  for (auto& g : ctx->graphs)
+    if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  ctx->graphs.clear();
+}
+
+int la_run_graph(pph_ctx* ctx, const GraphKey& key, const std::function<int()>& body) {
+  GraphEntry* hit = nullptr;
+  for (auto& g : ctx->graphs)
+    if (g.key == key) { hit = &g; break; }
+  if (!hit) {
+    // capture: the launches of `body` are recorded, not executed
+    const unsigned long long seq0 = ctx->pub_seq;
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+      (void)hipGetLastError();
+      ctx->use_graphs = 0;
+      return body();
+    }
+    const int st = body();
+    const hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+    ctx->pub_seq = seq0;   // nothing was published yet
+    hipGraphExec_t exec = nullptr;
+    if (st < 0 || e != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      if (graph) (void)hipGraphDestroy(graph);
+      ctx->use_graphs = 0;   // this runtime / this body cannot be captured: eager from now on
+      if (st < 0) return st;
+      return body();
+    }
+    (void)hipGraphDestroy(graph);
+    if (ctx->graphs.size() >= 16) {   // drop the least recently used entry
+      size_t lru = 0;
+      for (size_t i = 1; i < ctx->graphs.size(); ++i)
+        if (ctx->graphs[i].used < ctx->graphs[lru].used) lru = i;
+      (void)hipGraphExecDestroy(ctx->graphs[lru].exec);
+      ctx->graphs.erase(ctx->graphs.begin() + (long)lru);
+    }
+    GraphEntry ge;
+    ge.key = key; ge.exec = exec;
+    ctx->graphs.push_back(ge);
+    hit = &ctx->graphs.back();
+    ctx->n_graph_capture++;
+  }
+  hit->used = ++ctx->graph_clock;
+  // what the body would have counted on the host: one publication per replay
+  ++ctx->pub_seq;
+  PPH_HIP(ctx, hipGraphLaunch(hit->exec, ctx->stream));
+  ctx->n_graph_launch++;
+  return PPH_OK;
+}
+
 // host copy of already reduced scalars
 int la_fetch_raw(pph_ctx* ctx, int slot, int count) {
-  PPH_HIP(ctx, hipMemcpyAsync(ctx->h_scal + slot, ctx->scal.p + slot, sizeof(double) * (size_t)count,
-                              hipMemcpyDeviceToHost, ctx->stream));
-  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  PPH_TRY(fetch_to_host(ctx, slot, count));
   if (ctx->comm_status != PPH_OK) { ctx->err = ctx->comm_error; return ctx->comm_status; }
   return PPH_OK;
 }
 
 // x += alpha p ; r -= alpha q ; partials of r.r, with alpha = *num / *den read on the device
+// (z0 != null: also z0 = dinv0 .* r * w0, the multigrid cycle's pre-smoothing of the NEW residual from a zero guess -
+// the first kernel of the next preconditioner application, which then starts at its residual product)
 __global__ __launch_bounds__(256) void k_cg_update_dev(double* __restrict__ x, double* __restrict__ r,
                                                        const double* __restrict__ p, const double* __restrict__ q,
                                                        const double* __restrict__ num, const double* __restrict__ den,
-                                                       int64_t n, Seg sg, double* __restrict__ part) {
+                                                       int64_t n, Seg sg, double* __restrict__ part,
+                                                       double* __restrict__ z0, const double* __restrict__ dinv0,
+                                                       const double* __restrict__ w0p) {
   __shared__ double lds[4];
   const double alpha = *num / *den;
+  const double w0 = z0 ? *w0p : 0.0;
   double a = 0.0;
   EW_LOOP(i, n) {
     x[i] += alpha * p[i];
     const double ri = r[i] - alpha * q[i];
     r[i] = ri;
+    if (z0) z0[i] = dinv0[i] * ri * w0;
     if ((i >= sg.off1 && i < sg.off1 + sg.len1) || (i >= sg.off2 && i < sg.off2 + sg.len2)) a += ri * ri;
   }
   a = block_sum(a, lds);
@@ -1236,12 +1361,12 @@ __global__ __launch_bounds__(256) void k_cg_update_dev(double* __restrict__ x, d
 }
 
 void la_cg_update_dev(pph_ctx* ctx, double* x, double* r, const double* p, const double* q, int slot_num, int slot_den,
-                      int64_t n, int slot_out, Seg sg) {
+                      int64_t n, int slot_out, Seg sg, double* z0, const double* dinv0, const double* w0) {
   double* part = partials(ctx);
   int grid = ew_grid(n);
   if (grid > RED_BLOCKS) grid = RED_BLOCKS;
   hipLaunchKernelGGL(k_cg_update_dev, dim3(grid), dim3(256), 0, ctx->stream, x, r, p, q, ctx->scal.p + slot_num,
-                     ctx->scal.p + slot_den, n, sg, part);
+                     ctx->scal.p + slot_den, n, sg, part, z0, dinv0, w0);
   hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, ctx->stream, part, grid, ctx->scal.p + slot_out);
 }
 
@@ -1261,9 +1386,7 @@ int la_fetch(pph_ctx* ctx, int slot, int count) {
   const bool reduce = ctx->world > 1 && !ctx->comm_suspended;
   // RCCL: sum the partial results on the device, on the stream, before they travel to the host
   if (reduce && ctx->nccl_comm) PPH_TRY(comm_allreduce_device(ctx, ctx->scal.p + slot, count));
-  PPH_HIP(ctx, hipMemcpyAsync(ctx->h_scal + slot, ctx->scal.p + slot, sizeof(double) * (size_t)count,
-                              hipMemcpyDeviceToHost, ctx->stream));
-  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  PPH_TRY(fetch_to_host(ctx, slot, count));
   if (reduce && !ctx->nccl_comm) PPH_TRY(comm_allreduce_host(ctx, ctx->h_scal + slot, (int64_t)count));
   // a halo exchange or vector all-reduce that failed since the last fetch (their callers cannot return a status)
   if (ctx->comm_status != PPH_OK) { ctx->err = ctx->comm_error; return ctx->comm_status; }

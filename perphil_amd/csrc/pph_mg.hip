@@ -92,7 +92,7 @@ __global__ void k_mask_from_double(uint8_t* __restrict__ m, const double* __rest
 // (xc != null: also the coarse level's pre-smoothing from a zero guess, x_c = dinv_c .* b_c * wc, in the same pass)
 __global__ void k_restrict(double* __restrict__ bc, const double* __restrict__ rf, TStencil st,
                            const uint8_t* __restrict__ mc, const uint8_t* __restrict__ mf, TGeom g,
-                           double* __restrict__ xc, const double* __restrict__ dinvc, double wc) {
+                           double* __restrict__ xc, const double* __restrict__ dinvc, const double* __restrict__ wcp) {
   const int64_t nc = (int64_t)g.pxc * g.pyc * g.pzc;
   NODE_LOOP(id, nc) {
     const int I = (int)(id % g.pxc);
@@ -109,7 +109,7 @@ __global__ void k_restrict(double* __restrict__ bc, const double* __restrict__ r
       }
     }
     bc[id] = s;
-    if (xc) xc[id] = dinvc[id] * s * wc;
+    if (xc) xc[id] = dinvc[id] * s * (*wcp);
   }
 }
 
@@ -120,7 +120,7 @@ template <int DIM>
 __global__ __launch_bounds__(256) void k_restrict_q1(double* __restrict__ bc, const double* __restrict__ rf,
                                                      const uint8_t* __restrict__ mc, const uint8_t* __restrict__ mf,
                                                      TGeom g, double* __restrict__ xc, const double* __restrict__ dinvc,
-                                                     double wc) {
+                                                     const double* __restrict__ wcp) {
   const int64_t nc = (int64_t)g.pxc * g.pyc * g.pzc;
   NODE_LOOP(id, nc) {
     const int I = (int)(id % g.pxc);
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void k_restrict_q1(double* __restrict__ bc, co
           }
     }
     bc[id] = s;
-    if (xc) xc[id] = dinvc[id] * s * wc;
+    if (xc) xc[id] = dinvc[id] * s * (*wcp);
   }
 }
 
@@ -278,8 +278,11 @@ __global__ __launch_bounds__(256) void k_diag_lam(const int64_t* __restrict__ ro
 }
 
 // d = dinv .* r / theta ; x = d (zero guess) or x += d
+// (wp != null: 1 / theta is read from device memory instead of the argument)
 __global__ void k_cheb_init(double* __restrict__ x, double* __restrict__ d, const double* __restrict__ r,
-                            const double* __restrict__ dinv, double inv_theta, int zero_guess, int write_d, int64_t n) {
+                            const double* __restrict__ dinv, double inv_theta, int zero_guess, int write_d, int64_t n,
+                            const double* __restrict__ wp = nullptr) {
+  if (wp) inv_theta = *wp;
   NODE_LOOP(i, n) {
     const double di = dinv[i] * r[i] * inv_theta;
     if (write_d) d[i] = di;  // only the multi-step recurrence needs the direction
@@ -299,6 +302,13 @@ __global__ void k_cheb_step(double* __restrict__ x, double* __restrict__ d, doub
     x[i] += di;
   }
 }
+
+static inline double cheb_w(const MgLevel& L, int which) {
+  const double hi = L.lam[which], lo = MG_CHEB_LOWER * hi;
+  return 1.0 / (0.5 * (hi + lo));
+}
+// its device copy (refreshed by mg_setup)
+static inline const double* cheb_wp(const pph_ctx* ctx, int l, int which) { return ctx->mg_w.p + 2 * l + which; }
 
 static inline int mg_grid(int64_t n) {
   int64_t b = ceil_div64(n, 256);
@@ -338,6 +348,9 @@ void mg_release(pph_ctx* ctx) {
     L.x.release(); L.b.release(); L.r.release(); L.d.release(); L.t.release(); L.w.release();
   }
   ctx->mg.clear();
+  ctx->mg_w.release();
+  la_release_graphs(ctx);   // captured iteration bodies hold the hierarchy's pointers
+  ctx->mg_epoch++;
   ctx->mg_ok = false;
   ctx->mg_struct_ok = false;
 }
@@ -534,9 +547,17 @@ int mg_setup(pph_ctx* ctx) {
       }
     }
   }
+  // smoother weights of the fused cycle, read by its kernels from device memory
+  ctx->mg_w_host.resize((size_t)(2 * nlev));
+  for (int l = 0; l < nlev; ++l)
+    for (int f = 0; f < 2; ++f) ctx->mg_w_host[(size_t)(2 * l + f)] = cheb_w(ctx->mg[l], f);
+  PPH_TRY(ctx->mg_w.alloc(ctx, (size_t)(2 * nlev)));
+  PPH_HIP(ctx, hipMemcpyAsync(ctx->mg_w.p, ctx->mg_w_host.data(), sizeof(double) * ctx->mg_w_host.size(),
+                              hipMemcpyHostToDevice, ctx->stream));
   lamdev.release();
   mtmp.release();
   PPH_HIP(ctx, hipGetLastError());
+  if (build) ctx->mg_epoch++;
   ctx->mg_struct_ok = true;
   ctx->mg_ok = true;
   return PPH_OK;
@@ -700,7 +721,7 @@ struct TailLevel {
   const double* dinv;
   const uint8_t* mask;
   int px, py, pz, n;
-  double w;               // 1 / theta of the one-step Chebyshev smoother
+  const double* w;        // 1 / theta of the one-step Chebyshev smoother (device)
 };
 struct TailArgs {
   int nl;
@@ -760,7 +781,8 @@ __global__ __launch_bounds__(1024) void k_mg_tail(TailArgs ta, TStencil ts, int 
   }
   // ---- load: operator row of level 0 into registers, the other operators, the masks and b0 into LDS
   double a0[ST::S];
-  double dv[MG_TAIL_MAX];
+  double dv[MG_TAIL_MAX], wl[MG_TAIL_MAX];
+  for (int l = 0; l < nl; ++l) wl[l] = *ta.L[l].w;
   {
     const TailLevel& F = ta.L[0];
     const bool in = tid < F.n;
@@ -782,7 +804,7 @@ __global__ __launch_bounds__(1024) void k_mg_tail(TailArgs ta, TStencil ts, int 
     const TailLevel& C = ta.L[l + 1];
     const int n = F.n, pxy = F.px * F.py;
     const bool in = tid < n;
-    if (in) X[l][tid] = dv[l] * B[l][tid] * F.w;                 // pre-smoothing from a zero guess
+    if (in) X[l][tid] = dv[l] * B[l][tid] * wl[l];               // pre-smoothing from a zero guess
     __syncthreads();
     if (in) {                                                     // residual
       const double ax = (l == 0) ? tail_row<KIND>(a0, 1, X[l], tid, F.px, pxy, n)
@@ -883,7 +905,7 @@ __global__ __launch_bounds__(1024) void k_mg_tail(TailArgs ta, TStencil ts, int 
     if (in) {                                                     // post-smoothing (la_spmv_jacobi)
       const double at = (l == 0) ? tail_row<KIND>(a0, 1, T[l], tid, F.px, pxy, n)
                                  : tail_row<KIND>(M[l] + tid, n, T[l], tid, F.px, pxy, n);
-      X[l][tid] = T[l][tid] + dv[l] * (B[l][tid] - at) * F.w;
+      X[l][tid] = T[l][tid] + dv[l] * (B[l][tid] - at) * wl[l];
     }
     __syncthreads();
   }
@@ -900,10 +922,7 @@ static size_t mg_tail_lds(const int* n, int nl, int S) {
   return (d + mat) * sizeof(double) + mk;
 }
 
-static inline double cheb_w(const MgLevel& L, int which) {
-  const double hi = L.lam[which], lo = MG_CHEB_LOWER * hi;
-  return 1.0 / (0.5 * (hi + lo));
-}
+
 
 // first level of the tail (nlev: no tail): from there on every level holds a stencil-ELL operator, is not
 // distributed and the levels fit the kernel's limits (rows of the first one, LDS of the others)
@@ -944,22 +963,26 @@ static void mg_vcycle_fused(pph_ctx* ctx, int which, const double* rin, double* 
   const TStencil st = make_transfer_stencil(kind);
   const int lt = mg_tail_begin(ctx, which);
   const int top = (lt < nlev) ? lt : nlev - 1;   // levels [0, top) are swept by full-chip kernels
+  // requests of the calling Krylov loop (see pph_internal.h): zout already pre-smoothed; rin . zout wanted
+  const bool x0_ready = ctx->mg_x0_ready;
+  const int dot_slot = ctx->mg_dot_slot;
+  ctx->mg_x0_ready = false;
   for (int l = 0; l < top; ++l) {
     MgLevel& L = mg[l];
     MgLevel& C = mg[l + 1];
     const double* b = (l == 0) ? rin : L.b.p;
     double* x = (l == 0) ? zout : L.x.p;
     ctx->comm_suspended = L.replicated;
-    if (l == 0)   // coarser levels: done by the restriction that produced their right-hand side
-      hipLaunchKernelGGL(k_cheb_init, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, x, L.d.p, b, L.dinv[which].p,
-                         cheb_w(L, which), 1, 0, L.n);
+    if (l == 0 && !x0_ready)   // coarser levels: done by the restriction that produced their right-hand side
+      hipLaunchKernelGGL(k_cheb_init, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, x, L.d.p, b, L.dinv[which].p, 0.0,
+                         1, 0, L.n, cheb_wp(ctx, l, which));
     la_spmv_resid(ctx, level_csr(ctx, L, which), x, b, L.r.p);
     if (dist && !L.replicated) (void)la_halo(ctx, *L.geom, L.r.p);
     // the coarse level's pre-smoothing rides along unless the tail kernel (or the coarsest solve) does it itself
     const bool init_c = (l + 1 < top);
     double* xc = init_c ? C.x.p : nullptr;
     const double* dc = init_c ? C.dinv[which].p : nullptr;
-    const double wc = init_c ? cheb_w(C, which) : 0.0;
+    const double* wc = init_c ? cheb_wp(ctx, l + 1, which) : nullptr;
     const bool sum_c = dist && C.replicated && !L.replicated;   // partial right-hand sides are summed first
     if (sum_c) { xc = nullptr; }
     if (kind == PPH_CELL_HEX)
@@ -975,7 +998,7 @@ static void mg_vcycle_fused(pph_ctx* ctx, int which, const double* rin, double* 
       (void)la_allreduce_vec(ctx, C.b.p, C.n);
       if (init_c)
         hipLaunchKernelGGL(k_cheb_init, dim3(mg_grid(C.n)), dim3(256), 0, ctx->stream, C.x.p, C.d.p, C.b.p,
-                           C.dinv[which].p, cheb_w(C, which), 1, 0, C.n);
+                           C.dinv[which].p, 0.0, 1, 0, C.n, cheb_wp(ctx, l + 1, which));
     }
   }
   if (lt < nlev) {
@@ -987,7 +1010,7 @@ static void mg_vcycle_fused(pph_ctx* ctx, int which, const double* rin, double* 
       TailLevel& T = ta.L[q];
       T.A = L.ell[which].val; T.ld = L.ell[which].ld; T.dinv = L.dinv[which].p; T.mask = L.maskp[which];
       T.px = L.px; T.py = L.py; T.pz = L.pz; T.n = (int)L.n;
-      T.w = cheb_w(L, which);
+      T.w = cheb_wp(ctx, lt + q, which);
       ns[q] = (int)L.n;
     }
     ta.b0 = mg[lt].b.p;
@@ -1032,13 +1055,34 @@ static void mg_vcycle_fused(pph_ctx* ctx, int which, const double* rin, double* 
       hipLaunchKernelGGL(k_prolong_to<1>, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, L.t.p, x, C.x.p, L.maskp[which], tg);
     else
       hipLaunchKernelGGL(k_prolong_to<2>, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, L.t.p, x, C.x.p, L.maskp[which], tg);
-    la_spmv_jacobi(ctx, level_csr(ctx, L, which), L.t.p, b, L.dinv[which].p, cheb_w(L, which), x);
+    if (l == 0 && dot_slot >= 0) {
+      la_spmv_jacobi(ctx, level_csr(ctx, L, which), L.t.p, b, L.dinv[which].p, cheb_wp(ctx, l, which), x, dot_slot,
+                     ctx->mg_dot_seg.off1, ctx->mg_dot_seg.off1 + ctx->mg_dot_seg.len1);
+      ctx->mg_dot_slot = -2;   // delivered
+    } else {
+      la_spmv_jacobi(ctx, level_csr(ctx, L, which), L.t.p, b, L.dinv[which].p, cheb_wp(ctx, l, which), x);
+    }
   }
   ctx->comm_suspended = false;
 }
 
+// the pre-smoothing the fused cycle starts with on the fine level: z0 = dinv .* r * w (false: the cycle is not the
+// fused one, nothing to offer)
+bool mg_pre_smoother(pph_ctx* ctx, int which, int nsmooth, const double** dinv, const double** w, bool* launch_only) {
+  if (!ctx->mg_ok || !mg_can_fuse(ctx, which, nsmooth)) return false;
+  *dinv = ctx->mg[0].dinv[which].p;
+  *w = cheb_wp(ctx, 0, which);
+  // the cycle consists of kernel launches only (capturable into a graph) unless its coarsest solve is host-driven
+  const MgLevel& C = ctx->mg.back();
+  const int nlev = (int)ctx->mg.size();
+  *launch_only = mg_tail_begin(ctx, which) < nlev ||
+                 ((ctx->world == 1 || C.replicated) && C.n <= 4096 && ctx->coarse_on_device);
+  return true;
+}
+
 void mg_vcycle(pph_ctx* ctx, int which, const double* rin, double* zout, int nsmooth) {
   if (mg_can_fuse(ctx, which, nsmooth)) { mg_vcycle_fused(ctx, which, rin, zout); return; }
+  ctx->mg_x0_ready = false;   // the general cycle offers neither by-product (mg_dot_slot stays undelivered)
   std::vector<MgLevel>& mg = ctx->mg;
   const int nlev = (int)mg.size();
   const TStencil st = make_transfer_stencil(ctx->mesh.kind);
@@ -1060,13 +1104,13 @@ void mg_vcycle(pph_ctx* ctx, int which, const double* rin, double* zout, int nsm
     if (dist && !L.replicated) (void)la_halo(ctx, *L.geom, L.r.p);  // restriction reads one fine plane beyond the owned ones
     if (ctx->mesh.kind == PPH_CELL_HEX)
       hipLaunchKernelGGL(k_restrict_q1<3>, dim3(mg_grid(C.n)), dim3(256), 0, ctx->stream, C.b.p, L.r.p, C.maskp[which],
-                         L.maskp[which], tgeom(L, C), (double*)nullptr, (const double*)nullptr, 0.0);
+                         L.maskp[which], tgeom(L, C), (double*)nullptr, (const double*)nullptr, (const double*)nullptr);
     else if (ctx->mesh.kind == PPH_CELL_QUAD)
       hipLaunchKernelGGL(k_restrict_q1<2>, dim3(mg_grid(C.n)), dim3(256), 0, ctx->stream, C.b.p, L.r.p, C.maskp[which],
-                         L.maskp[which], tgeom(L, C), (double*)nullptr, (const double*)nullptr, 0.0);
+                         L.maskp[which], tgeom(L, C), (double*)nullptr, (const double*)nullptr, (const double*)nullptr);
     else
       hipLaunchKernelGGL(k_restrict, dim3(mg_grid(C.n)), dim3(256), 0, ctx->stream, C.b.p, L.r.p, st, C.maskp[which],
-                         L.maskp[which], tgeom(L, C), (double*)nullptr, (const double*)nullptr, 0.0);
+                         L.maskp[which], tgeom(L, C), (double*)nullptr, (const double*)nullptr, (const double*)nullptr);
     if (dist && C.replicated && !L.replicated) (void)la_allreduce_vec(ctx, C.b.p, C.n);
   }
   // coarsest level: Jacobi-CG to 1e-12 (a handful of unknowns)

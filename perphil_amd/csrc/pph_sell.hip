@@ -20,13 +20,15 @@ __device__ inline double sell_wave_sum(double v) {
 
 // MODE 0: y = A x      1: y = b - A x      2: y = A x and per-workgroup partial sums of x.y
 // MODE 3: y = x + w * dinv .* (b - A x)   (one damped-Jacobi / one-step Chebyshev sweep, out of place)
+// MODE 4: MODE 3 and the dot product b . y over the rows [dlo, dhi) (CG: r . z from the last kernel of the V-cycle)
+// MODE 2 / 4 write one partial sum per workgroup to part[blockIdx.x]; the caller finishes the sum.
 // One thread owns RPT consecutive rows; a workgroup a chunk of 256 RPT rows.  Chunks are dealt to the XCDs in groups
 // of `group` consecutive chunks (group 1 = plain grid-stride order); workgroups with equal blockIdx % 8 share an XCD.
 template <int KIND, int MODE, int RPT, bool CLAMP>
 __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_t ld, const double* __restrict__ x,
                                           const double* __restrict__ b, const double* __restrict__ dinv, double w,
                                           double* __restrict__ y, int64_t n, int px, int64_t pxy, int64_t r0,
-                                          double& dotacc) {
+                                          double& dotacc, int64_t dlo, int64_t dhi) {
   using ST = SellSt<KIND>;
   double acc[RPT];
   double bv[RPT], xr[RPT], dv[RPT];
@@ -37,9 +39,9 @@ __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_
     act[i] = !CLAMP || (r0 + i < n);
     // operands of the epilogue are requested before the matrix stream, not after the sums
     if (act[i]) {
-      if (MODE == 1 || MODE == 3) bv[i] = b[r0 + i];
-      if (MODE == 2 || MODE == 3) xr[i] = x[r0 + i];
-      if (MODE == 3) dv[i] = dinv[r0 + i];
+      if (MODE == 1 || MODE >= 3) bv[i] = b[r0 + i];
+      if (MODE >= 2) xr[i] = x[r0 + i];
+      if (MODE >= 3) dv[i] = dinv[r0 + i];
     }
   }
   int slot = 0;
@@ -93,18 +95,25 @@ __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_
     if (MODE == 0) y[r] = acc[i];
     else if (MODE == 1) y[r] = bv[i] - acc[i];
     else if (MODE == 2) { y[r] = acc[i]; dotacc += acc[i] * xr[i]; }
-    else y[r] = xr[i] + dv[i] * (bv[i] - acc[i]) * w;   // the order of k_cheb_init: dinv * r / theta
+    else {
+      const double yn = xr[i] + dv[i] * (bv[i] - acc[i]) * w;   // the order of k_cheb_init: dinv * r / theta
+      y[r] = yn;
+      if (MODE == 4 && r >= dlo && r < dhi) dotacc += bv[i] * yn;
+    }
   }
 }
 
 template <int KIND, int MODE, int RPT>
 __global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ val, int64_t ld,
                                                    const double* __restrict__ x, const double* __restrict__ b,
-                                                   const double* __restrict__ dinv, double w, double* __restrict__ y,
-                                                   int64_t n, int px, int64_t pxy, int64_t halo, int64_t nchunks,
-                                                   int group, double* __restrict__ part) {
+                                                   const double* __restrict__ dinv, const double* __restrict__ wp,
+                                                   double* __restrict__ y, int64_t n, int px, int64_t pxy, int64_t halo,
+                                                   int64_t nchunks,
+                                                   int group, double* __restrict__ part, int64_t dlo, int64_t dhi) {
   constexpr int CH = 256 * RPT;
   const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, bpx = gridDim.x >> 3;   // launcher keeps gridDim.x a multiple of 8
+  // the smoother weight lives in device memory (refreshed per assembly) so that captured graphs survive a re-assembly
+  const double w = (MODE >= 3) ? *wp : 0.0;
   double dotacc = 0.0;
   for (int64_t q = bx;; q += bpx) {
     const int64_t base = ((q / group) * 8 + xcd) * (int64_t)group;
@@ -116,11 +125,11 @@ __global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ va
     // a chunk whose rows and x window lie inside [0, n) needs no index clamps and no row masks (all but the first
     // and last few chunks)
     if (c0 >= halo && c0 + CH + halo <= n)
-      sell_rows<KIND, MODE, RPT, false>(val, ld, x, b, dinv, w, y, n, px, pxy, r0, dotacc);
+      sell_rows<KIND, MODE, RPT, false>(val, ld, x, b, dinv, w, y, n, px, pxy, r0, dotacc, dlo, dhi);
     else
-      sell_rows<KIND, MODE, RPT, true>(val, ld, x, b, dinv, w, y, n, px, pxy, r0, dotacc);
+      sell_rows<KIND, MODE, RPT, true>(val, ld, x, b, dinv, w, y, n, px, pxy, r0, dotacc, dlo, dhi);
   }
-  if (MODE == 2) {
+  if (MODE == 2 || MODE == 4) {
     __shared__ double lds[4];
     dotacc = sell_wave_sum(dotacc);
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = dotacc;
@@ -131,35 +140,37 @@ __global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ va
 
 template <int KIND, int RPT>
 static void sell_launch_mode(pph_ctx* ctx, int mode, int grid, const Sell& E, const double* x, const double* b,
-                             const double* dinv, double w, double* y, int64_t n, int64_t nchunks, int group,
-                             double* part) {
+                             const double* dinv, const double* w, double* y, int64_t n, int64_t nchunks, int group,
+                             double* part, int64_t dlo, int64_t dhi) {
   const int64_t pxy = (int64_t)E.px * E.py;
   const int64_t halo = (E.pz > 1 ? pxy : 0) + E.px + 2;   // reach of the x window of a row (2D: no z lines)
 #define PPH_SELL_GO(MM)                                                                                              \
   hipLaunchKernelGGL((k_spmv_sell<KIND, MM, RPT>), dim3(grid), dim3(256), 0, ctx->stream, E.val, E.ld, x, b, dinv, w, \
-                     y, n, E.px, pxy, halo, nchunks, group, part)
+                     y, n, E.px, pxy, halo, nchunks, group, part, dlo, dhi)
   switch (mode) {
     case 0: PPH_SELL_GO(0); break;
     case 1: PPH_SELL_GO(1); break;
     case 2: PPH_SELL_GO(2); break;
-    default: PPH_SELL_GO(3); break;
+    case 3: PPH_SELL_GO(3); break;
+    default: PPH_SELL_GO(4); break;
   }
 #undef PPH_SELL_GO
 }
 
 // launches the product; returns the grid (= number of partial sums written in mode 2)
 int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x, const double* b, const double* dinv,
-              double w, double* y, double* part) {
+              const double* w, double* y, double* part, int64_t dlo, int64_t dhi) {
   const int rpt = (ctx->sell_rpt == 1) ? 1 : 2;
   const int64_t nchunks = ceil_div64(n, 256 * rpt);
-  const int cap = (ctx->sell_blocks >= 8 && ctx->sell_blocks <= 8192) ? (ctx->sell_blocks / 8) * 8 : 2048;
+  int cap = (ctx->sell_blocks >= 8 && ctx->sell_blocks <= 8192) ? (ctx->sell_blocks / 8) * 8 : 2048;
+  if ((mode == 2 || mode == 4) && cap > 2048) cap = 2048;   // one partial sum per workgroup (PART_STRIDE of pph_la.hip)
   int64_t g = nchunks < cap ? nchunks : cap;
   g = ((g + 7) / 8) * 8;
   const int grid = (int)g;
   int group = ctx->sell_group > 0 ? ctx->sell_group : 1;
 #define PPH_SELL_KIND(KK)                                                                                     \
-  if (rpt == 1) sell_launch_mode<KK, 1>(ctx, mode, grid, E, x, b, dinv, w, y, n, nchunks, group, part);        \
-  else sell_launch_mode<KK, 2>(ctx, mode, grid, E, x, b, dinv, w, y, n, nchunks, group, part)
+  if (rpt == 1) sell_launch_mode<KK, 1>(ctx, mode, grid, E, x, b, dinv, w, y, n, nchunks, group, part, dlo, dhi); \
+  else sell_launch_mode<KK, 2>(ctx, mode, grid, E, x, b, dinv, w, y, n, nchunks, group, part, dlo, dhi)
   switch (E.kind) {
     case PPH_CELL_QUAD: PPH_SELL_KIND(PPH_CELL_QUAD); break;
     case PPH_CELL_TRI: PPH_SELL_KIND(PPH_CELL_TRI); break;

@@ -75,10 +75,19 @@ static Csr mono_csr(pph_ctx* ctx) {
 // none.  Tolerance: max(rtol * ||b||_2, atol, reduction * ||r_0||_2).  `bnorm_hint` is ||b||_2 of an
 // earlier, nearby system (see cg_solve).
 // ------------------------------------------------------------------------------------------------
+// by-products the fused multigrid cycle offers to the CG around it (mg_pre_smoother / pph_internal.h)
+struct MgPre {
+  bool on = false;
+  const double* dinv = nullptr;   // z0 = dinv .* r * w is the cycle's first kernel: the CG update writes it instead
+  const double* w = nullptr;      // (device)
+  int tag = 0;                    // identifies the preconditioner (block, smoothing steps) in the graph cache
+  bool launch_only = false;       // the cycle enqueues kernels only (no host decision inside): capturable
+};
+
 static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double* x, const double* dinv, const ApplyFn& pc,
                             double rtol, double atol, int max_it, bool warm, double* r, double* z, double* p, double* q,
                             int slot, KspOut* out, double* hist, int hist_cap, double bnorm_hint, double reduction,
-                            const double* r_init) {
+                            const double* r_init, const MgPre& pre) {
   const int64_t n = A.nrows;
   const Seg sg = pph_owned_seg(A.geom, n);
   auto apply_pc = [&](const double* in, double* o) {
@@ -113,29 +122,67 @@ static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double*
   if (la_device_scalars(ctx)) {
     // alpha and beta live in ctx->scal: the host sees p.Ap (breakdown test) and r.r (convergence test) once per
     // iteration, in one copy
-    const int sPQ = slot, sRR = slot + 1;
-    int sRZ[2] = {slot + 2, slot + 3};
-    apply_pc(r, p);                                   // first direction p = z_0: written in place
-    la_mdot_seg(ctx, r, 0, 1, p, sg, sRZ[0]);
-    PPH_TRY(la_reduce_device(ctx, sRZ[0], 1));
+    const int sPQ = slot, sRR = slot + 1, sRZn = slot + 2, sRZc = slot + 3;   // p.Ap, r.r, r.z (new), r.z (current)
+    // z = M^-1 r and r.z -> scal[slot_rz]; a fused multigrid cycle delivers the dot product from its last kernel
+    auto pc_and_rz = [&](double* zz, int slot_rz, bool x0_ready) {
+      if (pre.on) { ctx->mg_dot_slot = slot_rz; ctx->mg_dot_seg = sg; ctx->mg_x0_ready = x0_ready; }
+      apply_pc(r, zz);
+      const bool delivered = ctx->mg_dot_slot == -2;
+      ctx->mg_dot_slot = -1;
+      ctx->mg_x0_ready = false;
+      if (!delivered) la_mdot_seg(ctx, r, 0, 1, zz, sg, slot_rz);
+    };
+    // the two halves of an iteration around the host's convergence test.  `rotate`: r.z (current) := r.z (new) rides
+    // on the final reduction of p.Ap - after the direction update read both, before the CG update reads the current one
+    auto half_product = [&](bool rotate) -> int {
+      la_spmv_dot(ctx, A, p, q, sPQ, rotate ? sRZn : -1, sRZc);
+      PPH_TRY(la_reduce_device(ctx, sPQ, 1));
+      // x += alpha p ; r -= alpha q ; r.r (and the next cycle's pre-smoothed first guess into z)
+      la_cg_update_dev(ctx, x, r, p, q, sRZc, sPQ, n, sRR, sg, pre.on ? z : nullptr, pre.dinv, pre.w);
+      PPH_TRY(la_reduce_device(ctx, sRR, 1));
+      return PPH_OK;
+    };
+    auto half_direction = [&]() -> int {
+      pc_and_rz(z, sRZn, pre.on);
+      PPH_TRY(la_reduce_device(ctx, sRZn, 1));
+      la_p_update_dev(ctx, p, z, sRZn, sRZc, n);                          // p = z + (r.z_new / r.z) p
+      return PPH_OK;
+    };
+    pc_and_rz(p, sRZc, false);                        // first direction p = z_0: written in place
+    PPH_TRY(la_reduce_device(ctx, sRZc, 1));
+    // Iterations after the first are one hipGraph each (direction half, product half, publication of p.Ap and r.r):
+    // on small meshes the kernels are shorter than the 3.5 us the host needs to enqueue one, so an eager iteration
+    // is host-bound; the captured body replays in one call.  Single context, fused multigrid cycle only.
+    GraphKey gk;
+    const bool graphable = ctx->use_graphs && pre.on && pre.launch_only && ctx->world == 1 && !ctx->time_spmv && ctx->fetch_spin;
+    if (graphable) {
+      gk.p[0] = A.ell.val ? (const void*)A.ell.val : (const void*)A.val; gk.p[1] = x; gk.p[2] = r; gk.p[3] = z; gk.p[4] = p;
+      gk.p[5] = q; gk.p[6] = pre.dinv; gk.p[7] = pre.w;
+      gk.n = n; gk.slot = slot; gk.epoch = ctx->mg_epoch; gk.tag = pre.tag;
+    }
     int its = 0;
     while (its < max_it) {
-      la_spmv_dot(ctx, A, p, q, sPQ);
-      PPH_TRY(la_reduce_device(ctx, sPQ, 1));
-      la_cg_update_dev(ctx, x, r, p, q, sRZ[0], sPQ, n, sRR, sg);        // x += alpha p ; r -= alpha q ; r.r
-      PPH_TRY(la_reduce_device(ctx, sRR, 1));
-      PPH_TRY(la_fetch_raw(ctx, sPQ, 2));
+      if (its == 0) {
+        PPH_TRY(half_product(false));
+        PPH_TRY(la_fetch_raw(ctx, sPQ, 2));
+      } else {
+        auto body = [&]() -> int {
+          PPH_TRY(half_direction());
+          PPH_TRY(half_product(true));
+          la_publish(ctx, sPQ, 2);
+          return PPH_OK;
+        };
+        if (graphable) PPH_TRY(la_run_graph(ctx, gk, body));
+        else PPH_TRY(body());
+        PPH_TRY(la_wait_published(ctx));
+        if (ctx->comm_status != PPH_OK) { ctx->err = ctx->comm_error; return ctx->comm_status; }
+      }
       const double pq = ctx->h_scal[sPQ];
       res = std::sqrt(ctx->h_scal[sRR]);
       ++its;
       if (hist && its < hist_cap) hist[its] = res;
       if (!(pq > 0.0) || !(res == res)) { out->breakdown = true; break; }
       if (res <= tol) { out->converged = true; break; }
-      apply_pc(r, z);
-      la_mdot_seg(ctx, r, 0, 1, z, sg, sRZ[1]);
-      PPH_TRY(la_reduce_device(ctx, sRZ[1], 1));
-      la_p_update_dev(ctx, p, z, sRZ[1], sRZ[0], n);                      // p = z + (r.z_new / r.z) p
-      std::swap(sRZ[0], sRZ[1]);
     }
     out->its = its;
     out->res = res;
@@ -175,11 +222,12 @@ static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double*
 static int cg_solve(pph_ctx* ctx, const Csr& A, const double* b, double* x, const double* dinv, const ApplyFn& pc,
                     double rtol, double atol, int max_it, bool warm, double* r, double* z, double* p, double* q,
                     int slot, KspOut* out, double* hist, int hist_cap, double bnorm_hint = -1.0,
-                    double reduction = 0.0, const double* r_init = nullptr, int norm_type = 0) {
+                    double reduction = 0.0, const double* r_init = nullptr, int norm_type = 0,
+                    const MgPre& pre = MgPre()) {
   const int64_t n = A.nrows;
   if (norm_type == 1)
     return cg_solve_natural(ctx, A, b, x, dinv, pc, rtol, atol, max_it, warm, r, z, p, q, slot, out, hist, hist_cap,
-                            bnorm_hint, reduction, r_init);
+                            bnorm_hint, reduction, r_init, pre);
   // reductions run over the owned entries of a slab (whole vector on a single GPU)
   const Seg sg = pph_owned_seg(A.geom, n);
   const bool fused = (dinv != nullptr) || !pc;
@@ -446,9 +494,12 @@ struct BlockSolver {
       else la_copy(ctx, z, rhs, n);
       return PPH_OK;
     }
+    MgPre pre;
+    if (cfg->inner_pc_type == PPH_PC_MG) pre.on = mg_pre_smoother(ctx, which, ns, &pre.dinv, &pre.w, &pre.launch_only);
+    pre.tag = 16 * ns + which;
     PPH_TRY(cg_solve(ctx, A[which], rhs, z, dinv[which], pc, cfg->inner_rtol, cfg->inner_atol, cfg->inner_max_it,
                      warm, r, zz, p, q, S_INNER, &ko, nullptr, 0, warm ? bnorm_cache[which] : -1.0,
-                     cfg->inner_reduction, warm ? r_init : nullptr, cfg->inner_norm));
+                     cfg->inner_reduction, warm ? r_init : nullptr, cfg->inner_norm, pre));
     if (!warm) bnorm_cache[which] = ko.bnorm;
     last_resid = r;
     total_its += ko.its;
