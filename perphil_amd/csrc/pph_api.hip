@@ -526,6 +526,7 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
   if (!strcmp(name, "sell_rpt")) { ctx->sell_rpt = (int)value; return PPH_OK; }
   if (!strcmp(name, "sell_blocks")) { ctx->sell_blocks = (int)value; return PPH_OK; }
   if (!strcmp(name, "sell_group")) { ctx->sell_group = (int)value; return PPH_OK; }
+  if (!strcmp(name, "asm_tile")) { ctx->asm_tile = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "asm_fused")) { ctx->asm_fused = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "asm_ring")) { ctx->asm_ring = value > 0.0 ? (int)value : 0; return PPH_OK; }
   if (!strcmp(name, "asm_keep_km")) { ctx->asm_keep_km = value != 0.0 ? 1 : 0; return PPH_OK; }

@@ -1460,6 +1460,323 @@ int pph_launch_blocks(pph_ctx* ctx, int monolithic) {
   return blocks_mono(ctx, monolithic);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Single-pass fused assembly for multilinear cells ("tile" kernel, default): no element-row buffer at all.
+//
+// A workgroup owns a tile of TX x TY x TZ nodes (8 x 4 x 2 hexahedral, 16 x 8 quadrilateral nodes).
+//   A. lane (cell, q) over the (TX+1)(TY+1)(TZ+1) cells touching the tile: Jacobian at Gauss point q from the cell's
+//      vertex coordinates (staged in LDS), its inverse, and the GEOMETRY FACTOR D_q = |det J| J^-1 J^-T (symmetric
+//      DIM x DIM) + the weight |det J| -> LDS (7 doubles per (cell, q) instead of the 8 x 8 x 3 physical gradients);
+//   B. lane (node, corner c) forms row c of K_e and M_e of the node's incident cell c from the factors:
+//      K_e[a][b] = sum_q dN_q[a]^T D_q dN_q[b],  M_e[a][b] = sum_q |det J_q| N_q[a] N_q[b]
+//      with the reference gradients of the column vertices as compile-time constants (the row vertex's from a table);
+//      rows -> LDS (over the factors, which are dead by then);
+//   C. the 2^d lanes of a node sum, slot by slot of the node's stencil row and in a fixed order, the entries of the
+//      incident cells' rows that belong to the slot's column, and apply the fused epilogue of k_gather_rows
+//      (Dirichlet elimination, DPP blocks, lifting, 1 / a_ii, spectral bound) before the only global stores.
+// Every element row is formed exactly once (by the lane that consumes it); the Jacobian work is repeated for the
+// cells on tile faces (2.1 evaluations per cell on average instead of 1), which is what removing the 17 GB
+// element-row round trip of the two-pass kernels costs.  Deterministic, no atomics.  Vertices are addressed in
+// closed form (vertex v of cell (ci,cj,ck) = node (ci + v&1, cj + (v>>1)&1, ck + (v>>2)&1), the cell->dof map of
+// k_dofmap); the two-pass kernels (asm_tile 0) read the map itself.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr double tile_fac(int bbit, int qbit) {   // 0.5 (1 + s_b xi_q), xi = +-1/sqrt(3)
+  return (bbit == qbit) ? 0.78867513459481288225 : 0.21132486540518711775;
+}
+template <int DIM>
+__host__ __device__ constexpr double tile_N(int q, int b) {
+  double v = 1.0;
+  for (int f = 0; f < DIM; ++f) v *= tile_fac((b >> f) & 1, (q >> f) & 1);
+  return v;
+}
+template <int DIM>
+__host__ __device__ constexpr double tile_dN(int q, int b, int e) {
+  double v = ((b >> e) & 1) ? 0.5 : -0.5;
+  for (int f = 0; f < DIM; ++f)
+    if (f != e) v *= tile_fac((b >> f) & 1, (q >> f) & 1);
+  return v;
+}
+
+template <int DIM> struct TileGeo;
+template <> struct TileGeo<3> { static constexpr int TX = 8, TY = 4, TZ = 2; };
+template <> struct TileGeo<2> { static constexpr int TX = 16, TY = 8, TZ = 1; };
+
+template <int DIM>
+__global__ __launch_bounds__(512) void k_asm_tile(const double* __restrict__ cx, const double* __restrict__ cy,
+                                                  const double* __restrict__ cz, const int64_t* __restrict__ rowptr,
+                                                  double* __restrict__ K, double* __restrict__ M, int nx, int ny, int nzl,
+                                                  int px, int py, int pz, int64_t n, FuseArgs fa) {
+  using TG = TileGeo<DIM>;
+  constexpr int NB = 1 << DIM;
+  constexpr int TX = TG::TX, TY = TG::TY, TZ = TG::TZ;
+  constexpr int NT = TX * TY * TZ;                       // nodes of a tile (64 / 128)
+  constexpr int CX = TX + 1, CY = TY + 1, CZ = (DIM == 3) ? TZ + 1 : 1;
+  constexpr int NC = CX * CY * CZ;                       // cells touching the tile (135 / 153)
+  constexpr int VX = TX + 2, VY = TY + 2, VZ = (DIM == 3) ? TZ + 2 : 1;
+  constexpr int NV = VX * VY * VZ;                       // their vertices (240 / 180)
+  constexpr int ND = DIM * (DIM + 1) / 2 + 1;            // doubles per (cell, q): packed symmetric D and |det J|
+  constexpr int DSTR = NB * ND + 1;                      // cell stride of the factors (+1: off the bank period)
+  constexpr int RSTR = NB + 1;                           // row stride of the element rows
+  static_assert(NT * NB == 512, "one lane per (node, corner)");
+  // one LDS region, two lives: vertex coordinates + geometry factors (phases A, B), then the element rows K | M
+  // (phase C) - 74 KB for hexahedra, so that two workgroups share a CU
+  constexpr int NAB = NC * DSTR + NV * DIM;
+  constexpr int NUNI = (NAB > 2 * NT * NB * RSTR) ? NAB : 2 * NT * NB * RSTR;
+  __shared__ double sU[NUNI];
+  double (*const sXv)[DIM] = reinterpret_cast<double (*)[DIM]>(sU + NC * DSTR);
+  __shared__ double sdN[NB][NB][DIM];
+  __shared__ double sNq[NB][NB];
+  __shared__ uint8_t sOK[NT][NB];
+  double* const sD = sU;
+  double* const sK = sU;
+  double* const sM = sU + NT * NB * RSTR;
+  const int tid = threadIdx.x;
+  if (tid < NB * NB) {
+    const int q = tid / NB, b = tid % NB;
+    double nv = 1.0;
+#pragma unroll
+    for (int f = 0; f < DIM; ++f) nv *= tile_fac((b >> f) & 1, (q >> f) & 1);
+    sNq[q][b] = nv;
+#pragma unroll
+    for (int e = 0; e < DIM; ++e) {
+      double d = ((b >> e) & 1) ? 0.5 : -0.5;
+#pragma unroll
+      for (int f = 0; f < DIM; ++f)
+        if (f != e) d *= tile_fac((b >> f) & 1, (q >> f) & 1);
+      sdN[q][b][e] = d;
+    }
+  }
+  const int tiles_x = (px + TX - 1) / TX, tiles_y = (py + TY - 1) / TY, tiles_z = (DIM == 3) ? (pz + TZ - 1) / TZ : 1;
+  const int64_t ntiles = (int64_t)tiles_x * tiles_y * tiles_z;
+  const int64_t pxy = (int64_t)px * py;
+  // this lane's node and corner inside the tile: consecutive lanes = the corners of one node, then the next node in x
+  const int ln = tid / NB, c = tid % NB;
+  const int lx = ln % TX, ly = (ln / TX) % TY, lz = ln / (TX * TY);
+  double best1 = 0.0, best2 = 0.0;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tx = (int)(tile % tiles_x);
+    const int64_t tt = tile / tiles_x;
+    const int ty = (int)(tt % tiles_y), tz = (int)(tt / tiles_y);
+    const int i0 = tx * TX, j0 = ty * TY, k0 = tz * TZ;
+    __syncthreads();   // previous tile's rows are consumed
+    // ---- vertices of the tile's cells: nodes (i0-1 .. i0+TX, j0-1 .. j0+TY, k0-1 .. k0+TZ), clamped into the box
+    for (int v = tid; v < NV; v += 512) {
+      const int vx = v % VX, vy = (v / VX) % VY, vz = v / (VX * VY);
+      int gi = i0 - 1 + vx, gj = j0 - 1 + vy, gk = (DIM == 3) ? k0 - 1 + vz : 0;
+      gi = gi < 0 ? 0 : (gi > px - 1 ? px - 1 : gi);
+      gj = gj < 0 ? 0 : (gj > py - 1 ? py - 1 : gj);
+      gk = gk < 0 ? 0 : (gk > pz - 1 ? pz - 1 : gk);
+      const int64_t g = gi + (int64_t)px * gj + pxy * gk;
+      sXv[v][0] = cx[g];
+      sXv[v][1] = cy[g];
+      if constexpr (DIM == 3) sXv[v][2] = cz[g];
+    }
+    __syncthreads();
+    // ---- A: geometry factors, lane (cell, q)
+    for (int task = tid; task < NC * NB; task += 512) {
+      const int cl = task / NB, q = task % NB;
+      const int ccx = cl % CX, ccy = (cl / CX) % CY, ccz = cl / (CX * CY);
+      const int gi = i0 - 1 + ccx, gj = j0 - 1 + ccy, gk = (DIM == 3) ? k0 - 1 + ccz : 0;
+      const bool incell = gi >= 0 && gi < nx && gj >= 0 && gj < ny && (DIM == 2 || (gk >= 0 && gk < nzl));
+      if (!incell) continue;
+      double J[DIM][DIM];
+#pragma unroll
+      for (int e = 0; e < DIM; ++e)
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) J[e][d] = 0.0;
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int v = (ccx + (b & 1)) + VX * ((ccy + ((b >> 1) & 1)) + VY * ((DIM == 3) ? ccz + ((b >> 2) & 1) : 0));
+#pragma unroll
+        for (int e = 0; e < DIM; ++e)
+#pragma unroll
+          for (int d = 0; d < DIM; ++d) J[e][d] += sdN[q][b][e] * sXv[v][d];
+      }
+      double* out = sD + cl * DSTR + q * ND;
+      if constexpr (DIM == 2) {
+        const double det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+        const double r = 1.0 / det;
+        // I = J^-1 in the convention of k_elem_rows: g[b][d] = sum_e I[d][e] dN[b][e]
+        const double I00 = J[1][1] * r, I01 = -J[0][1] * r, I10 = -J[1][0] * r, I11 = J[0][0] * r;
+        const double w = fabs(det);
+        out[0] = w * (I00 * I00 + I10 * I10);
+        out[1] = w * (I00 * I01 + I10 * I11);
+        out[2] = w * (I01 * I01 + I11 * I11);
+        out[3] = w;
+      } else {
+        const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+        const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+        const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+        const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+        const double r = 1.0 / det;
+        double I[3][3];
+        I[0][0] = c00 * r;
+        I[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
+        I[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
+        I[1][0] = c01 * r;
+        I[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
+        I[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
+        I[2][0] = c02 * r;
+        I[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
+        I[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
+        const double w = fabs(det);
+        // D[e][f] = w sum_d I[d][e] I[d][f], packed 00 01 02 11 12 22
+        out[0] = w * (I[0][0] * I[0][0] + I[1][0] * I[1][0] + I[2][0] * I[2][0]);
+        out[1] = w * (I[0][0] * I[0][1] + I[1][0] * I[1][1] + I[2][0] * I[2][1]);
+        out[2] = w * (I[0][0] * I[0][2] + I[1][0] * I[1][2] + I[2][0] * I[2][2]);
+        out[3] = w * (I[0][1] * I[0][1] + I[1][1] * I[1][1] + I[2][1] * I[2][1]);
+        out[4] = w * (I[0][1] * I[0][2] + I[1][1] * I[1][2] + I[2][1] * I[2][2]);
+        out[5] = w * (I[0][2] * I[0][2] + I[1][2] * I[1][2] + I[2][2] * I[2][2]);
+        out[6] = w;
+      }
+    }
+    __syncthreads();
+    // ---- B: row c of the incident cell c of this lane's node
+    const int gi = i0 + lx, gj = j0 + ly, gk = (DIM == 3) ? k0 + lz : 0;
+    const bool innode = gi < px && gj < py && gk < pz;
+    const int64_t node = gi + (int64_t)px * gj + pxy * gk;
+    double Kr[NB], Mr[NB];
+    bool rowok = false;
+    {
+      const int ci = gi - (c & 1), cj = gj - ((c >> 1) & 1), ck = (DIM == 3) ? gk - ((c >> 2) & 1) : 0;
+      rowok = innode && ci >= 0 && ci < nx && cj >= 0 && cj < ny && (DIM == 2 || (ck >= 0 && ck < nzl));
+#pragma unroll
+      for (int b = 0; b < NB; ++b) { Kr[b] = 0.0; Mr[b] = 0.0; }
+      if (rowok) {
+        const int cl = (ci - (i0 - 1)) + CX * ((cj - (j0 - 1)) + CY * ((DIM == 3) ? ck - (k0 - 1) : 0));
+        const double* dc = sD + cl * DSTR;
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+          const double* dq = dc + q * ND;
+          double t[DIM];
+          if constexpr (DIM == 2) {
+            const double g0 = sdN[q][c][0], g1 = sdN[q][c][1];
+            t[0] = g0 * dq[0] + g1 * dq[1];
+            t[1] = g0 * dq[1] + g1 * dq[2];
+          } else {
+            const double g0 = sdN[q][c][0], g1 = sdN[q][c][1], g2 = sdN[q][c][2];
+            t[0] = g0 * dq[0] + g1 * dq[1] + g2 * dq[2];
+            t[1] = g0 * dq[1] + g1 * dq[3] + g2 * dq[4];
+            t[2] = g0 * dq[2] + g1 * dq[4] + g2 * dq[5];
+          }
+          const double sw = dq[ND - 1] * sNq[q][c];
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            double kb = Kr[b];
+#pragma unroll
+            for (int e = 0; e < DIM; ++e) kb += t[e] * tile_dN<DIM>(q, b, e);
+            Kr[b] = kb;
+            Mr[b] += sw * tile_N<DIM>(q, b);
+          }
+        }
+      }
+    }
+    __syncthreads();   // every lane has read its factors: the rows may overwrite them
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      sK[(ln * NB + c) * RSTR + b] = Kr[b];
+      sM[(ln * NB + c) * RSTR + b] = Mr[b];
+    }
+    sOK[ln][c] = rowok ? 1 : 0;
+    __syncthreads();
+    // ---- C: stencil row of the node, lane c takes slots c, c + NB, ...; fused epilogue
+    if (innode) {
+      constexpr int NSLOT = (DIM == 3) ? 27 : 9;
+      bool near = fa.near[node] != 0;
+      uint8_t r1 = 0, r2 = 0;
+      if (near) { r1 = fa.m1[node]; r2 = fa.m2[node]; }
+      double s11 = 0.0, s22 = 0.0, d11 = 0.0, d22 = 0.0, lK1 = 0.0, lK2 = 0.0, lM = 0.0;
+      int64_t rp = 0;
+      if (fa.ld == 0 || fa.keep_km) rp = rowptr[node];
+      for (int slot = c; slot < NSLOT; slot += NB) {
+        const int dx = slot % 3 - 1, dy = (slot / 3) % 3 - 1, dz = (DIM == 3) ? slot / 9 - 1 : 0;
+        const int ni = gi + dx, nj = gj + dy, nk = gk + dz;
+        if (ni < 0 || ni >= px || nj < 0 || nj >= py || nk < 0 || nk >= pz) continue;   // no such neighbour: pad / absent
+        const int dd[3] = {dx, dy, dz};
+        double kv = 0.0, mv = 0.0;
+#pragma unroll 1
+        for (int m = 0; m < NB; ++m) {   // m: corner bits of the node in the candidate incident cell (order of k_gather_rows)
+          int cc = 0, b = 0;
+          bool okc = true;
+#pragma unroll
+          for (int a = 0; a < DIM; ++a) {
+            const int cb = (m >> a) & 1;
+            const int bb = cb + dd[a];
+            okc = okc && (bb == 0 || bb == 1);
+            cc |= cb << a;
+            b |= (bb & 1) << a;
+          }
+          if (okc && sOK[ln][cc]) {
+            kv += sK[(ln * NB + cc) * RSTR + b];
+            mv += sM[(ln * NB + cc) * RSTR + b];
+          }
+        }
+        const int32_t j = (int32_t)(node + dx + (int64_t)dy * px + (int64_t)dz * pxy);
+        // position of the entry in the CSR row = number of existing neighbours in the slots before this one
+        int64_t kcsr = 0;
+        if (fa.ld == 0 || fa.keep_km) {
+          int rank = 0;
+          for (int s2 = 0; s2 < slot; ++s2) {
+            const int ex = gi + s2 % 3 - 1, ey = gj + (s2 / 3) % 3 - 1, ez = gk + ((DIM == 3) ? s2 / 9 - 1 : 0);
+            rank += (ex >= 0 && ex < px && ey >= 0 && ey < py && ez >= 0 && ez < pz) ? 1 : 0;
+          }
+          kcsr = rp + rank;
+        }
+        if (fa.keep_km) { K[kcsr] = kv; M[kcsr] = mv; }
+        const bool diag = (slot == NSLOT / 2);
+        double o11 = fa.a * kv + fa.b * mv, o22 = fa.c * kv + fa.b * mv, o12 = -fa.b * mv, o21 = o12;
+        if (near) {
+          const bool c1 = (fa.m1[j] & 1) != 0, c2 = fa.same ? c1 : (fa.m2[j] & 1) != 0;
+          if (fa.rhs) {
+            const double v1 = fa.g1[j], v2 = fa.g2[j];
+            lK1 += kv * v1; lK2 += kv * v2; lM += mv * (v1 - v2);
+          }
+          o11 = (r1 & 2) ? 0.0 : (r1 & 1) ? (diag ? 1.0 : 0.0) : (c1 ? 0.0 : o11);
+          o22 = (r2 & 2) ? 0.0 : (r2 & 1) ? (diag ? 1.0 : 0.0) : (c2 ? 0.0 : o22);
+          o12 = (r1 != 0 || c2) ? 0.0 : -fa.b * mv;
+          o21 = (r2 != 0 || c1) ? 0.0 : -fa.b * mv;
+        }
+        const int64_t ko = fa.ld ? (int64_t)fa.slot_of[(dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)] * fa.ld + node : kcsr;
+        fa.A11[ko] = o11;
+        fa.A22[ko] = o22;
+        if (fa.A12) fa.A12[ko] = o12;
+        if (fa.A21) fa.A21[ko] = o21;
+        s11 += fabs(o11); s22 += fabs(o22);
+        if (diag) { d11 = o11; d22 = o22; }
+      }
+#pragma unroll
+      for (int o = NB / 2; o > 0; o >>= 1) {
+        s11 += __shfl_down(s11, o, NB); s22 += __shfl_down(s22, o, NB);
+        d11 += __shfl_down(d11, o, NB); d22 += __shfl_down(d22, o, NB);
+        lK1 += __shfl_down(lK1, o, NB); lK2 += __shfl_down(lK2, o, NB); lM += __shfl_down(lM, o, NB);
+      }
+      if (c == 0) {
+        const double i1 = (d11 != 0.0) ? 1.0 / d11 : 1.0, i2 = (d22 != 0.0) ? 1.0 / d22 : 1.0;
+        fa.dinv1[node] = i1;
+        fa.dinv2[node] = i2;
+        const double q1 = s11 * fabs(i1), q2 = s22 * fabs(i2);
+        best1 = q1 > best1 ? q1 : best1;
+        best2 = q2 > best2 ? q2 : best2;
+        if (fa.rhs) {
+          fa.rhs[node] = (!near || r1 != 0) ? 0.0 : -(fa.a * lK1 + fa.b * lM);
+          fa.rhs[n + node] = (!near || r2 != 0) ? 0.0 : -(fa.c * lK2 - fa.b * lM);
+          fa.u0[node] = near ? fa.g1[node] : 0.0;
+          fa.u0[n + node] = near ? fa.g2[node] : 0.0;
+        }
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const double t1 = __shfl_down(best1, o, 64), t2 = __shfl_down(best2, o, 64);
+    best1 = t1 > best1 ? t1 : best1;
+    best2 = t2 > best2 ? t2 : best2;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(fa.lam, (unsigned long long)__double_as_longlong(best1));
+    atomicMax(fa.lam + 1, (unsigned long long)__double_as_longlong(best2));
+  }
+}
+
 // Fused assembly of the fine level for multilinear cells (two-pass kernels): element rows, then ONE node-centred
 // pass that writes the eliminated blocks, the lifted right-hand side and the smoother's diagonal / spectral bound
 // (and K, M as well when `asm_keep_km` is set, so that later assemblies with other coefficients reuse them).
@@ -1484,6 +1801,20 @@ int pph_launch_fused_kernels(pph_ctx* ctx, MeshData& mesh, const FuseArgs& fa, d
       hipLaunchKernelGGL((k_asm_simplex_gather<3, true>), dim3(gs), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p,
                          mesh.cy.p, mesh.cz.p, mesh.rowptr.p, mesh.col.p, Kp, Mp, mesh.nx, mesh.ny, mesh.nzl, mesh.px,
                          mesh.py, mesh.n, fa);
+    PPH_HIP(ctx, hipGetLastError());
+    return PPH_OK;
+  }
+  if (ctx->asm_tile && !ctx->asm_ring) {
+    // single pass, no element-row buffer (k_asm_tile)
+    const int tx = (mesh.dim == 3) ? 8 : 16, ty = (mesh.dim == 3) ? 4 : 8, tz = (mesh.dim == 3) ? 2 : 1;
+    const int64_t ntiles = ceil_div64(mesh.px, tx) * ceil_div64(mesh.py, ty) * ceil_div64(mesh.pzl, tz);
+    const int grid = (int)(ntiles < 256 * 16 ? ntiles : 256 * 16);
+    if (mesh.kind == PPH_CELL_QUAD)
+      hipLaunchKernelGGL(k_asm_tile<2>, dim3(grid), dim3(512), 0, ctx->stream, mesh.cx.p, mesh.cy.p, mesh.cz.p, mesh.rowptr.p,
+                         Kp, Mp, mesh.nx, mesh.ny, 0, mesh.px, mesh.py, 1, mesh.n, fa);
+    else
+      hipLaunchKernelGGL(k_asm_tile<3>, dim3(grid), dim3(512), 0, ctx->stream, mesh.cx.p, mesh.cy.p, mesh.cz.p, mesh.rowptr.p,
+                         Kp, Mp, mesh.nx, mesh.ny, mesh.nzl, mesh.px, mesh.py, mesh.pzl, mesh.n, fa);
     PPH_HIP(ctx, hipGetLastError());
     return PPH_OK;
   }

@@ -223,6 +223,7 @@ struct pph_ctx {
   DevBuf<unsigned long long> lam0;      // ... and their spectral bounds (bit patterns), valid when diag0_valid
   bool diag0_valid = false;
   int asm_fused = 1;                    // multilinear two-pass assembly writes the blocks directly (see pph_launch_assemble_fused)
+  int asm_tile = 1;                     // multilinear fused assembly: 1 single-pass tile kernel (no element-row buffer), 0 two-pass
   int asm_ring = 0;                     // > 0 (experiment, slower): fused 3D assembly alternates element and node passes over a ring of cell layers, about asm_ring cells per launch
   int asm_keep_km = 0;                  // 1: the fused pass also stores K and M (two more 8 B/nnz streams); 0: they are integrated on demand (pph_get_csr K/M, Darcy projection)
   DevBuf<uint8_t> rownear;              // 1: the row is constrained / ghost or has a constrained column (needs the masks)
