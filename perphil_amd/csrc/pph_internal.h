@@ -347,8 +347,10 @@ void pph_launch_row_near(pph_ctx* ctx, const MeshData& mesh, const uint8_t* m1, 
 void la_spmv(pph_ctx* ctx, const Csr& A, const double* x, double* y);
 void la_spmv_resid(pph_ctx* ctx, const Csr& A, const double* x, const double* b, double* y);  // y = b - A x
 // dot_slot >= 0: also scal[dot_slot] = b . y over the rows [dlo, dhi)
+// x_ghosts_valid: the ghost planes of x already hold the owners' values (no exchange before the product)
 void la_spmv_jacobi(pph_ctx* ctx, const Csr& A, const double* x, const double* b, const double* dinv,
-                    const double* w /* device */, double* y, int dot_slot = -1, int64_t dlo = 0, int64_t dhi = 0);
+                    const double* w /* device */, double* y, int dot_slot = -1, int64_t dlo = 0, int64_t dhi = 0,
+                    bool x_ghosts_valid = false);
 // y = A x and partial sums of dot(x, y) -> scal slot
 // (copy_src >= 0: scal[copy_dst] = scal[copy_src] is done by the final reduction's single workgroup)
 void la_spmv_dot(pph_ctx* ctx, const Csr& A, const double* x, double* y, int slot, int copy_src = -1, int copy_dst = -1);

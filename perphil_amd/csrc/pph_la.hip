@@ -744,9 +744,9 @@ static int stream_T(int max_row) {
 template <bool DOT>
 static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const double* bvec, double* y, double* part,
                          const double* jdinv = nullptr, const double* jw = nullptr, bool jdot = false, int64_t dlo = 0,
-                         int64_t dhi = 0) {
+                         int64_t dhi = 0, bool x_ghosts_valid = false) {
   const int variant = DOT ? 1 : 0;
-  if (A.geom) {  // ghost planes of x <- owners (slabs only); field-major mixed vectors carry two fields
+  if (A.geom && !x_ghosts_valid) {  // ghost planes of x <- owners (slabs only); field-major mixed vectors carry two fields
     (void)la_halo(ctx, *A.geom, const_cast<double*>(x));
     if (A.nrows == 2 * A.geom->n) (void)la_halo(ctx, *A.geom, const_cast<double*>(x) + A.geom->n);
   }
@@ -946,9 +946,9 @@ void la_spmv_resid(pph_ctx* ctx, const Csr& A, const double* x, const double* b,
 // y = x + w * dinv .* (b - A x): one damped-Jacobi (one-step Chebyshev) sweep, out of place (y != x); A must carry a
 // stencil-ELL copy
 void la_spmv_jacobi(pph_ctx* ctx, const Csr& A, const double* x, const double* b, const double* dinv, const double* w,
-                    double* y, int dot_slot, int64_t dlo, int64_t dhi) {
+                    double* y, int dot_slot, int64_t dlo, int64_t dhi, bool x_ghosts_valid) {
   const int grid = spmv_dispatch<false>(ctx, A, x, b, y, dot_slot >= 0 ? partials(ctx) : nullptr, dinv, w, dot_slot >= 0,
-                                        dlo, dhi);
+                                        dlo, dhi, x_ghosts_valid);
   if (dot_slot >= 0)
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, ctx->stream, partials(ctx), grid, ctx->scal.p + dot_slot);
 }

@@ -176,7 +176,9 @@ __global__ __launch_bounds__(256) void k_prolong_to(double* __restrict__ xout, c
   const int64_t nf = (int64_t)g.pxf * g.pyf * g.pzf;
   NODE_LOOP(id, nf) {
     const double x0 = xf[id];
-    if (mf[id] != 0) { xout[id] = x0; continue; }
+    // ghost rows (mask bit 2) are interpolated like owned ones: with the ghost planes of xf and xc refreshed, the
+    // ghost planes of xout equal the owners' values and the post-smoothing product needs no exchange of its own
+    if ((mf[id] & 1) != 0) { xout[id] = x0; continue; }
     const int i = (int)(id % g.pxf);
     const int64_t t = id / g.pxf;
     const int j = (int)(t % g.pyf), kg = (int)(t / g.pyf) + g.gzf;
@@ -1055,12 +1057,14 @@ static void mg_vcycle_fused(pph_ctx* ctx, int which, const double* rin, double* 
       hipLaunchKernelGGL(k_prolong_to<1>, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, L.t.p, x, C.x.p, L.maskp[which], tg);
     else
       hipLaunchKernelGGL(k_prolong_to<2>, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, L.t.p, x, C.x.p, L.maskp[which], tg);
+    // ghost planes of L.t: x's were refreshed by the residual product of the downward leg, the coarse correction's
+    // just above, and k_prolong_to interpolates ghost rows as well - one exchange per level and cycle less
     if (l == 0 && dot_slot >= 0) {
       la_spmv_jacobi(ctx, level_csr(ctx, L, which), L.t.p, b, L.dinv[which].p, cheb_wp(ctx, l, which), x, dot_slot,
-                     ctx->mg_dot_seg.off1, ctx->mg_dot_seg.off1 + ctx->mg_dot_seg.len1);
+                     ctx->mg_dot_seg.off1, ctx->mg_dot_seg.off1 + ctx->mg_dot_seg.len1, true);
       ctx->mg_dot_slot = -2;   // delivered
     } else {
-      la_spmv_jacobi(ctx, level_csr(ctx, L, which), L.t.p, b, L.dinv[which].p, cheb_wp(ctx, l, which), x);
+      la_spmv_jacobi(ctx, level_csr(ctx, L, which), L.t.p, b, L.dinv[which].p, cheb_wp(ctx, l, which), x, -1, 0, 0, true);
     }
   }
   ctx->comm_suspended = false;

@@ -111,6 +111,7 @@ class Communicator:
         self.on_device = self.backend == "nccl"
         self.halo_calls = 0
         self.allreduce_calls = 0
+        self.fail_halo_after = -1      # tests: the halo callback reports a failure from this call on (every rank alike)
         self._halo_c = _HALO_FN(self._halo)
         self._allreduce_c = _ALLREDUCE_FN(self._allreduce)
 
@@ -118,6 +119,8 @@ class Communicator:
         return self.torch.as_tensor(_DevView(ptr + 8 * off, count), device="cuda")
 
     def _halo(self, _user, vec, plane, send_lo, recv_lo, send_hi, recv_hi) -> int:
+        if 0 <= self.fail_halo_after <= self.halo_calls:
+            return -1
         try:
             torch, dist = self.torch, self.dist
             ops, copies = [], []

@@ -22,16 +22,33 @@ def _free_port():
                                                          (2, 16, "tet", "mg", "picard"), (2, 8, "hex", "jacobi", "picard"),
                                                          (2, 16, "tet", "mg", "gmres_fs"), (2, 8, "hex", "mg", "cg_block2"),
                                                          (4, 8, "hex", "mg", "gmres_jacobi"),
-                                                         (4, 32, "hex", "mg", "picard-inexact"), (2, 32, "tet", "mg", "picard-inexact")])
+                                                         (4, 32, "hex", "mg", "picard-inexact"), (2, 32, "tet", "mg", "picard-inexact"),
+                                                         # slabs of unequal thickness (cells not a multiple of the ranks)
+                                                         (4, 18, "hex", "mg", "picard-inexact"), (3, 20, "tet", "mg", "picard"),
+                                                         # the device-scalar CG branch of the RCCL transport, over the callbacks
+                                                         (2, 32, "hex", "mg", "picard-inexact-devscal"),
+                                                         (4, 32, "hex", "mg", "picard-inexact-devscal"),
+                                                         (2, 16, "tet", "jacobi", "picard-devscal")])
 def test_slab_runs_match_single_context(world, cells, kind, pc, solver):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tools", "slab_check.py"), "--cells", str(cells), "--backend", "gloo", "--kind", kind,
-           "--inner-pc", pc, "--solver", solver.split("-")[0]] + (["--inexact"] if solver.endswith("inexact") else [])
+           "--inner-pc", pc, "--solver", solver.split("-")[0]] + (["--inexact"] if "inexact" in solver else []) + (
+               ["--device-scalars"] if solver.endswith("devscal") else [])
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=280)
     line = [l for l in r.stdout.splitlines() if l.startswith("world=")]
     assert r.returncode == 0, (line, r.stdout[-2000:], r.stderr[-2000:])
     assert line and "max rel diff" in line[0]
+
+
+def test_failed_halo_exchange_is_reported_not_computed_through():
+    """A halo callback that fails (on every rank, at the same exchange) must surface as a COMM error from the solve -
+    not as a result computed on stale ghost planes - and the context must keep refusing afterwards (sticky status)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "slab_check.py"), "--cells", "16", "--backend",
+           "gloo", "--inexact", "--fail-halo-after", "40"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "COMM error on every rank" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
 def test_rccl_plumbing_single_rank():

@@ -712,6 +712,7 @@ def test_spmv_long_rows_and_residual_forms(gpu_ctx_factory, kern):
     CG and residual entry points (fused p.Ap, b - Ax) are covered through a Jacobi-CG solve against the oracle."""
     f = _ffi()
     ctx, om, osys = _setup(gpu_ctx_factory, 3, o.CELL_HEX, 5, 4, 3)
+    ctx.set_option("op_format", 0)
     ctx.set_option("spmv_kernel", kern)
     rng = np.random.default_rng(5)
     x = rng.uniform(-1, 1, 2 * osys.n)
@@ -722,6 +723,47 @@ def test_spmv_long_rows_and_residual_forms(gpu_ctx_factory, kern):
     res = o.pcg(osys.A, osys.rhs, o.jacobi_apply(osys.A), rtol=1e-10)
     assert info.converged and abs(info.iterations - res.its) <= 1
     assert np.abs(xs - (osys.u0 + res.x)).max() <= 1e-8 * np.abs(xs).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,kind,nx,ny,nz", [(2, o.CELL_QUAD, 1, 1, 0), (2, o.CELL_QUAD, 2, 5, 0), (2, o.CELL_TRI, 1, 3, 0),
+                                               (2, o.CELL_TRI, 7, 4, 0), (3, o.CELL_HEX, 1, 1, 1), (3, o.CELL_HEX, 2, 1, 3),
+                                               (3, o.CELL_HEX, 9, 7, 5), (3, o.CELL_TET, 1, 2, 1), (3, o.CELL_TET, 5, 3, 4),
+                                               (2, o.CELL_QUAD, 40, 33, 0), (3, o.CELL_HEX, 21, 18, 10)])
+def test_stencil_ell_format_equals_csr(gpu_ctx_factory, dim, kind, nx, ny, nz):
+    """The stencil-ELL operator format (default) against the CSR format on the same mesh, tiny boxes (stencil slots
+    clipped on every side, px < 3) and ragged ones included: the exported CSR blocks are identical entry for entry
+    (the fused assembly writes the stencil-ELL arrays, pph_get_csr converts), the products of all blocks agree with
+    SciPy's, and both formats solve to the same iterates."""
+    f = _ffi()
+    om = o.build_mesh(dim, kind, nx, ny, nz)
+    b = o.boundary_nodes(om)
+    g1, g2 = o.exact_pressures(om.coords[b], P)
+    res = {}
+    for fmt in (0, 1):
+        ctx = gpu_ctx_factory()
+        ctx.set_option("op_format", fmt)
+        ctx.set_option("asm_tile", 0)      # same element-row arithmetic in both runs
+        ctx.mesh_build(dim, kind, nx, ny, nz)
+        ctx.set_dirichlet(0, b, g1)
+        ctx.set_dirichlet(1, b, g2)
+        ctx.assemble(P.k1, P.k2, P.beta, P.mu, monolithic=False)
+        rng = np.random.default_rng(7)
+        x = rng.uniform(-1, 1, om.num_nodes)
+        prods = {w: ctx.spmv(w, x) for w in (f.MAT_A11, f.MAT_A22, f.MAT_A12, f.MAT_A21, f.MAT_K, f.MAT_M)}
+        mats = {w: ctx.csr(w) for w in (f.MAT_A11, f.MAT_A22, f.MAT_A12, f.MAT_A21, f.MAT_K, f.MAT_M)}
+        for w in mats:
+            ref = mats[w] @ x
+            assert np.abs(prods[w] - ref).max() <= 1e-13 * max(np.abs(ref).max(), 1e-300), (fmt, w)
+        xs, info, _ = ctx.solve(_cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_MG, inner_rtol=1e-10,
+                                     inner_reduction=1e-1, inner_norm=1, mg_smooth=1, picard_rtol=1e-9))
+        res[fmt] = (mats, xs, info.iterations, info.inner_iterations)
+    for w in res[0][0]:
+        np.testing.assert_array_equal(res[1][0][w].indptr, res[0][0][w].indptr)
+        np.testing.assert_array_equal(res[1][0][w].indices, res[0][0][w].indices)
+        np.testing.assert_array_equal(res[1][0][w].data, res[0][0][w].data)
+    assert res[0][2:] == res[1][2:]
+    np.testing.assert_allclose(res[1][1], res[0][1], rtol=0, atol=1e-10 * np.abs(res[0][1]).max())
 
 
 @pytest.mark.gpu
@@ -845,14 +887,18 @@ def test_config2_64cubed_monolithic_cg(gpu_ctx_factory, pc):
 @pytest.mark.gpu
 def test_option_paths_agree(gpu_ctx_factory):
     """Alternative code paths kept behind pph_set_option give the same solve: host-driven coarsest CG vs the
-    single-workgroup device CG, software-pipelined SpMV (17) vs the default kernel."""
+    on-chip tail of the cycle, CSR operators (and two of their SpMV kernels) vs the stencil-ELL default, the general
+    kernel-per-operation V-cycle vs the fused one, eager vs graph-replayed iterations, synchronising vs polled
+    fetches, two-pass vs tile assembly."""
     f = _ffi()
     ref = None
-    for opts in ({}, {"coarse_on_device": 0}, {"spmv_kernel": 17}, {"spmv_kernel": 1}, {"asm_ring": 200}):
+    for opts in ({}, {"coarse_on_device": 0}, {"op_format": 0, "spmv_kernel": 17}, {"op_format": 0, "spmv_kernel": 1},
+                 {"asm_ring": 200}, {"op_format": 0}, {"mg_fused": 0}, {"use_graphs": 0}, {"fetch_spin": 0},
+                 {"mg_tail_rows": 50}, {"mg_tail_rows": 0}, {"asm_tile": 0}, {"sell_rpt": 1}, {"sell_group": 4}):
         ctx, om, osys = _setup(gpu_ctx_factory, 3, o.CELL_HEX, 12, 8, 16)
         for k, v in opts.items():
             ctx.set_option(k, v)
-        if "asm_ring" in opts:        # layered assembly schedule: takes effect at the next assembly
+        if opts:                      # assembly-side options take effect at the next assembly
             ctx.assemble(P.k1, P.k2, P.beta, P.mu, monolithic=True)
         xs, info, _ = ctx.solve(_cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_MG, inner_rtol=1e-10,
                                      inner_reduction=1e-1, inner_norm=1, mg_smooth=1, picard_rtol=1e-9))
@@ -861,7 +907,7 @@ def test_option_paths_agree(gpu_ctx_factory):
             ref = (xs, info.iterations, info.inner_iterations)
         else:
             assert (info.iterations, info.inner_iterations) == ref[1:], opts
-            np.testing.assert_allclose(xs, ref[0], rtol=0, atol=1e-11 * np.abs(ref[0]).max())
+            np.testing.assert_allclose(xs, ref[0], rtol=0, atol=1e-10 * np.abs(ref[0]).max(), err_msg=str(opts))
 
 
 @pytest.mark.gpu

@@ -17,6 +17,10 @@ ap.add_argument("--inner-pc", default="mg")
 ap.add_argument("--solver", default="picard", choices=["picard", "gmres_fs", "cg_block2", "gmres_jacobi"])
 ap.add_argument("--inexact", action="store_true",
                 help="the benchmark's Picard settings: V(1,1), block solves to a tenfold drop of the unpreconditioned residual")
+ap.add_argument("--device-scalars", action="store_true",
+                help="run the device-scalar CG branch (what the RCCL transport executes) over the callback transport")
+ap.add_argument("--fail-halo-after", type=int, default=-1,
+                help="every rank's halo callback fails from this call on: the solve must return a COMM error, not a result")
 args = ap.parse_args()
 
 from perphil_amd import _ffi  # noqa: E402  (before torch: the library binds the system HIP runtime first)
@@ -39,6 +43,31 @@ if args.inexact:
                         inner_reduction=0.1, inner_norm=1)
 else:
     solver = SlabSolver(args.cells, world, rank, device, k1, k2, beta, mu, kind=kind, inner_pc=pc)
+if args.device_scalars:
+    solver.ctx.set_option("device_scalars", 1)
+if args.fail_halo_after >= 0:
+    solver.comm.fail_halo_after = args.fail_halo_after
+    try:
+        solver.step()
+    except RuntimeError as e:
+        ok = "-5" in str(e) or "failed" in str(e)
+        print(f"rank {rank}: solve refused after the injected halo failure: {e}", flush=True)
+    else:
+        ok = False
+        print(f"rank {rank}: solve returned a result although its halo exchanges failed", flush=True)
+    # a later solve on the same context must keep failing (sticky status) without touching the transport
+    try:
+        solver.step()
+        ok = False
+    except RuntimeError:
+        pass
+    flag = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(f"world={world} injected halo failure: {'COMM error on every rank' if flag.item() == 1.0 else 'NOT reported'}; max rel diff n/a", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0 if flag.item() == 1.0 else 1)
 mono = args.solver != "picard"
 if mono:
     solver.cfg.picard = 0
