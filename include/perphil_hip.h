@@ -94,7 +94,8 @@ typedef struct {
   int32_t iterations;        /* outer Krylov its (ksp.getIterationNumber(), solver.py:73) or Picard sweeps */
   int32_t inner_iterations;  /* total inner Krylov iterations                            */
   int32_t converged;         /* 1 / 0                                                    */
-  int32_t reserved;
+  int32_t inner_failed;      /* 1: a block solve of the field-split PC / a Picard sweep, or the coarsest multigrid
+                              * solve, hit its iteration limit or broke down (the outer result may still converge) */
   double resnorm;            /* final (preconditioned) residual norm (ksp.getResidualNorm(), solver.py:74) */
   double rhs_norm;           /* ||F(u0)||_2, PETSc's "0 SNES Function norm"               */
 } pph_solve_info;

@@ -61,7 +61,7 @@ class SolveInfo(C.Structure):
     """``pph_solve_info``"""
     _fields_ = [
         ("iterations", C.c_int32), ("inner_iterations", C.c_int32), ("converged", C.c_int32),
-        ("reserved", C.c_int32), ("resnorm", C.c_double), ("rhs_norm", C.c_double),
+        ("inner_failed", C.c_int32), ("resnorm", C.c_double), ("rhs_norm", C.c_double),
     ]
 
 

@@ -515,7 +515,7 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
     return PPH_OK;
   }
   if (!strcmp(name, "spmv_blocks")) { ctx->spmv_blocks = (int)value; return PPH_OK; }
-  if (!strcmp(name, "use_graphs")) { ctx->use_graphs = value != 0.0 ? 1 : 0; return PPH_OK; }
+  if (!strcmp(name, "use_graphs")) { ctx->use_graphs = (value == 2.0) ? 2 : (value != 0.0 ? 1 : 0); return PPH_OK; }
   if (!strcmp(name, "fetch_spin")) { ctx->fetch_spin = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "device_scalars")) { ctx->device_scalars = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "op_format")) {
@@ -526,10 +526,12 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
   if (!strcmp(name, "sell_rpt")) { ctx->sell_rpt = (int)value; return PPH_OK; }
   if (!strcmp(name, "sell_blocks")) { ctx->sell_blocks = (int)value; return PPH_OK; }
   if (!strcmp(name, "sell_group")) { ctx->sell_group = (int)value; return PPH_OK; }
-  if (!strcmp(name, "asm_tile")) { ctx->asm_tile = value != 0.0 ? 1 : 0; return PPH_OK; }
+  if (!strcmp(name, "asm_tile")) { ctx->asm_tile = (value == 2.0) ? 2 : (value != 0.0 ? 1 : 0); return PPH_OK; }
+  if (!strcmp(name, "asm_tile_min_nodes")) { ctx->asm_tile_min_nodes = (int64_t)value; return PPH_OK; }
   if (!strcmp(name, "asm_fused")) { ctx->asm_fused = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "asm_ring")) { ctx->asm_ring = value > 0.0 ? (int)value : 0; return PPH_OK; }
   if (!strcmp(name, "asm_keep_km")) { ctx->asm_keep_km = value != 0.0 ? 1 : 0; return PPH_OK; }
+  if (!strcmp(name, "coarse_max_it")) { ctx->coarse_max_it = value >= 1 ? (int)value : 1; return PPH_OK; }
   if (!strcmp(name, "mg_fused")) { ctx->mg_fused = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "mg_tail_rows")) { ctx->mg_tail_rows = (int64_t)value; return PPH_OK; }
   if (!strcmp(name, "coarse_on_device")) { ctx->coarse_on_device = value != 0.0 ? 1 : 0; return PPH_OK; }

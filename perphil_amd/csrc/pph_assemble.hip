@@ -1553,23 +1553,49 @@ __global__ __launch_bounds__(512) void k_asm_tile(const double* __restrict__ cx,
   const int ln = tid / NB, c = tid % NB;
   const int lx = ln % TX, ly = (ln / TX) % TY, lz = ln / (TX * TY);
   double best1 = 0.0, best2 = 0.0;
+  static_assert(NV <= 512, "one vertex per lane");
+  // vertices of a tile's cells: nodes (i0-1 .. i0+TX, j0-1 .. j0+TY, k0-1 .. k0+TZ), clamped into the box.  The
+  // coordinates of the NEXT tile are requested while the current one is computed (register double buffer): the
+  // load latency sat exposed in front of phase A with only two workgroups per CU to hide it
+  double pv[3] = {0.0, 0.0, 0.0};
+  auto fetch_vertex = [&](int64_t tile) {
+    if (tile >= ntiles || tid >= NV) return;
+    const int tx = (int)(tile % tiles_x);
+    const int64_t tt = tile / tiles_x;
+    const int ty = (int)(tt % tiles_y), tz = (int)(tt / tiles_y);
+    const int vx = tid % VX, vy = (tid / VX) % VY, vz = tid / (VX * VY);
+    int gi = tx * TX - 1 + vx, gj = ty * TY - 1 + vy, gk = (DIM == 3) ? tz * TZ - 1 + vz : 0;
+    gi = gi < 0 ? 0 : (gi > px - 1 ? px - 1 : gi);
+    gj = gj < 0 ? 0 : (gj > py - 1 ? py - 1 : gj);
+    gk = gk < 0 ? 0 : (gk > pz - 1 ? pz - 1 : gk);
+    const int64_t g = gi + (int64_t)px * gj + pxy * gk;
+    pv[0] = cx[g];
+    pv[1] = cy[g];
+    if constexpr (DIM == 3) pv[2] = cz[g];
+  };
+  fetch_vertex(blockIdx.x);
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int tx = (int)(tile % tiles_x);
     const int64_t tt = tile / tiles_x;
     const int ty = (int)(tt % tiles_y), tz = (int)(tt / tiles_y);
     const int i0 = tx * TX, j0 = ty * TY, k0 = tz * TZ;
     __syncthreads();   // previous tile's rows are consumed
-    // ---- vertices of the tile's cells: nodes (i0-1 .. i0+TX, j0-1 .. j0+TY, k0-1 .. k0+TZ), clamped into the box
-    for (int v = tid; v < NV; v += 512) {
-      const int vx = v % VX, vy = (v / VX) % VY, vz = v / (VX * VY);
-      int gi = i0 - 1 + vx, gj = j0 - 1 + vy, gk = (DIM == 3) ? k0 - 1 + vz : 0;
-      gi = gi < 0 ? 0 : (gi > px - 1 ? px - 1 : gi);
-      gj = gj < 0 ? 0 : (gj > py - 1 ? py - 1 : gj);
-      gk = gk < 0 ? 0 : (gk > pz - 1 ? pz - 1 : gk);
-      const int64_t g = gi + (int64_t)px * gj + pxy * gk;
-      sXv[v][0] = cx[g];
-      sXv[v][1] = cy[g];
-      if constexpr (DIM == 3) sXv[v][2] = cz[g];
+    if (tid < NV) {
+      sXv[tid][0] = pv[0];
+      sXv[tid][1] = pv[1];
+      if constexpr (DIM == 3) sXv[tid][2] = pv[2];
+    }
+    fetch_vertex(tile + gridDim.x);
+    // operands of phase C that depend on the node only: requested now, used after three barriers
+    uint8_t pnear = 0, pr1 = 0, pr2 = 0;
+    {
+      const int gi = i0 + lx, gj = j0 + ly, gk = (DIM == 3) ? k0 + lz : 0;
+      if (gi < px && gj < py && gk < pz) {
+        const int64_t nd = gi + (int64_t)px * gj + pxy * gk;
+        pnear = fa.near[nd];
+        pr1 = fa.m1[nd];
+        pr2 = fa.m2[nd];
+      }
     }
     __syncthreads();
     // ---- A: geometry factors, lane (cell, q)
@@ -1682,9 +1708,8 @@ __global__ __launch_bounds__(512) void k_asm_tile(const double* __restrict__ cx,
     // ---- C: stencil row of the node, lane c takes slots c, c + NB, ...; fused epilogue
     if (innode) {
       constexpr int NSLOT = (DIM == 3) ? 27 : 9;
-      bool near = fa.near[node] != 0;
-      uint8_t r1 = 0, r2 = 0;
-      if (near) { r1 = fa.m1[node]; r2 = fa.m2[node]; }
+      const bool near = pnear != 0;
+      const uint8_t r1 = near ? pr1 : 0, r2 = near ? pr2 : 0;
       double s11 = 0.0, s22 = 0.0, d11 = 0.0, d22 = 0.0, lK1 = 0.0, lK2 = 0.0, lM = 0.0;
       int64_t rp = 0;
       if (fa.ld == 0 || fa.keep_km) rp = rowptr[node];
@@ -1804,7 +1829,8 @@ int pph_launch_fused_kernels(pph_ctx* ctx, MeshData& mesh, const FuseArgs& fa, d
     PPH_HIP(ctx, hipGetLastError());
     return PPH_OK;
   }
-  if (ctx->asm_tile && !ctx->asm_ring) {
+  // (small levels: the two-pass kernels, whose many small workgroups fill the chip where a few thousand tiles do not)
+  if (ctx->asm_tile && !ctx->asm_ring && (ctx->asm_tile == 2 || mesh.n >= ctx->asm_tile_min_nodes)) {
     // single pass, no element-row buffer (k_asm_tile)
     const int tx = (mesh.dim == 3) ? 8 : 16, ty = (mesh.dim == 3) ? 4 : 8, tz = (mesh.dim == 3) ? 2 : 1;
     const int64_t ntiles = ceil_div64(mesh.px, tx) * ceil_div64(mesh.py, ty) * ceil_div64(mesh.pzl, tz);

@@ -223,6 +223,7 @@ struct pph_ctx {
   DevBuf<unsigned long long> lam0;      // ... and their spectral bounds (bit patterns), valid when diag0_valid
   bool diag0_valid = false;
   int asm_fused = 1;                    // multilinear two-pass assembly writes the blocks directly (see pph_launch_assemble_fused)
+  int64_t asm_tile_min_nodes = 500000;  // levels with fewer nodes use the two-pass kernels (asm_tile 2: tile kernel always)
   int asm_tile = 1;                     // multilinear fused assembly: 1 single-pass tile kernel (no element-row buffer), 0 two-pass
   int asm_ring = 0;                     // > 0 (experiment, slower): fused 3D assembly alternates element and node passes over a ring of cell layers, about asm_ring cells per launch
   int asm_keep_km = 0;                  // 1: the fused pass also stores K and M (two more 8 B/nnz streams); 0: they are integrated on demand (pph_get_csr K/M, Darcy projection)
@@ -307,6 +308,8 @@ struct pph_ctx {
   int mg_fused = 1;                     // V(1,1) cycles on stencil-ELL levels: fused smoother / transfer kernels and the
                                         // single-workgroup tail (pph_mg.hip); 0: the general kernel-per-operation cycle
   int64_t mg_tail_rows = 5000;          // levels with at most this many rows are handled inside the tail kernel
+  int coarse_max_it = 500;              // iteration limit of the coarsest-level Jacobi-CG (to rtol 1e-12)
+  int coarse_failed = 0;                // host-driven coarsest solves of the last solve that stopped at their iteration limit
   int coarse_on_device = 1;             // coarsest multigrid level (<= 4096 rows): CG inside one workgroup, no host round trips
   int spmv_bench_mode = 0;              // pph_spmv_bench protocol: 0 back-to-back, 1-3 interleaved (see pph_api.hip)
   int64_t mg_replicate_below = 40000;   // slabs: multigrid levels with at most this many global nodes are replicated

@@ -1022,7 +1022,7 @@ static void mg_vcycle_fused(pph_ctx* ctx, int which, const double* rin, double* 
     if (threads < 64) threads = 64;
     const size_t lds = mg_tail_lds(ns, ta.nl, sell_slots(kind));
 #define PPH_TAIL_GO(KK) \
-  hipLaunchKernelGGL(k_mg_tail<KK>, dim3(1), dim3(threads), lds, ctx->stream, ta, st, tk, 1e-12, 500)
+  hipLaunchKernelGGL(k_mg_tail<KK>, dim3(1), dim3(threads), lds, ctx->stream, ta, st, tk, 1e-12, ctx->coarse_max_it)
     switch (kind) {
       case PPH_CELL_QUAD: PPH_TAIL_GO(PPH_CELL_QUAD); break;
       case PPH_CELL_TRI: PPH_TAIL_GO(PPH_CELL_TRI); break;
@@ -1038,9 +1038,9 @@ static void mg_vcycle_fused(pph_ctx* ctx, int which, const double* rin, double* 
     if ((!dist || C.replicated) && C.n <= 4096 && ctx->coarse_on_device)
       hipLaunchKernelGGL(k_coarse_cg_sell, dim3(1), dim3(C.n <= 256 ? 256 : 1024), 0, ctx->stream, C.ell[which].val,
                          C.ell[which].ld, make_stencil(kind), C.px, C.py, C.pz, C.dinv[which].p, C.b.p, C.x.p, C.r.p,
-                         C.d.p, C.t.p, (int)C.n, 1e-12, 500);
+                         C.d.p, C.t.p, (int)C.n, 1e-12, ctx->coarse_max_it);
     else
-      pph_cg_jacobi(ctx, level_csr(ctx, C, which), C.b.p, C.x.p, C.dinv[which].p, 1e-12, 0.0, 500, C.r.p, C.d.p, C.t.p,
+      pph_cg_jacobi(ctx, level_csr(ctx, C, which), C.b.p, C.x.p, C.dinv[which].p, 1e-12, 0.0, ctx->coarse_max_it, C.r.p, C.d.p, C.t.p,
                     C.w.p, &its);
   }
   for (int l = top - 1; l >= 0; --l) {
@@ -1125,12 +1125,12 @@ void mg_vcycle(pph_ctx* ctx, int which, const double* rin, double* zout, int nsm
     if ((!dist || C.replicated) && C.n <= 4096 && ctx->coarse_on_device && C.ell[which].val)
       hipLaunchKernelGGL(k_coarse_cg_sell, dim3(1), dim3(C.n <= 256 ? 256 : 1024), 0, ctx->stream, C.ell[which].val,
                          C.ell[which].ld, make_stencil(ctx->mesh.kind), C.px, C.py, C.pz, C.dinv[which].p, C.b.p, C.x.p,
-                         C.r.p, C.d.p, C.t.p, (int)C.n, 1e-12, 500);
+                         C.r.p, C.d.p, C.t.p, (int)C.n, 1e-12, ctx->coarse_max_it);
     else if ((!dist || C.replicated) && C.n <= 4096 && ctx->coarse_on_device)
       hipLaunchKernelGGL(k_coarse_cg, dim3(1), dim3(C.n <= 256 ? 256 : 1024), 0, ctx->stream, C.rowptr, C.col, C.val[which],
-                         C.dinv[which].p, C.b.p, C.x.p, C.r.p, C.d.p, C.t.p, (int)C.n, 1e-12, 500);
+                         C.dinv[which].p, C.b.p, C.x.p, C.r.p, C.d.p, C.t.p, (int)C.n, 1e-12, ctx->coarse_max_it);
     else
-      pph_cg_jacobi(ctx, level_csr(ctx, C, which), C.b.p, C.x.p, C.dinv[which].p, 1e-12, 0.0, 500, C.r.p, C.d.p, C.t.p,
+      pph_cg_jacobi(ctx, level_csr(ctx, C, which), C.b.p, C.x.p, C.dinv[which].p, 1e-12, 0.0, ctx->coarse_max_it, C.r.p, C.d.p, C.t.p,
                     C.w.p, &its);
   }
   // upward leg

@@ -154,7 +154,10 @@ static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double*
     // on small meshes the kernels are shorter than the 3.5 us the host needs to enqueue one, so an eager iteration
     // is host-bound; the captured body replays in one call.  Single context, fused multigrid cycle only.
     GraphKey gk;
-    const bool graphable = ctx->use_graphs && pre.on && pre.launch_only && ctx->world == 1 && !ctx->time_spmv && ctx->fetch_spin;
+    // (measured: a replay starts 38 us after the host's decision, an eager launch 17 us - the replay pays off only
+    // where the iteration's kernels are shorter than the host's launch rate, i.e. on small systems; use_graphs 2: always)
+    const bool graphable = ctx->use_graphs && (ctx->use_graphs == 2 || n <= 600000) && pre.on && pre.launch_only &&
+                           ctx->world == 1 && !ctx->time_spmv && ctx->fetch_spin;
     if (graphable) {
       gk.p[0] = A.ell.val ? (const void*)A.ell.val : (const void*)A.val; gk.p[1] = x; gk.p[2] = r; gk.p[3] = z; gk.p[4] = p;
       gk.p[5] = q; gk.p[6] = pre.dinv; gk.p[7] = pre.w;
@@ -307,6 +310,7 @@ int pph_cg_jacobi(pph_ctx* ctx, const Csr& A, const double* b, double* x, const 
   KspOut ko;
   PPH_TRY(cg_solve(ctx, A, b, x, dinv, ApplyFn(), rtol, atol, max_it, false, r, z, p, q, S_COARSE, &ko, nullptr, 0));
   if (its) *its = ko.its;
+  if (!ko.converged || ko.breakdown) ctx->coarse_failed++;   // reported as pph_solve_info.inner_failed
   return PPH_OK;
 }
 
@@ -549,7 +553,8 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
   PPH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
 
   pph_solve_info inf;
-  inf.iterations = 0; inf.inner_iterations = 0; inf.converged = 0; inf.reserved = 0; inf.resnorm = 0; inf.rhs_norm = 0;
+  inf.iterations = 0; inf.inner_iterations = 0; inf.converged = 0; inf.inner_failed = 0; inf.resnorm = 0; inf.rhs_norm = 0;
+  ctx->coarse_failed = 0;
   la_dot(ctx, ctx->rhs.p, ctx->rhs.p, N, S_A);
   PPH_TRY(la_fetch(ctx, S_A, 1));
   inf.rhs_norm = std::sqrt(ctx->h_scal[S_A]);
@@ -638,6 +643,7 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
     inf.inner_iterations = bs.total_its;
     inf.resnorm = res;
     inf.converged = (res <= tol) ? 1 : 0;
+    inf.inner_failed = (bs.failed || ctx->coarse_failed) ? 1 : 0;
     if (!inf.converged) status = PPH_ERR_DIVERGED;
   } else {
     const Csr A = mono_csr(ctx);
@@ -689,6 +695,7 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
     inf.inner_iterations = bs.total_its;
     inf.resnorm = ko.res;
     inf.converged = (ko.converged && !bs.failed) ? 1 : 0;
+    inf.inner_failed = (bs.failed || ctx->coarse_failed) ? 1 : 0;
     if (!ko.converged || ko.breakdown) status = PPH_ERR_DIVERGED;
   }
 

@@ -56,6 +56,17 @@ def default_model_params() -> DPPParameters:
     return DPPParameters(k1=1.0, k2=1.0 / 1e2, beta=1.0, mu=1.0)
 
 
+def make_fieldsplit_params_with(block_pc: str = "lu") -> Dict:
+    """Field-split GMRES options with the given block preconditioner on both blocks ('lu' or 'ilu'); for 'ilu' the
+    block solves are a single preconditioner application (reference iterative_bench.py:134-154)."""
+    opts = {**solver_params.FIELDSPLIT_LU_PARAMS, "ksp_type": "gmres"}
+    if block_pc.lower() != "lu":
+        for i in (0, 1):
+            opts[f"fieldsplit_{i}_pc_type"] = block_pc
+            opts.setdefault(f"fieldsplit_{i}_ksp_type", "preonly")
+    return opts
+
+
 def params_for(approach: Approach) -> Dict:
     if approach == Approach.PLAIN_GMRES:
         return solver_params.PLAIN_GMRES_PARAMS.copy()
@@ -101,4 +112,22 @@ def estimate_condition_numbers(W, params: Optional[DPPParameters] = None, bcs: O
                                num_of_factors: Optional[int] = 50, use_sparse: bool = True) -> Dict[str, float]:
     csr, n0, n1 = assemble_monolithic_matrix(W, params=params, bcs=bcs)
     cond = conditioning.calculate_condition_number
-    return {"monolithic": cond(csr), "macro": cond(csr[:n0, :n0].tocsr()), "micro": cond(csr[n0:n0 + n1, n0:n0 + n1].tocsr())}
+    kw = {"num_singular_values": num_of_factors, "use_sparse": use_sparse}
+    return {"monolithic": cond(csr, **kw), "macro": cond(csr[:n0, :n0].tocsr(), **kw),
+            "micro": cond(csr[n0:n0 + n1, n0:n0 + n1].tocsr(), **kw)}
+
+
+def l2_errors_against_reference(W, fields: Tuple[fd.Function, fd.Function],
+                                ref_fields: Tuple[fd.Function, fd.Function]) -> Tuple[float, float]:
+    """L2 norms of p1 - r1 and p2 - r2 for CG-1 fields on the mesh of W (reference iterative_bench.py:340-362:
+    sqrt(assemble((p - r)^2 dx))).  For CG-1 differences that integral is exactly d^T M d with the mass matrix M,
+    which the device assembles (pph_get_csr K/M export)."""
+    from . import _ffi
+
+    ctx = W.mesh().context()
+    M = ctx.csr(_ffi.MAT_M)
+    out = []
+    for p, r in zip(fields, ref_fields):
+        d = np.asarray(p.vector(), dtype=np.float64) - np.asarray(r.vector(), dtype=np.float64)
+        out.append(float(np.sqrt(max(d @ (M @ d), 0.0))))
+    return out[0], out[1]

@@ -19,16 +19,13 @@ class DPPParameters:
     scale_contrast: float = 1e2
 
     def __attrs_post_init__(self):
-        if not isinstance(self.k1, fd.Constant):
-            self.k1 = fd.Constant(self.k1)
-        if self.k2 is None:
-            self.k2 = self.k1 / self.scale_contrast
-        if not isinstance(self.k2, fd.Constant):
-            self.k2 = fd.Constant(self.k2)
-        if not isinstance(self.beta, fd.Constant):
-            self.beta = fd.Constant(self.beta)
-        if not isinstance(self.mu, fd.Constant):
-            self.mu = fd.Constant(self.mu)
+        # every coefficient ends up as a Constant (so that eta and the forms can do arithmetic on them); the
+        # micro-scale permeability defaults to the macro-scale one divided by the contrast
+        as_constant = lambda v: v if isinstance(v, fd.Constant) else fd.Constant(v)   # noqa: E731
+        self.k1 = as_constant(self.k1)
+        self.k2 = as_constant(self.k1 / self.scale_contrast if self.k2 is None else self.k2)
+        for name in ("beta", "mu"):
+            setattr(self, name, as_constant(getattr(self, name)))
 
     @property
     def eta(self) -> fd.Constant:

@@ -94,3 +94,13 @@ def save_perf_csv(df, path: str) -> None:
 
     os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
     df.to_csv(path, index=False)
+
+
+def save_perf_json(df, path: str) -> None:
+    """Rows of the sweep as a JSON list of records (reference petsc_profiling_3d.py:238-241)."""
+    import json
+    import os
+
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    with open(path, "w", encoding="utf-8") as f:
+        json.dump(df.to_dict(orient="records"), f, indent=2)

@@ -106,7 +106,8 @@ def translate_options(params: Dict, nonlinear: bool = False) -> Tuple[_ffi.Solve
     cfg = _ffi.SolverCfg()
     cfg.restart = int(params.get("ksp_gmres_restart", 30))
     cfg.max_it = int(params.get("ksp_max_it", 10000))
-    cfg.rtol = float(params.get("ksp_rtol", 1e-5 if params.get("ksp_type") else 1e-7))
+    # Firedrake's solver defaults (set_defaults of its variational solvers): ksp_rtol 1e-7 unless the user gives one
+    cfg.rtol = float(params.get("ksp_rtol", 1e-7))
     cfg.atol = float(params.get("ksp_atol", 1e-50))
     cfg.inner_ksp_type, cfg.inner_pc_type = _ffi.KSP_CG, _ffi.PC_MG
     cfg.inner_rtol, cfg.inner_atol, cfg.inner_max_it = 1e-10, 1e-50, 50000
@@ -117,7 +118,10 @@ def translate_options(params: Dict, nonlinear: bool = False) -> Tuple[_ffi.Solve
     cfg.mg_smooth = int(params.get("pph_mg_smooth", 2))
     info = {"direct_equivalent": False}
 
-    ksp = params.get("ksp_type", "preonly" if not nonlinear else "gmres")
+    # ... and ksp_type preonly + pc_type lu only when the user sets NEITHER: once pc_type is given, the Krylov
+    # method is left to PETSc, whose default is gmres (parity unpinned: the reference's own call sites always merge
+    # GMRES_PARAMS or LINEAR_SOLVER_PARAMS, so no golden shows these two defaults)
+    ksp = params.get("ksp_type", "gmres" if (nonlinear or "pc_type" in params) else "preonly")
     pc = params.get("pc_type", "lu" if ksp == "preonly" else "ilu")
     if pc == "fieldsplit" and params.get("pc_fieldsplit_type", "multiplicative") != "multiplicative":
         raise NotImplementedError("only pc_fieldsplit_type multiplicative is supported")
@@ -189,7 +193,11 @@ def _run(W, model_params: DPPParameters, bcs, solver_parameters: Dict, nonlinear
     x, sinfo, _ = ctx.solve(cfg, fetch=True)
     solution = fd.Function(W, x, name="dpp_solution")
     info.update(iterations=int(sinfo.iterations), inner_iterations=int(sinfo.inner_iterations),
-                residual=float(sinfo.resnorm), rhs_norm=float(sinfo.rhs_norm), timers=ctx.timers())
+                residual=float(sinfo.resnorm), rhs_norm=float(sinfo.rhs_norm), timers=ctx.timers(),
+                converged=bool(sinfo.converged), inner_failed=bool(sinfo.inner_failed))
+    if sinfo.inner_failed:
+        warnings.warn("a block solve (or the coarsest multigrid solve) stopped at its iteration limit or broke down: the "
+                      "preconditioner was inexact beyond its tolerance", stacklevel=3)
     if info.get("direct_equivalent"):
         return Solution(solution, 1, 0.0, info)
     return Solution(solution, int(sinfo.iterations), float(sinfo.resnorm), info)

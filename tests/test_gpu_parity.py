@@ -663,6 +663,56 @@ def test_full_size_properties_256cubed(gpu_ctx_factory, hexa, k2):
 
 
 @pytest.mark.gpu
+def test_config5_256cubed_tets_gmres_fieldsplit(gpu_ctx_factory, goldens):
+    """BASELINE config 5 as stated, at full size on one GPU: 256^3 Kuhn P1 tetrahedra (100.7 M cells), k1/k2 = 1e4
+    (k2 = 1e-4, eta = 100), GMRES + multiplicative field-split (reference src/perphil/solvers/parameters.py:30-37,
+    block LU -> multigrid-CG block solves).  Checks: 4 outer iterations like the reference at every size (golden G9,
+    notebooks/results-conforming-3d/petsc_profiling/petsc_perf_breakdown_3d.csv:39), the TRUE residual recomputed
+    through pph_spmv on the blocks <= 1e-8 ||F(u0)||, and agreement with the block-Picard solution to 1e-6."""
+    f = _ffi()
+    N = 256
+    Pp = o.Params(k1=1.0, k2=1e-4)
+    ctx = gpu_ctx_factory()
+    ctx.mesh_build(3, f.CELL_TET, N, N, N)
+    n = ctx.n
+    import perphil_amd.fd as fdm
+
+    mesh = fdm.UnitCubeMesh(N, N, N, hexahedral=False)
+    b = mesh.boundary_nodes()
+    e1, e2 = o.exact_pressures(mesh.node_coordinates(b), Pp)
+    ctx.set_dirichlet(0, b, e1)
+    ctx.set_dirichlet(1, b, e2)
+    ctx.assemble(Pp.k1, Pp.k2, Pp.beta, Pp.mu, monolithic=True)
+    g9 = {r["iterations"] for r in goldens["G6_G9_perf_3d_tets"] if r["approach"] == "Scale-Splitting GMRES"}
+    assert g9 == {4}            # the reference: 4 outer iterations at every mesh size
+    cfg = _cfg(ksp_type=f.KSP_GMRES, pc_type=f.PC_FIELDSPLIT, rtol=1e-8, atol=1e-12, inner_ksp_type=f.KSP_CG,
+               inner_pc_type=f.PC_MG, inner_rtol=1e-10, mg_smooth=2)
+    xs, info, hist = ctx.solve(cfg, hist_cap=16)
+    assert info.converged and info.iterations == 4
+    # PETSc's criterion (left preconditioning): the PRECONDITIONED residual dropped by ksp_rtol
+    assert info.resnorm <= 1e-8 * hist[0]
+    r, u0 = ctx.rhs()
+
+    def true_residual(x):
+        d = x - u0
+        res1 = r[:n] - ctx.spmv(f.MAT_A11, d[:n]) - ctx.spmv(f.MAT_A12, d[n:])
+        res2 = r[n:] - ctx.spmv(f.MAT_A21, d[:n]) - ctx.spmv(f.MAT_A22, d[n:])
+        return np.sqrt(res1 @ res1 + res2 @ res2)
+
+    # the unpreconditioned residual of that iterate sits a decade above (the block scaling at k1/k2 = 1e4 separates
+    # the two norms); one more decade of ksp_rtol brings the TRUE residual under 1e-8 ||F(u0)||
+    assert true_residual(xs) <= 1e-6 * np.linalg.norm(r)
+    cfg.rtol = 1e-10
+    xs, info, _ = ctx.solve(cfg)
+    assert info.converged and info.iterations <= 6
+    assert true_residual(xs) <= 1e-8 * np.linalg.norm(r)
+    xp, pinfo, _ = ctx.solve(_cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_MG, inner_rtol=1e-10,
+                                  inner_reduction=1e-1, inner_norm=1, mg_smooth=1, picard_rtol=1e-9, picard_max_it=200))
+    assert pinfo.converged
+    assert np.abs(xs - xp).max() <= 1e-6 * np.abs(xp).max()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("hexa,N,norm,red", [(True, 96, 0, 1e-2), (False, 48, 0, 1e-2), (True, 96, 1, 1e-1), (False, 48, 1, 1e-1),
                                              (True, 40, 1, 3e-2)])
 def test_hip_matches_cpu_port_mid_size(gpu_ctx_factory, hexa, N, norm, red):
@@ -786,7 +836,7 @@ def test_fused_assembly_equals_two_step(gpu_ctx_factory, dim, kind, nx, ny, nz, 
     exact = (tile == 0) or kind in (o.CELL_TRI, o.CELL_TET)
     for mode, (fused, keep) in {"two-step": (0, 1), "fused": (1, 1), "fused-nokeep": (1, 0)}.items():
         ctx = gpu_ctx_factory()
-        ctx.set_option("asm_tile", tile)
+        ctx.set_option("asm_tile", 2 * tile)   # 2: the tile kernel on every level, whatever its size
         ctx.set_option("asm_fused", fused)
         ctx.set_option("asm_keep_km", keep)
         ctx.mesh_build(dim, kind, nx, ny, nz)
@@ -893,8 +943,9 @@ def test_option_paths_agree(gpu_ctx_factory):
     f = _ffi()
     ref = None
     for opts in ({}, {"coarse_on_device": 0}, {"op_format": 0, "spmv_kernel": 17}, {"op_format": 0, "spmv_kernel": 1},
-                 {"asm_ring": 200}, {"op_format": 0}, {"mg_fused": 0}, {"use_graphs": 0}, {"fetch_spin": 0},
-                 {"mg_tail_rows": 50}, {"mg_tail_rows": 0}, {"asm_tile": 0}, {"sell_rpt": 1}, {"sell_group": 4}):
+                 {"asm_ring": 200}, {"op_format": 0}, {"mg_fused": 0}, {"use_graphs": 0}, {"use_graphs": 2}, {"fetch_spin": 0},
+                 {"mg_tail_rows": 50}, {"mg_tail_rows": 0}, {"asm_tile": 0}, {"asm_tile": 2}, {"sell_rpt": 1},
+                 {"sell_group": 4}):
         ctx, om, osys = _setup(gpu_ctx_factory, 3, o.CELL_HEX, 12, 8, 16)
         for k, v in opts.items():
             ctx.set_option(k, v)
@@ -1053,3 +1104,20 @@ def test_odd_mid_size_shapes_match_cpu_port(gpu_ctx_factory, hexa, shape):
     assert info.converged and sweeps > 0
     assert info.iterations == sweeps
     assert np.abs(xs - x_ref).max() <= 1e-7 * np.abs(x_ref).max()
+
+
+@pytest.mark.gpu
+def test_truncated_coarsest_solve_is_reported(gpu_ctx_factory):
+    """A mesh that coarsens only once (34 -> 17 cells: 18^3 = 5832 coarse rows, beyond the on-chip tail) solves its
+    coarsest level with the host-driven Jacobi-CG; when that solve stops at its iteration limit the cycle is a
+    truncated, non-stationary preconditioner: the solve must say so (pph_solve_info.inner_failed, a warning from
+    solve_dpp) instead of passing silently; with the default limit the flag stays clear."""
+    f = _ffi()
+    ctx, om, osys = _setup(gpu_ctx_factory, 3, o.CELL_HEX, 34, 34, 34, monolithic=False)
+    cfg = _cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_MG, inner_rtol=1e-10, inner_reduction=1e-1,
+               inner_norm=1, mg_smooth=1, picard_rtol=1e-8)
+    xs, info, _ = ctx.solve(cfg)
+    assert info.converged and not info.inner_failed
+    ctx.set_option("coarse_max_it", 2)
+    xs2, info2, _ = ctx.solve(cfg, raise_on_diverged=False)
+    assert info2.inner_failed

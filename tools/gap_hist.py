@@ -15,9 +15,11 @@ for lo, hi in ((0, 2), (2, 5), (5, 10), (10, 20), (20, 50), (50, 200), (200, 1e9
     g = [x for x in gaps if lo <= x < hi]
     print(f"  gaps {lo:>4}-{hi if hi < 1e9 else 'inf':>4} us: {len(g):6d}  sum {sum(g) / 1e3:8.2f} ms")
 from collections import Counter
-big = Counter()
+big, cnt = Counter(), Counter()
 for (a, b), x in zip(zip(rows, rows[1:]), gaps):
-    if x >= 10:
-        big[(a["Kernel_Name"].split("(")[0][-28:], b["Kernel_Name"].split("(")[0][-28:])] += x
-for k, v in big.most_common(12):
-    print(f"  {v / 1e3:7.2f} ms  after {k[0]:30s} before {k[1]}")
+    if 5 <= x < 200:      # inside the steps (longer gaps are host-side set-up between phases)
+        key = (a["Kernel_Name"].split("(")[0][-28:], b["Kernel_Name"].split("(")[0][-28:])
+        big[key] += x
+        cnt[key] += 1
+for k, v in big.most_common(14):
+    print(f"  {v / 1e3:7.2f} ms in {cnt[k]:5d} gaps (avg {v / cnt[k]:5.1f} us)  after {k[0]:30s} before {k[1]}")
