@@ -55,7 +55,9 @@ enum {
   PPH_PC_JACOBI = 1,      /* pc_type jacobi                                              */
   PPH_PC_BLOCK2 = 2,      /* 2x2 node-block Jacobi (both pressures of one node coupled)    */
   PPH_PC_FIELDSPLIT = 3,  /* pc_type fieldsplit, pc_fieldsplit_type multiplicative         */
-  PPH_PC_MG = 4           /* geometric multigrid V-cycle (scalar blocks; inside fieldsplit/Picard) */
+  PPH_PC_MG = 4,          /* geometric multigrid V-cycle (scalar blocks; inside fieldsplit/Picard) */
+  PPH_PC_ILU = 5          /* pc_type ilu, pc_factor_levels 0: ILU(0) in the natural row order, level-scheduled
+                           * (monolithic system, or the scalar blocks inside fieldsplit / Picard); single context */
 };
 
 typedef struct {
@@ -67,8 +69,8 @@ typedef struct {
   double atol;           /* ksp_atol                                                     */
   /* block solves of the field-split PC / Picard sweeps (fieldsplit_0_/fieldsplit_1_ options;
    * the reference's LU block solves become inner Krylov solves run to inner_rtol)          */
-  int32_t inner_ksp_type;
-  int32_t inner_pc_type;
+  int32_t inner_ksp_type;   /* PPH_KSP_PREONLY | PPH_KSP_CG | PPH_KSP_GMRES (restart 30, zero guess per solve) */
+  int32_t inner_pc_type;    /* PPH_PC_NONE | PPH_PC_JACOBI | PPH_PC_MG | PPH_PC_ILU */
   int32_t inner_max_it;
   int32_t picard;        /* 0: Krylov on the monolithic system; 1: block Picard (fixed-stress)
                           * outer loop per reference src/perphil/forms/dpp.py:196-203       */

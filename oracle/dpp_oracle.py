@@ -463,6 +463,61 @@ def fieldsplit_multiplicative_apply(A: sp.csr_matrix, n: int) -> Callable:
     return apply
 
 
+def ilu0(A: sp.csr_matrix) -> sp.csr_matrix:
+    """ILU(0) in the natural (row) ordering on the pattern of A, explicit zeros of the pattern kept (PETSc's
+    pc_type ilu with pc_factor_levels 0, reference src/perphil/solvers/parameters.py:27; PETSc's algorithm: IKJ
+    Gaussian elimination restricted to the pattern).  Returns one CSR holding the strict lower part of L (unit
+    diagonal implied) and U.  Plain Python loops over the rows: small systems only (oracle)."""
+    A = sp.csr_matrix(A).copy()
+    A.sort_indices()
+    ip, ix, v = A.indptr, A.indices, A.data.astype(np.float64).copy()
+    n = A.shape[0]
+    diag = np.full(n, -1, dtype=np.int64)
+    for i in range(n):
+        cols = ix[ip[i]:ip[i + 1]]
+        pos = np.searchsorted(cols, i)
+        assert pos < cols.size and cols[pos] == i, "ILU(0) needs a structurally non-zero diagonal"
+        diag[i] = ip[i] + pos
+    for i in range(n):
+        lo, hi = ip[i], ip[i + 1]
+        where = {int(c): lo + q for q, c in enumerate(ix[lo:hi])}
+        for kk in range(lo, diag[i]):
+            k = int(ix[kk])
+            piv = v[kk] / v[diag[k]]
+            v[kk] = piv
+            for jj in range(diag[k] + 1, ip[k + 1]):
+                pos = where.get(int(ix[jj]))
+                if pos is not None:
+                    v[pos] -= piv * v[jj]
+    return sp.csr_matrix((v, ix.copy(), ip.copy()), shape=A.shape)
+
+
+def ilu0_apply(A: sp.csr_matrix) -> Callable:
+    """z = (L U)^-1 r with the ILU(0) factors of A (forward / backward substitution)."""
+    LU = ilu0(A)
+    L = sp.tril(LU, k=-1, format="csr") + sp.identity(A.shape[0], format="csr")
+    U = sp.triu(LU, k=0, format="csr")
+    return lambda r: spla.spsolve_triangular(U, spla.spsolve_triangular(L, r, lower=True, unit_diagonal=True), lower=False)
+
+
+def fieldsplit_ilu_gmres_apply(A: sp.csr_matrix, n: int, rtol=1e-8, atol=1e-12, max_it=50000, preonly=False) -> Callable:
+    """pc_fieldsplit multiplicative whose block solves are GMRES + ILU(0) (FIELDSPLIT_GMRES_ILU_PARAMS,
+    parameters.py:50-57) or, with `preonly`, one ILU(0) application (iterative_bench.make_fieldsplit_params_with)."""
+    A = A.tocsr()
+    A11, A22, A21 = A[:n, :n].tocsr(), A[n:, n:].tocsr(), A[n:, :n]
+    p11, p22 = ilu0_apply(A11), ilu0_apply(A22)
+
+    def block(Ab, pb, r):
+        return pb(r) if preonly else gmres(Ab, r, pb, rtol=rtol, atol=atol, max_it=max_it).x
+
+    def apply(v):
+        z1 = block(A11, p11, v[:n])
+        z2 = block(A22, p22, v[n:] - A21 @ z1)
+        return np.concatenate([z1, z2])
+
+    return apply
+
+
 def solve_direct(sys_: System) -> np.ndarray:
     du = spla.spsolve(sys_.A.tocsc(), sys_.rhs)
     return sys_.u0 + du

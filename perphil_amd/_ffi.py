@@ -22,7 +22,7 @@ LIB_PATH = os.path.join(_HERE, "libperphil_hip.so")
 PPH_OK, PPH_ERR_INVALID, PPH_ERR_HIP, PPH_ERR_NOMEM, PPH_ERR_DIVERGED, PPH_ERR_COMM = 0, -1, -2, -3, -4, -5
 CELL_QUAD, CELL_TRI, CELL_HEX, CELL_TET = 0, 1, 2, 3
 KSP_PREONLY, KSP_CG, KSP_GMRES = 0, 1, 2
-PC_NONE, PC_JACOBI, PC_BLOCK2, PC_FIELDSPLIT, PC_MG = 0, 1, 2, 3, 4
+PC_NONE, PC_JACOBI, PC_BLOCK2, PC_FIELDSPLIT, PC_MG, PC_ILU = 0, 1, 2, 3, 4, 5
 MAT_MONO, MAT_K, MAT_M, MAT_A11, MAT_A22, MAT_A12, MAT_A21 = 0, 1, 2, 3, 4, 5, 6
 
 # every symbol include/perphil_hip.h declares (checked by tests/test_abi.py)

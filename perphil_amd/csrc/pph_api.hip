@@ -106,6 +106,7 @@ int pph_ctx_create(int device, pph_ctx** out) {
 
 // the assembled system is stale (parameters / boundary data changed): buffers are kept for re-use
 static void release_system(pph_ctx* ctx) {
+  for (auto& I : ctx->ilu) I.valid = false;   // factors of a stale matrix (the level structure survives)
   ctx->asm_ok = false;
   ctx->ell_ok = false;
   ctx->csr_ok = false;
@@ -120,6 +121,7 @@ static void free_system(pph_ctx* ctx) {
   ctx->rhs.release(); ctx->u0.release(); ctx->sol.release();
   ctx->mrowptr.release(); ctx->mcol.release(); ctx->mval.release();
   mg_release(ctx);
+  for (auto& I : ctx->ilu) ilu_release(I);
   release_system(ctx);
 }
 

@@ -207,6 +207,21 @@ struct GraphKey {
 };
 struct GraphEntry { GraphKey key; hipGraphExec_t exec = nullptr; uint64_t used = 0; };
 
+// ILU(0) factors of one CSR operator with the level schedule of its rows (pph_ilu.hip)
+struct IluData {
+  const int64_t* rowptr = nullptr;
+  const int32_t* col = nullptr;
+  int64_t nrows = 0, nnz = 0;
+  DevBuf<double> lu;             // strict lower part of L (unit diagonal implied) and U on the pattern of A
+  DevBuf<int64_t> diag;          // position of the diagonal entry of every row
+  DevBuf<int32_t> perm;          // rows sorted by level
+  DevBuf<double> y;
+  std::vector<int64_t> levptr;   // offsets of the non-empty levels in perm
+  bool struct_ok = false, valid = false;
+  uint64_t epoch = 0;
+};
+void ilu_release(IluData& I);
+
 struct pph_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -281,6 +296,7 @@ struct pph_ctx {
   int fetch_spin = 1;                   // 1: la_fetch publishes through the mapped mirror and polls (no stream synchronisation)
   std::vector<DevBuf<double>> work;     // named work vectors, grown on demand
   std::vector<MgLevel> mg;              // multigrid hierarchy (level 0 = fine)
+  IluData ilu[3];                       // ILU(0) factors: 0 monolithic system, 1 A11, 2 A22 (pc_type ilu)
   DevBuf<double> mg_w;                  // [2 l + which]: 1 / theta of the one-step Chebyshev smoother of level l (device copy:
                                         // kernels read it through a pointer, so captured graphs survive a re-assembly)
   std::vector<double> mg_w_host;
@@ -361,7 +377,10 @@ void la_spmv_dot(pph_ctx* ctx, const Csr& A, const double* x, double* y, int slo
 void la_publish(pph_ctx* ctx, int slot, int count);
 int la_wait_published(pph_ctx* ctx);
 // runs `body` (kernel launches on the context stream only) through a captured hipGraph cached under `key`
-int la_run_graph(pph_ctx* ctx, const GraphKey& key, const std::function<int()>& body);
+// (publishes: the body ends with one la_publish, which every replay repeats)
+int la_run_graph(pph_ctx* ctx, const GraphKey& key, const std::function<int()>& body, bool publishes = true);
+int ilu_factor(pph_ctx* ctx, IluData& I, const Csr& A);
+int ilu_apply(pph_ctx* ctx, IluData& I, const double* r, double* z);
 void la_release_graphs(pph_ctx* ctx);
 void la_set(pph_ctx* ctx, double* x, double v, int64_t n);
 void la_copy(pph_ctx* ctx, double* dst, const double* src, int64_t n);

@@ -1283,7 +1283,7 @@ void la_release_graphs(pph_ctx* ctx) {
   ctx->graphs.clear();
 }
 
-int la_run_graph(pph_ctx* ctx, const GraphKey& key, const std::function<int()>& body) {
+int la_run_graph(pph_ctx* ctx, const GraphKey& key, const std::function<int()>& body, bool publishes) {
   GraphEntry* hit = nullptr;
   for (auto& g : ctx->graphs)
     if (g.key == key) { hit = &g; break; }
@@ -1323,7 +1323,7 @@ int la_run_graph(pph_ctx* ctx, const GraphKey& key, const std::function<int()>& 
   }
   hit->used = ++ctx->graph_clock;
   // what the body would have counted on the host: one publication per replay
-  ++ctx->pub_seq;
+  if (publishes) ++ctx->pub_seq;
   PPH_HIP(ctx, hipGraphLaunch(hit->exec, ctx->stream));
   ctx->n_graph_launch++;
   return PPH_OK;

@@ -18,6 +18,7 @@ enum {
   W_R = 0, W_Z, W_P, W_Q, W_T,          // outer CG
   W_IR, W_IZ, W_IP, W_IQ,               // inner CG (block solves)
   W_GV, W_GW, W_GT,                     // GMRES basis / work
+  W_IGV, W_IGW, W_IGT, W_IGR,           // inner GMRES (block solves): basis / work / residual of a warm start
   W_FS1, W_FS2,                         // field-split temporaries
   W_DINV_M, W_DINV_1, W_DINV_2, W_BINV, // preconditioner data
   W_DU, W_PB, W_T12, W_TN, W_RHS1, W_R1, W_R2,  // Picard: correction, block rhs, coupling terms, block residuals
@@ -318,13 +319,19 @@ int pph_cg_jacobi(pph_ctx* ctx, const Csr& A, const double* b, double* x, const 
 // left-preconditioned restarted GMRES, classical Gram-Schmidt (one fused multi-dot + one multi-axpy
 // per step), Givens recurrence on the host
 // ------------------------------------------------------------------------------------------------
+// work vectors and reduction slots of one GMRES instance (the block solves run one inside the outer one's PC)
+struct GmresWs { int idV, idW, idT, sA, sMD; };
+static const GmresWs GMRES_OUTER = {W_GV, W_GW, W_GT, S_A, S_MDOT};
+static const GmresWs GMRES_INNER = {W_IGV, W_IGW, W_IGT, S_INNER, S_MDOT + 64};
+
 static int gmres_solve(pph_ctx* ctx, const ApplyFn& Aop, int64_t n, const double* b, double* x, const ApplyFn& pc,
                        int restart, double rtol, double atol, int max_it, KspOut* out, double* hist, int hist_cap,
-                       Seg sg) {
+                       Seg sg, const GmresWs& ws = GMRES_OUTER) {
+  const int S_A = ws.sA, S_MDOT = ws.sMD;   // (shadow the outer instance's slots)
   double *V, *w, *t;
-  PPH_TRY(work(ctx, W_GV, (size_t)(restart + 1) * (size_t)n, &V));
-  PPH_TRY(work(ctx, W_GW, (size_t)n, &w));
-  PPH_TRY(work(ctx, W_GT, (size_t)n, &t));
+  PPH_TRY(work(ctx, ws.idV, (size_t)(restart + 1) * (size_t)n, &V));
+  PPH_TRY(work(ctx, ws.idW, (size_t)n, &w));
+  PPH_TRY(work(ctx, ws.idT, (size_t)n, &t));
   auto apply_pc = [&](const double* in, double* o) {
     if (pc) pc(in, o); else la_copy(ctx, o, in, n);
   };
@@ -470,8 +477,15 @@ struct BlockSolver {
       }
     } else if (cfg->inner_pc_type == PPH_PC_MG) {
       PPH_TRY(mg_setup(ctx));
+    } else if (cfg->inner_pc_type == PPH_PC_ILU) {
+      // ILU(0) of both diagonal blocks (CSR values needed: the fused assembly keeps stencil-ELL copies only)
+      PPH_TRY(pph_ensure_csr_blocks(ctx));
+      A[0] = block_csr(ctx, 0);
+      A[1] = block_csr(ctx, 1);
+      for (int f = 0; f < 2; ++f)
+        if (!ctx->ilu[1 + f].valid) PPH_TRY(ilu_factor(ctx, ctx->ilu[1 + f], A[f]));
     } else if (cfg->inner_pc_type != PPH_PC_NONE) {
-      pph_set_error(ctx, "inner pc_type %d not supported for block solves (none, jacobi, mg)", cfg->inner_pc_type);
+      pph_set_error(ctx, "inner pc_type %d not supported for block solves (none, jacobi, mg, ilu)", cfg->inner_pc_type);
       return PPH_ERR_INVALID;
     }
     return PPH_OK;
@@ -490,12 +504,37 @@ struct BlockSolver {
     ApplyFn pc;
     const int ns = cfg->mg_smooth > 0 ? cfg->mg_smooth : 2;
     if (cfg->inner_pc_type == PPH_PC_MG) pc = [this, which, ns](const double* in, double* o) { mg_vcycle(ctx, which, in, o, ns); };
+    if (cfg->inner_pc_type == PPH_PC_ILU)
+      pc = [this, which](const double* in, double* o) { if (ilu_apply(ctx, ctx->ilu[1 + which], in, o) < 0) failed = true; };
     KspOut ko;
     if (cfg->inner_ksp_type == PPH_KSP_PREONLY) {
       // one application of the inner preconditioner
       if (dinv[which]) la_pointwise_mult(ctx, z, dinv[which], rhs, n);
       else if (pc) pc(rhs, z);
       else la_copy(ctx, z, rhs, n);
+      return PPH_OK;
+    }
+    if (cfg->inner_ksp_type == PPH_KSP_GMRES) {
+      // restarted GMRES on the block (FIELDSPLIT_GMRES*_PARAMS); a warm start solves for the correction
+      const Csr& Ab = A[which];
+      ApplyFn Aop = [this, &Ab](const double* xx, double* yy) { la_spmv(ctx, Ab, xx, yy); };
+      ApplyFn pcj = pc;
+      if (dinv[which]) { const double* dj = dinv[which]; pcj = [this, dj, n](const double* in, double* o) { la_pointwise_mult(ctx, o, dj, in, n); }; }
+      const Seg sg = pph_owned_seg(Ab.geom, n);
+      if (!warm) {
+        PPH_TRY(gmres_solve(ctx, Aop, n, rhs, z, pcj, 30, cfg->inner_rtol, cfg->inner_atol, cfg->inner_max_it, &ko, nullptr, 0,
+                            sg, GMRES_INNER));
+      } else {
+        double* rr;
+        PPH_TRY(work(ctx, W_IGR, (size_t)n, &rr));
+        la_spmv_resid(ctx, Ab, z, rhs, rr);
+        PPH_TRY(gmres_solve(ctx, Aop, n, rr, zz, pcj, 30, cfg->inner_rtol, cfg->inner_atol, cfg->inner_max_it, &ko, nullptr, 0,
+                            sg, GMRES_INNER));
+        la_axpy(ctx, z, 1.0, zz, n);
+      }
+      last_resid = nullptr;
+      total_its += ko.its;
+      if (ko.breakdown || !ko.converged) failed = true;
       return PPH_OK;
     }
     MgPre pre;
@@ -525,14 +564,17 @@ static int validate_cfg(pph_ctx* ctx, const pph_solver_cfg* cfg) {
   PPH_REQUIRE(ctx, cfg != nullptr, "solver cfg is NULL");
   PPH_REQUIRE(ctx, cfg->ksp_type >= PPH_KSP_PREONLY && cfg->ksp_type <= PPH_KSP_GMRES, "unknown ksp_type %d",
               cfg->ksp_type);
-  PPH_REQUIRE(ctx, cfg->pc_type >= PPH_PC_NONE && cfg->pc_type <= PPH_PC_MG, "unknown pc_type %d", cfg->pc_type);
+  PPH_REQUIRE(ctx, cfg->pc_type >= PPH_PC_NONE && cfg->pc_type <= PPH_PC_ILU, "unknown pc_type %d", cfg->pc_type);
+  PPH_REQUIRE(ctx, !(cfg->pc_type == PPH_PC_ILU || cfg->inner_pc_type == PPH_PC_ILU) || ctx->world == 1,
+              "pc_type ilu eliminates sequentially along the global row order: single context only");
   PPH_REQUIRE(ctx, cfg->restart >= 1 && cfg->restart <= 30, "GMRES restart %d outside [1,30]", cfg->restart);
   PPH_REQUIRE(ctx, cfg->max_it >= 0 && cfg->inner_max_it >= 0 && cfg->picard_max_it >= 0, "negative max_it");
   PPH_REQUIRE(ctx, cfg->rtol >= 0 && cfg->atol >= 0 && cfg->inner_rtol >= 0 && cfg->inner_atol >= 0, "negative tolerance");
   PPH_REQUIRE(ctx, cfg->inner_reduction >= 0 && cfg->inner_reduction < 1, "inner_reduction must be in [0,1)");
   PPH_REQUIRE(ctx, cfg->inner_norm == 0 || cfg->inner_norm == 1, "inner_norm must be 0 (preconditioned) or 1 (unpreconditioned)");
-  PPH_REQUIRE(ctx, cfg->inner_ksp_type == PPH_KSP_PREONLY || cfg->inner_ksp_type == PPH_KSP_CG,
-              "inner ksp_type %d not supported (preonly, cg)", cfg->inner_ksp_type);
+  PPH_REQUIRE(ctx, cfg->inner_ksp_type == PPH_KSP_PREONLY || cfg->inner_ksp_type == PPH_KSP_CG ||
+                       cfg->inner_ksp_type == PPH_KSP_GMRES,
+              "inner ksp_type %d not supported (preonly, cg, gmres)", cfg->inner_ksp_type);
   if (!cfg->picard) {
     PPH_REQUIRE(ctx, cfg->pc_type != PPH_PC_MG, "pc_type mg applies to the scalar blocks: use it as inner_pc_type");
     PPH_REQUIRE(ctx, ctx->mono_ok, "monolithic Krylov solve needs pph_assemble_dpp(..., monolithic=1)");
@@ -662,6 +704,10 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
       hipLaunchKernelGGL(k_block2_build, dim3(grid), dim3(256), 0, ctx->stream, ctx->mesh.rowptr.p, ctx->mesh.col.p,
                          ctx->A11.p, ctx->A22.p, ctx->A12.p, ctx->A21p(), n, binv);
       pc = [&, binv](const double* in, double* o) { la_block2_apply(ctx, o, binv, in, n); };
+    } else if (cfg->pc_type == PPH_PC_ILU) {
+      // ILU(0) of the monolithic field-major CSR (GMRES_ILU_PARAMS, parameters.py:27)
+      if (!ctx->ilu[0].valid) PPH_TRY(ilu_factor(ctx, ctx->ilu[0], A));
+      pc = [&](const double* in, double* o) { if (ilu_apply(ctx, ctx->ilu[0], in, o) < 0) bs.failed = true; };
     } else if (cfg->pc_type == PPH_PC_FIELDSPLIT) {
       // multiplicative: z1 = A11^-1 r1 ; z2 = A22^-1 (r2 - A21 z1)   (parameters.py:30-37)
       PPH_TRY(bs.setup());

@@ -15,8 +15,10 @@ pc_type fieldsplit (multiplicative)     same; block solves = inner CG with multi
 ksp_type preonly + pc_type lu (MUMPS)   "direct-equivalent": field-split GMRES with multigrid-CG
                                         block solves run to 1e-13 relative residual; reports
                                         iteration_number 1 and residual 0.0 like PETSc's preonly
-pc_type ilu                             no GPU counterpart: substituted (with a warning) by 2x2
-                                        node-block Jacobi (monolithic) or multigrid (blocks)
+pc_type ilu (pc_factor_levels 0)        ILU(0) in the natural row order, factorisation and triangular solves
+                                        level-scheduled on the device (levels i + 2j + 4k of the lexicographic
+                                        numbering), monolithic system or field-split / Picard blocks;
+                                        block ksp_type gmres = restarted GMRES(30) on the block
 snes_type ngs | nrichardson             block Picard (fixed-stress) sweeps per dpp_delayed_form
                                         (dpp.py:196-203); the reference's PETSc secant-NGS history is
                                         not reproduced, the fixed point is
@@ -73,18 +75,15 @@ def _inner_cfg(cfg: _ffi.SolverCfg, subs: List[Dict], notes: List[str]) -> None:
         cfg.inner_pc_type, cfg.inner_rtol = _ffi.PC_MG, 1e-12
         notes.append("block LU -> CG + geometric multigrid, rtol 1e-12")
         return
-    if p == "ilu":
-        warnings.warn("pc_type ilu has no GPU counterpart; block solves use CG + geometric multigrid", stacklevel=4)
-        notes.append("block ILU -> geometric multigrid")
-        p = "mg"
-    if p not in ("mg", "jacobi", "none"):
+    if p not in ("mg", "jacobi", "none", "ilu"):
         raise NotImplementedError(f"fieldsplit block pc_type {p!r} is not supported (lu, ilu, mg, jacobi, none)")
-    cfg.inner_pc_type = {"mg": _ffi.PC_MG, "jacobi": _ffi.PC_JACOBI, "none": _ffi.PC_NONE}[p]
+    cfg.inner_pc_type = {"mg": _ffi.PC_MG, "jacobi": _ffi.PC_JACOBI, "none": _ffi.PC_NONE, "ilu": _ffi.PC_ILU}[p]
     if k == "preonly":
         cfg.inner_ksp_type = _ffi.KSP_PREONLY
-    elif k in ("gmres", "cg", "fgmres"):
-        if k != "cg":
-            notes.append(f"block {k} -> CG (blocks are SPD)")
+    elif k in ("gmres", "fgmres"):
+        cfg.inner_ksp_type = _ffi.KSP_GMRES      # restarted GMRES(30) on the block, as stated
+    elif k == "cg":
+        cfg.inner_ksp_type = _ffi.KSP_CG
     else:
         raise NotImplementedError(f"fieldsplit block ksp_type {k!r} is not supported")
     cfg.inner_rtol = min(rtols) if rtols else 1e-5  # PETSc default ksp_rtol
@@ -153,15 +152,12 @@ def translate_options(params: Dict, nonlinear: bool = False) -> Tuple[_ffi.Solve
                     "fgmres": _ffi.KSP_GMRES}.get(ksp, -1)
     if cfg.ksp_type < 0:
         raise NotImplementedError(f"ksp_type {ksp!r} is not supported (preonly, cg, gmres)")
-    if pc == "ilu":
-        warnings.warn("pc_type ilu has no GPU counterpart; using the 2x2 node-block Jacobi preconditioner",
-                      stacklevel=3)
-        notes.append("ILU(0) -> 2x2 node-block Jacobi")
-        pc = "pph_block2"
+    if pc == "ilu" and int(params.get("pc_factor_levels", 0)) != 0:
+        raise NotImplementedError("only pc_factor_levels 0 (ILU(0)) is supported")
     if pc in ("lu", "cholesky"):
         raise NotImplementedError("pc_type lu is only supported with ksp_type preonly (direct-equivalent solve)")
     table = {"none": _ffi.PC_NONE, "jacobi": _ffi.PC_JACOBI, "pph_block2": _ffi.PC_BLOCK2,
-             "fieldsplit": _ffi.PC_FIELDSPLIT}
+             "fieldsplit": _ffi.PC_FIELDSPLIT, "ilu": _ffi.PC_ILU}
     if pc not in table:
         raise NotImplementedError(f"pc_type {pc!r} is not supported")
     cfg.pc_type = table[pc]

@@ -84,7 +84,9 @@ def test_option_translation():
     cfg, _ = translate_options({**sp.GMRES_PARAMS, **sp.FIELDSPLIT_LU_PARAMS})
     assert cfg.pc_type == _ffi.PC_FIELDSPLIT and cfg.inner_pc_type == _ffi.PC_MG and cfg.inner_rtol == 1e-12
     cfg, _ = translate_options({**sp.GMRES_PARAMS, **sp.FIELDSPLIT_GMRES_PARAMS})
-    assert cfg.inner_pc_type == _ffi.PC_NONE and cfg.inner_ksp_type == _ffi.KSP_CG and cfg.inner_rtol == 1e-8
+    assert cfg.inner_pc_type == _ffi.PC_NONE and cfg.inner_ksp_type == _ffi.KSP_GMRES and cfg.inner_rtol == 1e-8
+    cfg, _ = translate_options({**sp.GMRES_PARAMS, **sp.FIELDSPLIT_GMRES_ILU_PARAMS})
+    assert cfg.inner_pc_type == _ffi.PC_ILU and cfg.inner_ksp_type == _ffi.KSP_GMRES
     cfg, _ = translate_options(sp.PICARD_LU_SOLVER_PARAMS, nonlinear=True)
     assert cfg.picard == 1 and cfg.picard_rtol == 1e-8 and cfg.picard_atol == 1e-12
     # flattened fieldsplit keys (iterative_bench.make_fieldsplit_params_with)
@@ -99,9 +101,23 @@ def test_option_translation():
     assert cfg.inner_norm == 0 and cfg.inner_reduction == 0.0
     with pytest.raises(NotImplementedError):
         translate_options({**sp.PICARD_MG_SOLVER_PARAMS, "fieldsplit_0_ksp_norm_type": "natural"}, nonlinear=True)
-    with pytest.warns(UserWarning):
-        cfg, info = translate_options(sp.GMRES_ILU_PARAMS)
-    assert cfg.pc_type == _ffi.PC_BLOCK2 and any("ILU" in n for n in info["notes"])
+    cfg, info = translate_options(sp.GMRES_ILU_PARAMS)          # the stated preconditioner, no substitution
+    assert cfg.pc_type == _ffi.PC_ILU and cfg.ksp_type == _ffi.KSP_GMRES
+    with pytest.raises(NotImplementedError):
+        translate_options({**sp.GMRES_ILU_PARAMS, "pc_factor_levels": 1})
+    # Firedrake's defaults: ksp_rtol 1e-7 unless given; a user-set pc_type without ksp_type leaves the Krylov
+    # method to PETSc (gmres); neither set = direct solve (parity of these two defaults is unpinned)
+    cfg, info = translate_options({"pc_type": "jacobi"})
+    assert cfg.ksp_type == _ffi.KSP_GMRES and cfg.pc_type == _ffi.PC_JACOBI and cfg.rtol == 1e-7
+    cfg, info = translate_options(sp.FIELDSPLIT_LU_PARAMS)
+    assert cfg.ksp_type == _ffi.KSP_GMRES and cfg.pc_type == _ffi.PC_FIELDSPLIT and not info["direct_equivalent"]
+    cfg, info = translate_options({"ksp_type": "cg", "pc_type": "jacobi"})
+    assert cfg.rtol == 1e-7
+    from perphil_amd import iterative_bench as ib
+    cfg, _ = translate_options(ib.make_fieldsplit_params_with("ilu"))
+    assert (cfg.ksp_type, cfg.inner_ksp_type, cfg.inner_pc_type) == (_ffi.KSP_GMRES, _ffi.KSP_PREONLY, _ffi.PC_ILU)
+    cfg, _ = translate_options(ib.make_fieldsplit_params_with("lu"))
+    assert cfg.inner_pc_type == _ffi.PC_MG and cfg.inner_rtol == 1e-12
     with pytest.raises(NotImplementedError):
         translate_options({"ksp_type": "bcgs", "pc_type": "none"})
     with pytest.raises(NotImplementedError):
