@@ -365,7 +365,8 @@ def main():
         "config": {
             "workload": f"3D UnitCube {N}^3 Q1, two-pressure DPP (k1=1, k2=1e-2, beta=mu=1), manufactured Dirichlet data, "
                         f"assemble + block Picard (fixed-stress) to snes_rtol 1e-8 (true residual), warm-started block solves = "
-                        f"CG + geometric multigrid (Chebyshev-Jacobi V({args.smooth},{args.smooth})) on CSR blocks, each to a "
+                        f"CG + geometric multigrid (Chebyshev-Jacobi V({args.smooth},{args.smooth})) on {'stencil-ELL' if sell else 'CSR'} "
+                        f"scalar blocks, each to a "
                         f"reduction of the {'unpreconditioned' if args.inner_norm else 'preconditioned'} residual by "
                         f"{args.inner_reduction:g} (or rtol {args.inner_rtol:g})",
             "preallocation": "outside the timed step: mesh, sparsity pattern, boundary-data upload (setup_ms) and the first "

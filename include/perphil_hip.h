@@ -229,16 +229,28 @@ int pph_comm_stats(pph_ctx* ctx, int64_t* halo_exchanges, int64_t* allreduces, i
  * fine-level operators only (rows >= nodes of the mesh), i.e. without the coarser multigrid levels. */
 int pph_get_timers(pph_ctx* ctx, double* out, int n);
 /* tuning / profiling switches (no reference counterpart; defaults in brackets):
- *   "spmv_kernel" [3]    SpMV variant kept for A/B measurement, "spmv_lanes" [0 = automatic,
- *                        4..64 lanes per CSR row], "spmv_blocks" [0 = 1024 workgroups], "spmv_bench_mode" [0]
+ *   "op_format" [1]      operator format of the scalar blocks inside block solves / Picard sweeps: 1 stencil-ELL
+ *                        (values only, val[slot][row]; written directly by the fused assembly), 0 CSR.  pph_get_csr /
+ *                        pph_spmv export CSR either way (converted on demand).
+ *   "sell_rpt" [2], "sell_blocks" [2048], "sell_group" [1]   stencil-ELL SpMV: rows per thread, grid cap, XCD chunk group
+ *   "spmv_kernel" [3]    CSR SpMV variant; values other than 3 need a library built with EXPERIMENTS=1
+ *   "spmv_lanes" [0 = automatic, 4..64 lanes per CSR row], "spmv_blocks" [0 = 1024 workgroups], "spmv_bench_mode" [0]
  *   "time_spmv" [0]      1: bracket every SpMV launch of a solve with a HIP event pair on the context stream
- *   "asm_kernel" [2]     multilinear assembly: 0 cell-centred scatter-add (atomics), 1 node-centred gather, 2 two-pass
+ *   "asm_kernel" [2]     multilinear assembly: 0 cell-centred scatter-add (atomics), 1 node-centred gather, 2 fused kernels
+ *   "asm_tile" [1]       fused multilinear assembly: 1 single-pass tile kernel on levels of at least
+ *                        "asm_tile_min_nodes" [500000] nodes (2: on every level), 0 two-pass (element rows + gather)
  *   "asm_fused" [1]      the node-centred pass writes the eliminated blocks, lifted right-hand side and smoother
  *                        diagonal directly; 0: K and M first, then separate elimination kernels
  *   "asm_keep_km" [0]    1: the fused pass also stores K and M (otherwise they are integrated on demand)
  *   "invalidate_KM"      drop the integrated K and M so that the next assemble integrates again
+ *   "mg_fused" [1]       V(1,1) on stencil-ELL levels: fused smoother / transfer kernels + on-chip tail; 0 general cycle
+ *   "mg_tail_rows" [5000] levels with at most min(this, 1024) rows join the single-workgroup tail of the cycle
+ *   "coarse_max_it" [500] iteration limit of the coarsest-level Jacobi-CG (reported through inner_failed)
  *   "mg_fp32" [0], "mg_replicate_below" [40000 nodes], "coarse_on_device" [1]   multigrid: fp32 copies of the V-cycle
- *                        operators, replication threshold of coarse levels on slabs, coarsest solve in one workgroup */
+ *                        operators (CSR only), replication threshold of coarse levels on slabs, coarsest solve on the device
+ *   "fetch_spin" [1]     reduction results reach the host through a mapped mirror the host polls; 0: D2H copy + sync
+ *   "use_graphs" [1]     Krylov iteration bodies / ILU sweeps replayed from captured hipGraphs on small systems (2: always)
+ *   "device_scalars" [0] 1: the device-scalar CG branch also over the callback transport (tests) */
 int pph_set_option(pph_ctx* ctx, const char* name, double value);
 
 #ifdef __cplusplus

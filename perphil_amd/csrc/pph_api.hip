@@ -432,7 +432,9 @@ int pph_spmv_bench(pph_ctx* ctx, int which, int reps, double* avg_ms) {
   Csr A;
   PPH_TRY(select_csr(ctx, which, &A));
   A.lanes = pph_pick_lanes(ctx, A.nnz, A.nrows);
+#ifdef PPH_EXPERIMENTS
   if (ctx->spmv_kernel == 16) return la_padded_experiment(ctx, A, reps, avg_ms);  // padded-row experiment
+#endif
   PPH_TRY(attach_sell(ctx, which, &A));
   DevBuf<double> x, y;
   PPH_TRY(x.alloc(ctx, (size_t)A.nrows));
@@ -493,7 +495,12 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
   }
   if (!strcmp(name, "spmv_kernel")) {
     const int v = (int)value;
+#ifdef PPH_EXPERIMENTS
     PPH_REQUIRE(ctx, (v >= 0 && v <= 17), "spmv_kernel: 0 vector, 1 vector+preload, 2 LDS stream, 3 aligned-wide (default), 4 LDS-transposed, 5-7 multi-row, 8 aligned-wide XCD-contiguous, 10 no-gather probe");
+#else
+    PPH_REQUIRE(ctx, v == 3, "spmv_kernel %d is an A/B variant: this library was built without PPH_EXPERIMENTS "
+                             "(make -C perphil_amd/csrc EXPERIMENTS=1)", v);
+#endif
     ctx->spmv_kernel = v;
     return PPH_OK;
   }

@@ -51,65 +51,6 @@ __device__ inline double group8_sum(double v) {
   return v;
 }
 
-// ------------------------------------------------------------------------------------------------
-// CSR SpMV, G lanes per row, persistent workgroups, XCD-aware chunk order:
-// workgroups with equal (blockIdx % 8) share an XCD (and its 4 MiB L2), so each XCD walks one
-// contiguous eighth of the rows and the x entries its rows gather stay in that XCD's L2.
-// ------------------------------------------------------------------------------------------------
-template <int G, bool DOT, int U>
-__global__ __launch_bounds__(256) void k_spmv(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                              const double* __restrict__ val, const double* __restrict__ x,
-                                              const double* __restrict__ bvec, double* __restrict__ y, int64_t nrows,
-                                              double* __restrict__ part) {
-  constexpr int RPB = 256 / G;  // rows per workgroup per step
-  __shared__ double lds[4];
-  const int sub = threadIdx.x % G;
-  const int grp = threadIdx.x / G;
-  const int64_t nchunks = (nrows + RPB - 1) / RPB;
-  const int xcd = blockIdx.x & 7;
-  const int bx = blockIdx.x >> 3;
-  const int bpx = gridDim.x >> 3;  // launcher keeps gridDim.x a multiple of 8
-  const int64_t cpx = (nchunks + 7) >> 3;
-  const int64_t c_begin = (int64_t)xcd * cpx;
-  const int64_t c_end = (c_begin + cpx < nchunks) ? c_begin + cpx : nchunks;
-  double acc = 0.0;
-  for (int64_t ch = c_begin + bx; ch < c_end; ch += bpx) {
-    const int64_t row = ch * RPB + grp;
-    double sum = 0.0;
-    if (row < nrows) {
-      const int64_t s = rowptr[row], e = rowptr[row + 1];
-      if (U == 1) {
-        for (int64_t k = s + sub; k < e; k += G) sum += val[k] * x[col[k]];
-      } else {
-        // issue U column + U value loads per lane before the first gather (more bytes in flight per wave)
-        for (int64_t k0 = s + sub; k0 < e; k0 += (int64_t)U * G) {
-          int32_t c[U];
-          double v[U];
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int64_t k = k0 + (int64_t)u * G;
-            const bool ok = k < e;
-            c[u] = ok ? col[k] : 0;
-            v[u] = ok ? val[k] : 0.0;
-          }
-#pragma unroll
-          for (int u = 0; u < U; ++u) sum += v[u] * x[c[u]];
-        }
-      }
-    }
-#pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, G);
-    if (sub == 0 && row < nrows) {
-      y[row] = bvec ? bvec[row] - sum : sum;
-      if (DOT) acc += sum * x[row];
-    }
-  }
-  if (DOT) {
-    acc = block_sum(acc, lds);
-    if (threadIdx.x == 0) part[blockIdx.x] = acc;
-  }
-}
-
 // Aligned-wide CSR-vector variant: every lane reads 4 consecutive non-zeros per step with 16-byte loads
 // (one dwordx4 of columns, two dwordx4 of values) from the row start rounded DOWN to a multiple of 4;
 // entries outside [rowptr[row], rowptr[row+1]) are masked.  8-byte and 4-byte-per-lane streams reach a
@@ -216,502 +157,6 @@ __global__ __launch_bounds__(256) void k_spmv_wide(const int64_t* __restrict__ r
   }
 }
 
-// Software-pipelined aligned-wide variant.  A row's critical path in k_spmv_wide is three dependent memory
-// latencies (row pointers -> matrix entries -> x gather) that only occupancy hides.  Here every lane group
-// keeps two stages in flight: the row pointers of chunk i+2 and the first 4 G matrix entries of chunk i+1 are
-// requested before chunk i's gather starts, so the gather of one row overlaps the matrix stream of the next
-// and the only exposed latency per row is the gather itself.  Rows longer than one 4 G-entry step finish
-// with unpipelined steps (none for the 27- / 15-entry stencil rows of this path).
-template <int G, bool DOT, typename VT = double>
-__global__ __launch_bounds__(256) void k_spmv_pipe(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                   const VT* __restrict__ val, const double* __restrict__ x,
-                                                   const double* __restrict__ bvec, double* __restrict__ y,
-                                                   int64_t nrows, double* __restrict__ part) {
-  constexpr int RPB = 256 / G;
-  __shared__ double lds[4];
-  const int sub = threadIdx.x % G;
-  const int grp = threadIdx.x / G;
-  const int64_t nchunks = (nrows + RPB - 1) / RPB;
-  const int64_t step = gridDim.x;
-  auto load_ptr = [&](int64_t chunk, int64_t& ps, int64_t& pe) {
-    const int64_t r = chunk * RPB + grp;
-    ps = pe = 0;
-    if (chunk < nchunks && r < nrows) {
-      ps = rowptr[r];
-      pe = rowptr[r + 1];
-    }
-  };
-  auto load_mat = [&](int64_t base, int64_t pe, int4& c, double2& a01, double2& a23) {
-    c = make_int4(0, 0, 0, 0);
-    a01 = a23 = make_double2(0.0, 0.0);
-    if (base < pe) {
-      c = *reinterpret_cast<const int4*>(col + base);
-      if constexpr (sizeof(VT) == 4) {
-        const float4 vf = *reinterpret_cast<const float4*>(val + base);
-        a01 = make_double2((double)vf.x, (double)vf.y);
-        a23 = make_double2((double)vf.z, (double)vf.w);
-      } else {
-        a01 = *reinterpret_cast<const double2*>(reinterpret_cast<const double*>(val) + base);
-        a23 = *reinterpret_cast<const double2*>(reinterpret_cast<const double*>(val) + base + 2);
-      }
-    }
-  };
-  auto consume = [&](int64_t base, int64_t s, int64_t e, const int4& c, const double2& a01, const double2& a23) -> double {
-    const bool k0 = base >= s && base < e, k1 = base + 1 >= s && base + 1 < e, k2 = base + 2 >= s && base + 2 < e,
-               k3 = base + 3 >= s && base + 3 < e;
-    const double x0 = x[k0 ? c.x : 0], x1 = x[k1 ? c.y : 0], x2 = x[k2 ? c.z : 0], x3 = x[k3 ? c.w : 0];
-    return (k0 ? a01.x : 0.0) * x0 + (k1 ? a01.y : 0.0) * x1 + (k2 ? a23.x : 0.0) * x2 + (k3 ? a23.y : 0.0) * x3;
-  };
-  double acc = 0.0;
-  int64_t ch = blockIdx.x;
-  int64_t s, e, ns, ne;
-  int4 c;
-  double2 v01, v23;
-  load_ptr(ch, s, e);
-  load_mat((s & ~(int64_t)3) + 4 * sub, e, c, v01, v23);
-  load_ptr(ch + step, ns, ne);
-  for (; ch < nchunks; ch += step) {
-    const int64_t row = ch * RPB + grp;
-    int4 nc;
-    double2 nv01, nv23;
-    load_mat((ns & ~(int64_t)3) + 4 * sub, ne, nc, nv01, nv23);   // chunk i+1: matrix entries
-    int64_t nns, nne;
-    load_ptr(ch + 2 * step, nns, nne);                            // chunk i+2: row pointers
-    double bv = 0.0, xr = 0.0;
-    if (row < nrows) {
-      if (bvec) bv = bvec[row];
-      if (DOT) xr = x[row];
-    }
-    int64_t base = (s & ~(int64_t)3) + 4 * sub;
-    double sum = 0.0;
-    if (base < e) sum = consume(base, s, e, c, v01, v23);
-    for (base += 4 * G; base < e; base += 4 * G) {                // long rows: remaining steps, unpipelined
-      int4 c2;
-      double2 a01, a23;
-      load_mat(base, e, c2, a01, a23);
-      sum += consume(base, s, e, c2, a01, a23);
-    }
-    if constexpr (G == 8) {
-      sum = group8_sum(sum);
-    } else {
-#pragma unroll
-      for (int o = G / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, G);
-    }
-    if (sub == 0 && row < nrows) {
-      y[row] = bvec ? bv - sum : sum;
-      if (DOT) acc += sum * xr;
-    }
-    s = ns; e = ne; c = nc; v01 = nv01; v23 = nv23; ns = nns; ne = nne;
-  }
-  if (DOT) {
-    acc = block_sum(acc, lds);
-    if (threadIdx.x == 0) part[blockIdx.x] = acc;
-  }
-}
-
-// Row-block streaming variant (one wavefront per workgroup): R consecutive rows own a contiguous range of
-// non-zeros; the wave streams that range with fully contiguous 16-byte loads (columns straight to registers
-// for the x gather, values through LDS because their 2-per-lane layout differs from the columns' 4-per-lane
-// layout), parks the products in LDS and lets two lanes per row sum them.  No masked over-read beyond the
-// 4-alignment of the block start, no per-row pointer dependency in front of the loads.
-// Needs R * max_row + 3 <= 1024.
-template <int R, bool DOT>
-__global__ __launch_bounds__(64) void k_spmv_block(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                   const double* __restrict__ val, const double* __restrict__ x,
-                                                   const double* __restrict__ bvec, double* __restrict__ y,
-                                                   int64_t nrows, double* __restrict__ part) {
-  constexpr int SLOTS = 1024;
-  constexpr int LPR = 64 / R;  // lanes per row in the summation phase (R = 32: 2, R = 16: 4)
-  __shared__ __attribute__((aligned(16))) double sv[SLOTS + 8];
-  __shared__ __attribute__((aligned(16))) double sp[SLOTS + 8];
-  const int lane = threadIdx.x;
-  const int64_t nchunks = (nrows + R - 1) / R;
-  double acc = 0.0;
-  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-    const int64_t r0 = ch * R;
-    const int64_t rend = (r0 + R < nrows) ? r0 + R : nrows;
-    const int64_t s = rowptr[r0], e = rowptr[rend];
-    const int64_t s4 = s & ~(int64_t)3;
-    const int span = (int)(e - s4);
-    const int lead = (int)(s - s4);
-    // my row's range (summation phase), requested early
-    const int rl = lane / LPR, hl = lane % LPR;
-    const int64_t myrow = r0 + rl;
-    int b = 0, en = 0;
-    if (myrow < rend) {
-      b = (int)(rowptr[myrow] - s4);
-      en = (int)(rowptr[myrow + 1] - s4);
-    }
-    int4 c[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int k = 4 * (lane + 64 * t);
-      c[t] = (k < span) ? *reinterpret_cast<const int4*>(col + s4 + k) : make_int4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int k = 2 * (lane + 64 * u);
-      if (k < span) *reinterpret_cast<double2*>(sv + k) = *reinterpret_cast<const double2*>(val + s4 + k);
-    }
-    double xs[4][4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int k = 4 * (lane + 64 * t);
-      const bool v0 = k >= lead && k < span, v1 = k + 1 >= lead && k + 1 < span, v2 = k + 2 >= lead && k + 2 < span,
-                 v3 = k + 3 >= lead && k + 3 < span;
-      xs[t][0] = v0 ? x[c[t].x] : 0.0;
-      xs[t][1] = v1 ? x[c[t].y] : 0.0;
-      xs[t][2] = v2 ? x[c[t].z] : 0.0;
-      xs[t][3] = v3 ? x[c[t].w] : 0.0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int k = 4 * (lane + 64 * t);
-      if (k < span) {
-        const double2 a01 = *reinterpret_cast<const double2*>(sv + k);
-        const double2 a23 = *reinterpret_cast<const double2*>(sv + k + 2);
-        *reinterpret_cast<double2*>(sp + k) = make_double2(a01.x * xs[t][0], a01.y * xs[t][1]);
-        *reinterpret_cast<double2*>(sp + k + 2) = make_double2(a23.x * xs[t][2], a23.y * xs[t][3]);
-      }
-    }
-    __syncthreads();
-    double sum = 0.0;
-    for (int i = b + hl; i < en; i += LPR) sum += sp[i];
-#pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, LPR);
-    if (hl == 0 && myrow < rend) {
-      y[myrow] = bvec ? bvec[myrow] - sum : sum;
-      if (DOT) acc += sum * x[myrow];
-    }
-    __syncthreads();
-  }
-  if (DOT) {
-    acc = wave_sum(acc);
-    if (lane == 0) part[blockIdx.x] = acc;
-  }
-}
-
-// Variant of the aligned-wide kernel in which every load INSTRUCTION of a lane group is contiguous: the group's
-// 32 slots are covered by two column loads (8 B per lane) and two value loads (16 B per lane) over slots
-// [2 sub, 2 sub + 1] and [16 + 2 sub, 17 + 2 sub] instead of one 16-byte column load and two interleaved value
-// loads per lane (which touch every 128-byte line of the values twice).
-template <bool DOT>
-__global__ __launch_bounds__(256) void k_spmv_wide2(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                    const double* __restrict__ val, const double* __restrict__ x,
-                                                    const double* __restrict__ bvec, double* __restrict__ y,
-                                                    int64_t nrows, double* __restrict__ part) {
-  constexpr int G = 8, RPB = 256 / G;
-  __shared__ double lds[4];
-  const int sub = threadIdx.x % G;
-  const int grp = threadIdx.x / G;
-  const int64_t nchunks = (nrows + RPB - 1) / RPB;
-  double acc = 0.0;
-  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-    const int64_t row = ch * RPB + grp;
-    double sum = 0.0;
-    if (row < nrows) {
-      const int64_t s = rowptr[row], e = rowptr[row + 1];
-      for (int64_t g0 = (s & ~(int64_t)3); g0 < e; g0 += 32) {
-        const int64_t ba = g0 + 2 * sub, bb = g0 + 16 + 2 * sub;
-        const bool la = ba < e, lb = bb < e;
-        int2 ca = make_int2(0, 0), cb = make_int2(0, 0);
-        double2 va = make_double2(0.0, 0.0), vb = make_double2(0.0, 0.0);
-        if (la) { ca = *reinterpret_cast<const int2*>(col + ba); va = *reinterpret_cast<const double2*>(val + ba); }
-        if (lb) { cb = *reinterpret_cast<const int2*>(col + bb); vb = *reinterpret_cast<const double2*>(val + bb); }
-        const bool k0 = ba >= s && ba < e, k1 = ba + 1 >= s && ba + 1 < e, k2 = bb >= s && bb < e, k3 = bb + 1 >= s && bb + 1 < e;
-        const double x0 = x[k0 ? ca.x : 0], x1 = x[k1 ? ca.y : 0], x2 = x[k2 ? cb.x : 0], x3 = x[k3 ? cb.y : 0];
-        sum += (k0 ? va.x : 0.0) * x0 + (k1 ? va.y : 0.0) * x1 + (k2 ? vb.x : 0.0) * x2 + (k3 ? vb.y : 0.0) * x3;
-      }
-    }
-    sum = group8_sum(sum);
-    if (sub == 0 && row < nrows) {
-      y[row] = bvec ? bvec[row] - sum : sum;
-      if (DOT) acc += sum * x[row];
-    }
-  }
-  if (DOT) {
-    acc = block_sum(acc, lds);
-    if (threadIdx.x == 0) part[blockIdx.x] = acc;
-  }
-}
-
-// Experiment: rows padded to a multiple of 4 entries with explicit zeros (column = the row itself) and
-// row starts aligned to 4: no masks at all in the inner loop, every 16-byte load is aligned inside its row.
-template <int G, bool DOT>
-__global__ __launch_bounds__(256) void k_spmv_padded(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                     const double* __restrict__ val, const double* __restrict__ x,
-                                                     const double* __restrict__ bvec, double* __restrict__ y,
-                                                     int64_t nrows, double* __restrict__ part) {
-  constexpr int RPB = 256 / G;
-  __shared__ double lds[4];
-  const int sub = threadIdx.x % G;
-  const int grp = threadIdx.x / G;
-  const int64_t nchunks = (nrows + RPB - 1) / RPB;
-  double acc = 0.0;
-  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-    const int64_t row = ch * RPB + grp;
-    double sum = 0.0;
-    if (row < nrows) {
-      const int64_t s = rowptr[row], e = rowptr[row + 1];
-      for (int64_t base = s + 4 * sub; base < e; base += 4 * G) {
-        const int4 c = *reinterpret_cast<const int4*>(col + base);
-        const double2 v01 = *reinterpret_cast<const double2*>(val + base);
-        const double2 v23 = *reinterpret_cast<const double2*>(val + base + 2);
-        sum += v01.x * x[c.x] + v01.y * x[c.y] + v23.x * x[c.z] + v23.y * x[c.w];
-      }
-    }
-    if constexpr (G == 8) sum = group8_sum(sum);
-    else {
-#pragma unroll
-      for (int o = G / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, G);
-    }
-    if (sub == 0 && row < nrows) {
-      y[row] = bvec ? bvec[row] - sum : sum;
-      if (DOT) acc += sum * x[row];
-    }
-  }
-  if (DOT) {
-    acc = block_sum(acc, lds);
-    if (threadIdx.x == 0) part[blockIdx.x] = acc;
-  }
-}
-
-__global__ void k_pad_fill(const int64_t* __restrict__ rp, const int32_t* __restrict__ col, const double* __restrict__ val,
-                           const int64_t* __restrict__ rpp, int32_t* __restrict__ colp, double* __restrict__ valp,
-                           int64_t nrows) {
-  for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < nrows; row += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t s = rp[row], e = rp[row + 1], sp = rpp[row], ep = rpp[row + 1];
-    for (int64_t k = 0; k < ep - sp; ++k) {
-      const bool real = s + k < e;
-      colp[sp + k] = real ? col[s + k] : (int32_t)row;
-      valp[sp + k] = real ? val[s + k] : 0.0;
-    }
-  }
-}
-
-// Aligned-wide CSR-vector kernel with UR rows in flight per lane group: the dependent chain
-// rowptr -> (columns, values) -> x gather is latency-bound when a wave carries one row per group
-// (about 3 KB in flight), so every group walks UR row-chunks at once: all row pointers are requested
-// first, then all 16-byte column/value loads, then all gathers.
-template <int G, bool DOT, int UR>
-__global__ __launch_bounds__(256) void k_spmv_wide_u(const int64_t* __restrict__ rowptr,
-                                                     const int32_t* __restrict__ col,
-                                                     const double* __restrict__ val, const double* __restrict__ x,
-                                                     const double* __restrict__ bvec, double* __restrict__ y,
-                                                     int64_t nrows, double* __restrict__ part) {
-  constexpr int RPB = 256 / G;
-  __shared__ double lds[4];
-  const int sub = threadIdx.x % G;
-  const int grp = threadIdx.x / G;
-  const int64_t nchunks = (nrows + RPB - 1) / RPB;
-  double acc = 0.0;
-  for (int64_t ch0 = blockIdx.x; ch0 < nchunks; ch0 += (int64_t)UR * gridDim.x) {
-    int64_t row[UR], s[UR], e[UR], base[UR];
-    double sum[UR], bv[UR], xr[UR];   // epilogue operands requested with the row pointers (see k_spmv_wide)
-#pragma unroll
-    for (int u = 0; u < UR; ++u) {
-      const int64_t ch = ch0 + (int64_t)u * gridDim.x;
-      row[u] = ch * RPB + grp;
-      const bool ok = ch < nchunks && row[u] < nrows;
-      if (!ok) row[u] = -1;
-      s[u] = ok ? rowptr[row[u]] : 0;
-      e[u] = ok ? rowptr[row[u] + 1] : 0;
-      bv[u] = (ok && bvec) ? bvec[row[u]] : 0.0;
-      xr[u] = (ok && DOT) ? x[row[u]] : 0.0;
-      sum[u] = 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < UR; ++u) base[u] = (s[u] & ~(int64_t)3) + 4 * sub;
-    bool more = false;
-#pragma unroll
-    for (int u = 0; u < UR; ++u) more = more || (base[u] < e[u]);
-    while (more) {
-      int4 c[UR];
-      double2 va[UR], vb[UR];
-#pragma unroll
-      for (int u = 0; u < UR; ++u) {
-        const bool act = base[u] < e[u];
-        const int64_t b = act ? base[u] : 0;
-        c[u] = *reinterpret_cast<const int4*>(col + b);
-        va[u] = *reinterpret_cast<const double2*>(val + b);
-        vb[u] = *reinterpret_cast<const double2*>(val + b + 2);
-      }
-      double xg[UR][4];
-      bool kk[UR][4];
-#pragma unroll
-      for (int u = 0; u < UR; ++u) {
-        const int64_t b = base[u];
-        kk[u][0] = b >= s[u] && b < e[u];
-        kk[u][1] = b + 1 >= s[u] && b + 1 < e[u];
-        kk[u][2] = b + 2 >= s[u] && b + 2 < e[u];
-        kk[u][3] = b + 3 >= s[u] && b + 3 < e[u];
-        xg[u][0] = x[kk[u][0] ? c[u].x : 0];
-        xg[u][1] = x[kk[u][1] ? c[u].y : 0];
-        xg[u][2] = x[kk[u][2] ? c[u].z : 0];
-        xg[u][3] = x[kk[u][3] ? c[u].w : 0];
-      }
-      more = false;
-#pragma unroll
-      for (int u = 0; u < UR; ++u) {
-        sum[u] += (kk[u][0] ? va[u].x : 0.0) * xg[u][0] + (kk[u][1] ? va[u].y : 0.0) * xg[u][1] +
-                  (kk[u][2] ? vb[u].x : 0.0) * xg[u][2] + (kk[u][3] ? vb[u].y : 0.0) * xg[u][3];
-        base[u] += 4 * G;
-        more = more || (base[u] < e[u]);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < UR; ++u) {
-      double t = sum[u];
-#pragma unroll
-      for (int o = G / 2; o > 0; o >>= 1) t += __shfl_down(t, o, G);
-      if (sub == 0 && row[u] >= 0) {
-        y[row[u]] = bvec ? bv[u] - t : t;
-        if (DOT) acc += t * xr[u];
-      }
-    }
-  }
-  if (DOT) {
-    acc = block_sum(acc, lds);
-    if (threadIdx.x == 0) part[blockIdx.x] = acc;
-  }
-}
-
-// LDS-transposed CSR variant ("stream in by non-zero, consume by row"): a 64-lane workgroup (one wavefront)
-// takes RB = 64/T consecutive rows, copies their contiguous column/value ranges into LDS with 16-byte
-// coalesced loads, then every lane walks ONE row (T = 1; T lanes share a row for long rows) out of LDS.
-// Consecutive lanes hold consecutive rows, so for a stencil-like matrix the x gathers of one wave
-// instruction fall on a few consecutive cache lines instead of one line per lane group, and y is written
-// coalesced without any cross-lane reduction.  Needs max_row <= 32 T (at most SPMV_LDS_N entries per step).
-#define SPMV_LDS_N 2048
-template <int T, bool DOT>
-__global__ __launch_bounds__(64) void k_spmv_lds(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                 const double* __restrict__ val, const double* __restrict__ x,
-                                                 const double* __restrict__ bvec, double* __restrict__ y,
-                                                 int64_t nrows, double* __restrict__ part) {
-  constexpr int RB = 64 / T;
-  __shared__ __attribute__((aligned(16))) int32_t sc[SPMV_LDS_N + 8];
-  __shared__ __attribute__((aligned(16))) double sv[SPMV_LDS_N + 8];
-  const int lane = threadIdx.x;
-  const int64_t nchunks = (nrows + RB - 1) / RB;
-  double acc = 0.0;
-  for (int64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-    const int64_t R0 = ch * RB;
-    const int64_t Rend = (R0 + RB < nrows) ? R0 + RB : nrows;
-    const int64_t s = rowptr[R0];
-    const int64_t s4 = s & ~(int64_t)3;
-    const int span = (int)(rowptr[Rend] - s4);
-    for (int i = lane * 4; i < span; i += 256) {
-      const int4 c = *reinterpret_cast<const int4*>(col + s4 + i);
-      const double2 v01 = *reinterpret_cast<const double2*>(val + s4 + i);
-      const double2 v23 = *reinterpret_cast<const double2*>(val + s4 + i + 2);
-      *reinterpret_cast<int4*>(sc + i) = c;
-      *reinterpret_cast<double2*>(sv + i) = v01;
-      *reinterpret_cast<double2*>(sv + i + 2) = v23;
-    }
-    __syncthreads();
-    const int rl = lane / T, j = lane % T;
-    const int64_t row = R0 + rl;
-    double sum = 0.0;
-    if (row < Rend) {
-      const int b = (int)(rowptr[row] - s4), e = (int)(rowptr[row + 1] - s4);
-      const int per = (e - b + T - 1) / T;
-      const int b2 = b + j * per;
-      const int e2 = (b2 + per < e) ? b2 + per : e;
-      for (int i = b2; i < e2; i += 8) {
-        double xv[8], vv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const bool ok = i + u < e2;
-          const int32_t c = ok ? sc[i + u] : 0;
-          vv[u] = ok ? sv[i + u] : 0.0;
-          xv[u] = x[c];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) sum += vv[u] * xv[u];
-      }
-    }
-#pragma unroll
-    for (int o = T / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, T);
-    if (j == 0 && row < Rend) {
-      y[row] = bvec ? bvec[row] - sum : sum;
-      if (DOT) acc += sum * x[row];
-    }
-    __syncthreads();
-  }
-  if (DOT) {
-    acc = wave_sum(acc);
-    if (lane == 0) part[blockIdx.x] = acc;
-  }
-}
-
-// CSR-stream variant: a workgroup takes RB = 256/T consecutive rows, streams their (contiguous) column
-// and value ranges with fully coalesced loads, parks the products in LDS and lets T lanes per row sum
-// them.  Requires max row length <= 8 T (launcher picks T), i.e. at most SPMV_LB products per chunk.
-#define SPMV_LB 2048
-template <int T, bool DOT>
-__global__ __launch_bounds__(256) void k_spmv_stream(const int64_t* __restrict__ rowptr,
-                                                     const int32_t* __restrict__ col,
-                                                     const double* __restrict__ val, const double* __restrict__ x,
-                                                     const double* __restrict__ bvec, double* __restrict__ y,
-                                                     int64_t nrows, double* __restrict__ part) {
-  constexpr int RB = 256 / T;
-  constexpr int U = SPMV_LB / 256;
-  __shared__ double prod[SPMV_LB];
-  __shared__ int64_t rp[RB + 1];
-  __shared__ double lds[4];
-  const int tid = threadIdx.x;
-  const int64_t nchunks = (nrows + RB - 1) / RB;
-  const int xcd = blockIdx.x & 7;
-  const int bx = blockIdx.x >> 3;
-  const int bpx = gridDim.x >> 3;
-  const int64_t cpx = (nchunks + 7) >> 3;
-  const int64_t c_begin = (int64_t)xcd * cpx;
-  const int64_t c_end = (c_begin + cpx < nchunks) ? c_begin + cpx : nchunks;
-  double acc = 0.0;
-  for (int64_t ch = c_begin + bx; ch < c_end; ch += bpx) {
-    const int64_t R0 = ch * RB;
-    if (tid <= RB) {
-      const int64_t r = R0 + tid;
-      rp[tid] = rowptr[r < nrows ? r : nrows];
-    }
-    __syncthreads();
-    const int64_t s = rp[0];
-    const int cnt = (int)(rp[RB] - s);
-    int32_t c[U];
-    double v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int k = tid + u * 256;
-      const bool ok = k < cnt;
-      c[u] = ok ? col[s + k] : 0;
-      v[u] = ok ? val[s + k] : 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int k = tid + u * 256;
-      if (k < cnt) prod[k] = v[u] * x[c[u]];
-    }
-    __syncthreads();
-    const int rl = tid / T, j = tid % T;
-    const int b = (int)(rp[rl] - s), e = (int)(rp[rl + 1] - s);
-    double sum = 0.0;
-    for (int i = b + j; i < e; i += T) sum += prod[i];
-#pragma unroll
-    for (int o = T / 2; o > 0; o >>= 1) sum += __shfl_down(sum, o, T);
-    const int64_t row = R0 + rl;
-    if (j == 0 && row < nrows) {
-      y[row] = bvec ? bvec[row] - sum : sum;
-      if (DOT) acc += sum * x[row];
-    }
-    __syncthreads();
-  }
-  if (DOT) {
-    acc = block_sum(acc, lds);
-    if (threadIdx.x == 0) part[blockIdx.x] = acc;
-  }
-}
-
 __global__ __launch_bounds__(256) void k_reduce_final(const double* __restrict__ part, int nblocks,
                                                       double* __restrict__ out, const double* copy_src = nullptr,
                                                       double* copy_dst = nullptr) {
@@ -738,6 +183,10 @@ static int stream_T(int max_row) {
   while (8 * T < max_row && T < 64) T *= 2;
   return T;
 }
+
+#ifdef PPH_EXPERIMENTS
+#include "pph_spmv_experiments.inc"   // the A/B kernel variants of DESIGN.md section 4 (not part of the shipped library)
+#endif
 
 // returns the grid used (number of partial sums written when DOT)
 // jdinv != null (stencil-ELL operators only): y = x + jw * jdinv .* (bvec - A x), one damped-Jacobi sweep out of place
@@ -794,88 +243,21 @@ static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const doub
     if (A.nrows >= ctx->mesh.n) { ctx->n_spmv_fine++; ctx->spmv_bytes_fine += bytes_per_nnz * (double)A.nnz + 20.0 * (double)A.nrows; }
     return grid;
   }
-  const bool can_stream = A.max_row > 0 && A.max_row <= 8 * 64;
-  if (ctx->spmv_kernel == 2 && can_stream) {
-    const int T = stream_T(A.max_row);
-    grid = spmv_grid(ctx, A.nrows, 256 / T);
-#define PPH_STREAM_CASE(TT)                                                                                       \
-  case TT:                                                                                                        \
-    hipLaunchKernelGGL((k_spmv_stream<TT, DOT>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, \
-                       bvec, y, A.nrows, part);                                                                   \
-    break;
-    switch (T) {
-      PPH_STREAM_CASE(4)
-      PPH_STREAM_CASE(8)
-      PPH_STREAM_CASE(16)
-      PPH_STREAM_CASE(32)
-      default:
-        hipLaunchKernelGGL((k_spmv_stream<64, DOT>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x,
-                           bvec, y, A.nrows, part);
-    }
-#undef PPH_STREAM_CASE
-  } else if (ctx->spmv_kernel == 4 && A.max_row > 0 && A.max_row <= 32 * 4) {
-    const int T = A.max_row <= 32 ? 1 : (A.max_row <= 64 ? 2 : 4);
-    const int64_t nchunks = ceil_div64(A.nrows, 64 / T);
-    grid = (int)(nchunks < SPMV_MAX_BLOCKS ? nchunks : SPMV_MAX_BLOCKS);
-    if (T == 1)
-      hipLaunchKernelGGL((k_spmv_lds<1, DOT>), dim3(grid), dim3(64), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
-    else if (T == 2)
-      hipLaunchKernelGGL((k_spmv_lds<2, DOT>), dim3(grid), dim3(64), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
-    else
-      hipLaunchKernelGGL((k_spmv_lds<4, DOT>), dim3(grid), dim3(64), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
-  } else if (ctx->spmv_kernel >= 5 && ctx->spmv_kernel <= 7) {
-    grid = spmv_grid(ctx, A.nrows, 256 / 8);
-    if (ctx->spmv_kernel == 5)
-      hipLaunchKernelGGL((k_spmv_wide_u<8, DOT, 2>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
-    else if (ctx->spmv_kernel == 6)
-      hipLaunchKernelGGL((k_spmv_wide_u<8, DOT, 4>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
-    else
-      hipLaunchKernelGGL((k_spmv_wide_u<4, DOT, 4>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
-  } else if (ctx->spmv_kernel == 14 && A.max_row > 0 && A.max_row * 16 + 3 <= 1024) {
-    const bool r32 = A.max_row * 32 + 3 <= 1024;
-    const int64_t nchunks = ceil_div64(A.nrows, r32 ? 32 : 16);
-    const int64_t cap = (int64_t)(ctx->spmv_blocks >= 8 ? ctx->spmv_blocks : SPMV_DEF_BLOCKS) * 4;  // one wave per workgroup
-    grid = (int)(nchunks < cap ? nchunks : cap);
-    if (r32)
-      hipLaunchKernelGGL((k_spmv_block<32, DOT>), dim3(grid), dim3(64), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
-    else
-      hipLaunchKernelGGL((k_spmv_block<16, DOT>), dim3(grid), dim3(64), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
-  } else if (ctx->spmv_kernel == 17) {
-    if (A.max_row > 0 && A.max_row + 3 <= 16) {
-      grid = spmv_grid(ctx, A.nrows, 256 / 4);
-      hipLaunchKernelGGL((k_spmv_pipe<4, DOT>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
-    } else {
-      grid = spmv_grid(ctx, A.nrows, 256 / 8);
-      hipLaunchKernelGGL((k_spmv_pipe<8, DOT>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
-    }
-  } else if (ctx->spmv_kernel == 15) {
-    grid = spmv_grid(ctx, A.nrows, 256 / 8);
-    hipLaunchKernelGGL((k_spmv_wide2<DOT>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
-  } else if (ctx->spmv_kernel == 9) {
-    grid = spmv_grid(ctx, A.nrows, 256 / 8);
-    hipLaunchKernelGGL((k_spmv_wide<8, DOT, 3>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
-  } else if (ctx->spmv_kernel == 10) {
-    grid = spmv_grid(ctx, A.nrows, 256 / 8);
-    hipLaunchKernelGGL((k_spmv_wide<8, DOT, 1>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
-  } else if (ctx->spmv_kernel == 12) {
-    grid = spmv_grid(ctx, A.nrows, 256 / 8);
-    hipLaunchKernelGGL((k_spmv_wide<8, DOT, 4>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
-  } else if (ctx->spmv_kernel == 13) {
-    grid = spmv_grid(ctx, A.nrows, 256 / 8);
-    hipLaunchKernelGGL((k_spmv_wide<8, DOT, 5>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, y, A.nrows, part);
-  } else if (ctx->spmv_kernel == 3 || ctx->spmv_kernel == 8 || ctx->spmv_kernel == 11) {
-    // lanes per row: one 4-wide step covers 4 G entries; rows of up to 29 entries fit G = 8
+  if (ctx->spmv_kernel != 3) {
+#ifdef PPH_EXPERIMENTS
+    grid = spmv_dispatch_experiment<DOT>(ctx, A, x, bvec, y, part);   // A/B variants (pph_spmv_experiments.inc)
+#else
+    grid = -1;   // pph_set_option refuses other variants in a build without PPH_EXPERIMENTS
+#endif
+  } else {
+    // aligned-wide CSR-vector kernel.  Lanes per row: one 4-wide step covers 4 G entries; rows of up to 29 entries fit G = 8
     int G = ctx->spmv_lanes_override > 0 ? ctx->spmv_lanes_override : (A.max_row > 0 && A.max_row + 3 <= 16 ? 4 : 8);
     if (G != 4 && G != 8 && G != 16 && G != 32 && G != 64) G = 8;
     grid = spmv_grid(ctx, A.nrows, 256 / G);
 #define PPH_WIDE_CASE(GG)                                                                                       \
   case GG:                                                                                                      \
-    if (ctx->spmv_kernel == 8)                                                                                  \
-      hipLaunchKernelGGL((k_spmv_wide<GG, DOT, 0>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, \
-                         bvec, y, A.nrows, part);                                                               \
-    else                                                                                                        \
-      hipLaunchKernelGGL((k_spmv_wide<GG, DOT, 2>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, \
-                         bvec, y, A.nrows, part);                                                               \
+    hipLaunchKernelGGL((k_spmv_wide<GG, DOT, 2>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, \
+                       bvec, y, A.nrows, part);                                                                 \
     break;
     switch (G) {
       PPH_WIDE_CASE(4)
@@ -885,27 +267,6 @@ static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const doub
       PPH_WIDE_CASE(64)
     }
 #undef PPH_WIDE_CASE
-  } else {
-    int G = A.lanes;
-    if (G != 4 && G != 8 && G != 16 && G != 32 && G != 64) G = 8;
-    grid = spmv_grid(ctx, A.nrows, 256 / G);
-#define PPH_SPMV_CASE(GG)                                                                                          \
-  case GG:                                                                                                         \
-    if (ctx->spmv_kernel == 0)                                                                                     \
-      hipLaunchKernelGGL((k_spmv<GG, DOT, 1>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, \
-                         y, A.nrows, part);                                                                        \
-    else                                                                                                           \
-      hipLaunchKernelGGL((k_spmv<GG, DOT, 4>), dim3(grid), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, x, bvec, \
-                         y, A.nrows, part);                                                                        \
-    break;
-    switch (G) {
-      PPH_SPMV_CASE(4)
-      PPH_SPMV_CASE(8)
-      PPH_SPMV_CASE(16)
-      PPH_SPMV_CASE(32)
-      PPH_SPMV_CASE(64)
-    }
-#undef PPH_SPMV_CASE
   }
   if (ev) (void)hipEventRecord(ev->e1, ctx->stream);
   ctx->n_spmv[variant]++;
@@ -1392,37 +753,3 @@ int la_fetch(pph_ctx* ctx, int slot, int count) {
   if (ctx->comm_status != PPH_OK) { ctx->err = ctx->comm_error; return ctx->comm_status; }
   return PPH_OK;
 }
-
-// builds the padded copy of A (host-side row-pointer scan: experiment only) and times `reps` launches
-int la_padded_experiment(pph_ctx* ctx, const Csr& A, int reps, double* avg_ms) {
-  std::vector<int64_t> rp((size_t)A.nrows + 1), rpp((size_t)A.nrows + 1);
-  PPH_HIP(ctx, hipMemcpy(rp.data(), A.rowptr, sizeof(int64_t) * rp.size(), hipMemcpyDeviceToHost));
-  rpp[0] = 0;
-  for (int64_t r = 0; r < A.nrows; ++r) rpp[(size_t)r + 1] = rpp[(size_t)r] + ((rp[(size_t)r + 1] - rp[(size_t)r] + 3) / 4) * 4;
-  const int64_t nnzp = rpp[(size_t)A.nrows];
-  DevBuf<int64_t> drpp;
-  DevBuf<int32_t> colp;
-  DevBuf<double> valp, x, y;
-  PPH_TRY(drpp.alloc(ctx, rpp.size()));
-  PPH_TRY(colp.alloc(ctx, (size_t)nnzp));
-  PPH_TRY(valp.alloc(ctx, (size_t)nnzp));
-  PPH_TRY(x.alloc(ctx, (size_t)A.nrows));
-  PPH_TRY(y.alloc(ctx, (size_t)A.nrows));
-  PPH_HIP(ctx, hipMemcpy(drpp.p, rpp.data(), sizeof(int64_t) * rpp.size(), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_pad_fill, dim3(2048), dim3(256), 0, ctx->stream, A.rowptr, A.col, A.val, drpp.p, colp.p, valp.p, A.nrows);
-  hipLaunchKernelGGL(k_set, dim3(2048), dim3(256), 0, ctx->stream, x.p, 1.0, A.nrows);
-  const int grid = spmv_grid(ctx, A.nrows, 32);
-  for (int i = 0; i < 5 + reps; ++i) {
-    if (i == 5) PPH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL((k_spmv_padded<8, false>), dim3(grid), dim3(256), 0, ctx->stream, drpp.p, colp.p, valp.p, x.p,
-                       (const double*)nullptr, y.p, A.nrows, (double*)nullptr);
-  }
-  PPH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-  PPH_HIP(ctx, hipEventSynchronize(ctx->ev1));
-  float ms = 0.f;
-  PPH_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
-  *avg_ms = ms / reps;
-  drpp.release(); colp.release(); valp.release(); x.release(); y.release();
-  return PPH_OK;
-}
-

@@ -764,7 +764,7 @@ def test_hip_matches_cpu_port_mid_size(gpu_ctx_factory, hexa, N, norm, red):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kern", [3, 17])
+@pytest.mark.parametrize("kern", [3])
 def test_spmv_long_rows_and_residual_forms(gpu_ctx_factory, kern):
     """Monolithic 3D rows (up to 54 entries) take more than one 32-entry step of the aligned-wide kernels; the
     CG and residual entry points (fused p.Ap, b - Ax) are covered through a Jacobi-CG solve against the oracle."""
@@ -945,13 +945,12 @@ def test_config2_64cubed_monolithic_cg(gpu_ctx_factory, pc):
 @pytest.mark.gpu
 def test_option_paths_agree(gpu_ctx_factory):
     """Alternative code paths kept behind pph_set_option give the same solve: host-driven coarsest CG vs the
-    on-chip tail of the cycle, CSR operators (and two of their SpMV kernels) vs the stencil-ELL default, the general
+    on-chip tail of the cycle, CSR operators vs the stencil-ELL default, the general
     kernel-per-operation V-cycle vs the fused one, eager vs graph-replayed iterations, synchronising vs polled
     fetches, two-pass vs tile assembly."""
     f = _ffi()
     ref = None
-    for opts in ({}, {"coarse_on_device": 0}, {"op_format": 0, "spmv_kernel": 17}, {"op_format": 0, "spmv_kernel": 1},
-                 {"asm_ring": 200}, {"op_format": 0}, {"mg_fused": 0}, {"use_graphs": 0}, {"use_graphs": 2}, {"fetch_spin": 0},
+    for opts in ({}, {"coarse_on_device": 0}, {"asm_ring": 200}, {"op_format": 0}, {"mg_fused": 0}, {"use_graphs": 0}, {"use_graphs": 2}, {"fetch_spin": 0},
                  {"mg_tail_rows": 50}, {"mg_tail_rows": 0}, {"asm_tile": 0}, {"asm_tile": 2}, {"sell_rpt": 1},
                  {"sell_group": 4}):
         ctx, om, osys = _setup(gpu_ctx_factory, 3, o.CELL_HEX, 12, 8, 16)
