@@ -305,7 +305,8 @@ def main():
     sell = not any(kv.split("=")[0] == "op_format" and float(kv.split("=")[1]) == 0 for kv in args.set)
     tr, launches, ms, byts = instrumented_step()
     achieved = (byts / 1e9) / (ms / 1e3) if ms > 0 else 0.0
-    S = 27
+    sym = world == 1 and not any(kv.split("=")[0] == "sell_sym" and float(kv.split("=")[1]) == 0 for kv in args.set)
+    S = 14 if sym else 27        # stored slots per row: diagonal + upper half of the 27-point stencil, or all of it
     sell_bytes = 8.0 * S * ctx.n + 16.0 * ctx.n
     csr_bytes = 12.0 * ctx.nnzb + 20.0 * ctx.n
     # HBM traffic of the same kernel mix from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB), taken
@@ -317,21 +318,40 @@ def main():
         try:
             with open(pmc_file) as f:
                 pmc = json.load(f)
-            if int(pmc.get("launches_per_step", -1)) == int(launches) and pmc.get("kernel") == "k_spmv_sell":
+            if (int(pmc.get("launches_per_step", -1)) == int(launches) and pmc.get("kernel") == "k_spmv_sell"
+                    and bool(pmc.get("symmetric", False)) == bool(sym)):
                 traffic = pmc.get("traffic_bytes_per_launch")
         except (OSError, ValueError):
             traffic = None
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-        "kernel": ("k_spmv_sell<kind,mode,2> (stencil-ELL SpMV, 8 B per stored entry, all multigrid levels of one step)"
+        "kernel": ((f"k_spmv_sell<kind,mode,2,{'sym' if sym else 'full'}> (stencil-ELL SpMV, "
+                    + ("symmetric storage: 14 of 27 slot arrays, every value serves two rows, " if sym else "")
+                    + "8 B per stored entry, all multigrid levels of one step)")
                    if sell else "k_spmv_wide<8,*,2> (aligned-wide CSR-vector SpMV, all multigrid levels of one step)"),
-        "format": "stencil-ELL" if sell else "CSR",
+        "format": ("stencil-ELL (symmetric)" if sym else "stencil-ELL") if sell else "CSR",
         "launches_per_step": int(launches), "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
         "algorithmic_bytes_per_launch": round(byts / max(launches, 1), 0),
         "fine_level": fine_block(sell_bytes if sell else csr_bytes),
         "fine_level_in_solver": in_solver(tr),
     }
+    if sell and sym and not args.skip_csr:
+        # the same step on full (27-slot) stencil-ELL storage: untimed, for the record
+        ctx.set_option("sell_sym", 0)
+        step()
+        tf, lf, msf, bf = instrumented_step()
+        t0f = time.perf_counter()
+        step()
+        ctx.synchronize()
+        full_ms = 1e3 * (time.perf_counter() - t0f)
+        af = (bf / 1e9) / (msf / 1e3) if msf > 0 else 0.0
+        full_bytes = 8.0 * 27 * ctx.n + 16.0 * ctx.n
+        roofline["full_storage"] = {"kernel": "k_spmv_sell<kind,mode,2,full> (all 27 slot arrays)", "achieved": round(af, 1),
+                                    "frac": round(af / HBM_PEAK_GBS, 4), "launches_per_step": int(lf),
+                                    "algorithmic_bytes_per_launch": round(bf / max(lf, 1), 0), "ms_per_step": round(full_ms, 3),
+                                    "fine_level": fine_block(full_bytes), "fine_level_in_solver": in_solver(tf)}
+        ctx.set_option("sell_sym", 1)
     if sell and not args.skip_csr:
         # the same step on the CSR operator format (the north-star's "CSR SpMV inner loop"): untimed, for the record
         ctx.set_option("op_format", 0)
@@ -372,7 +392,7 @@ def main():
             "preallocation": "outside the timed step: mesh, sparsity pattern, boundary-data upload (setup_ms) and the first "
                              "step's buffer / multigrid-hierarchy allocation (cold_step_ms = that first step)",
             "setup_ms": round(setup_ms, 2), "cold_step_ms": None if cold_ms is None else round(cold_ms, 2),
-            "operator_format": "stencil-ELL" if sell else "CSR",
+            "operator_format": ("stencil-ELL, symmetric storage" if sym else "stencil-ELL") if sell else "CSR",
             "transport": transport, "ranks_seen": int(ranks_seen),
             "allreduces_per_step": int(cs["allreduces"]),
             "cells": N ** 3, "dofs": int(dofs_global), "parallelism": f"slab{world}" if world > 1 else "single",

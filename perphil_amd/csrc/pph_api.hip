@@ -89,8 +89,8 @@ int pph_ctx_create(int device, pph_ctx** out) {
     return fail("hipHostGetDevicePointer", e);
   ctx->h_seq = reinterpret_cast<unsigned long long*>(ctx->h_scal + PPH_MAX_SCAL);
   ctx->h_seq_dev = reinterpret_cast<unsigned long long*>(ctx->h_scal_dev + PPH_MAX_SCAL);
-  // reduction results + partial sums (32 slots x 2048 workgroups)
-  if (ctx->scal.alloc(ctx, (size_t)PPH_MAX_SCAL + 32 * 2048) < 0) {
+  // reduction results + partial sums (32 slots x 4096 workgroups)
+  if (ctx->scal.alloc(ctx, (size_t)PPH_MAX_SCAL + 32 * 4096) < 0) {
     g_last_error = ctx->err;
     delete ctx;
     return PPH_ERR_NOMEM;
@@ -362,7 +362,9 @@ static int attach_sell(pph_ctx* ctx, int which, Csr* A) {
     A->ell = (which == 3) ? ctx->S11 : (which == 4) ? ctx->S22 : (which == 5) ? ctx->S12 : ctx->S21;
     return PPH_OK;
   }
-  return sell_from_csr(ctx, ctx->mesh, A->val, ctx->sell_tmp, &A->ell);
+  // K, M and the blocks of the two-step path: symmetric as well (K, M before elimination; A12 only with one Dirichlet set)
+  const int sym = pph_sell_sym(ctx) && (which != 5 && which != 6 ? 1 : (ctx->a21_alias ? 1 : 0));
+  return sell_from_csr(ctx, ctx->mesh, A->val, ctx->sell_tmp, &A->ell, sym);
 }
 
 int pph_csr_sizes(const pph_ctx* cctx, int which, int64_t* nrows, int64_t* nnz) {
@@ -532,6 +534,12 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
     ctx->op_format = (int)value;
     return PPH_OK;
   }
+  if (!strcmp(name, "sell_sym")) {   // takes effect at the next assembly
+    ctx->sell_sym = value != 0.0 ? 1 : 0;
+    release_system(ctx);
+    return PPH_OK;
+  }
+  if (!strcmp(name, "sell_zwalk")) { ctx->sell_zwalk = value > 0 ? (int)value : 0; return PPH_OK; }
   if (!strcmp(name, "sell_rpt")) { ctx->sell_rpt = (int)value; return PPH_OK; }
   if (!strcmp(name, "sell_blocks")) { ctx->sell_blocks = (int)value; return PPH_OK; }
   if (!strcmp(name, "sell_group")) { ctx->sell_group = (int)value; return PPH_OK; }
@@ -570,6 +578,7 @@ int pph_comm_set_callbacks(pph_ctx* ctx, int rank, int world, pph_halo_fn halo, 
   ctx->allreduce_cb = allreduce;
   ctx->comm_user = user;
   ctx->comm_status = PPH_OK;
+  release_system(ctx);   // operators assembled for another decomposition (storage format, ghost rows) are stale
   mg_release(ctx);
   ctx->mg_ok = false;
   return PPH_OK;

@@ -662,19 +662,30 @@ struct FuseArgs {
   int same;                        // both fields carry the same Dirichlet set (one mask gather per entry)
   // ld > 0: A11 .. A21 are stencil-ELL arrays (pph_sell.hip): entry (row, column row + (dx,dy,dz)) is stored at
   // [slot_of[(dz+1)*9 + (dy+1)*3 + (dx+1)] * ld + row]; ld == 0: CSR value arrays addressed by the pattern position
+  // With symmetric storage (Sell::sym) only the diagonal and the upper slots are stored: slot_of is then the STORED
+  // slot (s - S/2) or -1 for a lower slot, whose entry is not written.  The diagonal blocks (slot_of) and the coupling
+  // blocks (slot_of_c: symmetric only when both fields carry the same Dirichlet set) have their own tables.
   int64_t ld;
   int8_t slot_of[27];
+  int8_t slot_of_c[27];
 };
 
-static void fuse_set_format(FuseArgs& fa, int kind, int64_t ld) {
+static void fuse_set_format(FuseArgs& fa, int kind, int64_t ld, int sym = 0, int sym_c = 0) {
   fa.ld = ld;
-  for (int q = 0; q < 27; ++q) fa.slot_of[q] = -1;
+  for (int q = 0; q < 27; ++q) { fa.slot_of[q] = -1; fa.slot_of_c[q] = -1; }
   const Stencil st = make_stencil(kind);
-  for (int s = 0; s < st.count; ++s) fa.slot_of[(st.d[s][2] + 1) * 9 + (st.d[s][1] + 1) * 3 + (st.d[s][0] + 1)] = (int8_t)s;
+  const int c0 = st.count / 2;
+  for (int s = 0; s < st.count; ++s) {
+    const int q = (st.d[s][2] + 1) * 9 + (st.d[s][1] + 1) * 3 + (st.d[s][0] + 1);
+    fa.slot_of[q] = (int8_t)(sym ? (s >= c0 ? s - c0 : -1) : s);
+    fa.slot_of_c[q] = (int8_t)(sym_c ? (s >= c0 ? s - c0 : -1) : s);
+  }
 }
 
-// output position of the entry (node, column j): the CSR position k or the stencil-ELL address
-__device__ __forceinline__ int64_t fuse_out_index(const FuseArgs& fa, int64_t k, int64_t node, int32_t j, int px, int py) {
+// output position of the entry (node, column j): the CSR position k or the stencil-ELL address; -1: not stored
+// (lower half of a symmetric operator).  coupling: the table of the coupling blocks.
+__device__ __forceinline__ int64_t fuse_out_index(const FuseArgs& fa, int64_t k, int64_t node, int32_t j, int px, int py,
+                                                  bool coupling = false) {
   if (fa.ld == 0) return k;
   const int i0 = (int)(node % px);
   const int64_t t0 = node / px;
@@ -682,8 +693,9 @@ __device__ __forceinline__ int64_t fuse_out_index(const FuseArgs& fa, int64_t k,
   const int i1 = (int)(j % px);
   const int64_t t1 = (int64_t)j / px;
   const int j1 = (int)(t1 % py), k1 = (int)(t1 / py);
-  const int s = fa.slot_of[(k1 - k0 + 1) * 9 + (j1 - j0 + 1) * 3 + (i1 - i0 + 1)];
-  return (int64_t)s * fa.ld + node;
+  const int q = (k1 - k0 + 1) * 9 + (j1 - j0 + 1) * 3 + (i1 - i0 + 1);
+  const int s = coupling ? fa.slot_of_c[q] : fa.slot_of[q];
+  return s < 0 ? -1 : (int64_t)s * fa.ld + node;
 }
 // A12 / A21 null: coupling blocks not wanted; rhs null: no lifting (multigrid coarse levels: g1, g2, u0 unused)
 
@@ -837,11 +849,12 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__
             o12 = (r1 != 0 || c2) ? 0.0 : -fa.b * mv;
             o21 = (r2 != 0 || c1) ? 0.0 : -fa.b * mv;
           }
-          const int64_t ko = fuse_out_index(fa, k, node, j, px, py);
-          fa.A11[ko] = o11;
-          fa.A22[ko] = o22;
-          if (fa.A12) fa.A12[ko] = o12;
-          if (fa.A21) fa.A21[ko] = o21;
+          const int64_t ko = fuse_out_index(fa, k, node, j, px, py), kc = fuse_out_index(fa, k, node, j, px, py, true);
+          if (ko >= 0) { fa.A11[ko] = o11; fa.A22[ko] = o22; }
+          if (kc >= 0) {
+            if (fa.A12) fa.A12[kc] = o12;
+            if (fa.A21) fa.A21[kc] = o21;
+          }
           s11 += fabs(o11); s22 += fabs(o22);
           if (diag) { d11 = o11; d22 = o22; }
         }
@@ -1027,11 +1040,12 @@ __global__ __launch_bounds__(256) void k_asm_simplex_gather(const int32_t* __res
             o12 = (r1 != 0 || c2) ? 0.0 : -fa.b * mv;
             o21 = (r2 != 0 || c1) ? 0.0 : -fa.b * mv;
           }
-          const int64_t ko = fuse_out_index(fa, s + q, node, jc, px, py);
-          fa.A11[ko] = o11;
-          fa.A22[ko] = o22;
-          if (fa.A12) fa.A12[ko] = o12;
-          if (fa.A21) fa.A21[ko] = o21;
+          const int64_t ko = fuse_out_index(fa, s + q, node, jc, px, py), kc = fuse_out_index(fa, s + q, node, jc, px, py, true);
+          if (ko >= 0) { fa.A11[ko] = o11; fa.A22[ko] = o22; }
+          if (kc >= 0) {
+            if (fa.A12) fa.A12[kc] = o12;
+            if (fa.A21) fa.A21[kc] = o21;
+          }
           s11 += fabs(o11); s22 += fabs(o22);
           if (diag) { d11 = o11; d22 = o22; }
         }
@@ -1366,11 +1380,14 @@ static int blocks_alloc_csr(pph_ctx* ctx) {
 }
 
 static int blocks_alloc_sell(pph_ctx* ctx) {
-  PPH_TRY(sell_alloc(ctx, ctx->mesh, ctx->E11, &ctx->S11));
-  PPH_TRY(sell_alloc(ctx, ctx->mesh, ctx->E22, &ctx->S22));
-  PPH_TRY(sell_alloc(ctx, ctx->mesh, ctx->E12, &ctx->S12));
+  // diagonal blocks: symmetric after the symmetric elimination; coupling blocks: A21 = A12^T, and A12 itself is
+  // symmetric only when both fields carry the same Dirichlet set (then A21 is not stored at all)
+  const int sym = pph_sell_sym(ctx), sym_c = (sym && ctx->a21_alias) ? 1 : 0;
+  PPH_TRY(sell_alloc(ctx, ctx->mesh, ctx->E11, &ctx->S11, sym));
+  PPH_TRY(sell_alloc(ctx, ctx->mesh, ctx->E22, &ctx->S22, sym));
+  PPH_TRY(sell_alloc(ctx, ctx->mesh, ctx->E12, &ctx->S12, sym_c));
   if (ctx->a21_alias) { ctx->E21.release(); ctx->S21 = ctx->S12; }
-  else PPH_TRY(sell_alloc(ctx, ctx->mesh, ctx->E21, &ctx->S21));
+  else PPH_TRY(sell_alloc(ctx, ctx->mesh, ctx->E21, &ctx->S21, 0));
   return PPH_OK;
 }
 
@@ -1450,11 +1467,12 @@ int pph_launch_blocks(pph_ctx* ctx, int monolithic) {
   ctx->ell_ok = false;
   if (ctx->op_format == 1) {
     // the block solves run on stencil-ELL copies
-    PPH_TRY(sell_from_csr(ctx, ctx->mesh, ctx->A11.p, ctx->E11, &ctx->S11));
-    PPH_TRY(sell_from_csr(ctx, ctx->mesh, ctx->A22.p, ctx->E22, &ctx->S22));
-    PPH_TRY(sell_from_csr(ctx, ctx->mesh, ctx->A12.p, ctx->E12, &ctx->S12));
+    const int sym = pph_sell_sym(ctx), sym_c = (sym && ctx->a21_alias) ? 1 : 0;
+    PPH_TRY(sell_from_csr(ctx, ctx->mesh, ctx->A11.p, ctx->E11, &ctx->S11, sym));
+    PPH_TRY(sell_from_csr(ctx, ctx->mesh, ctx->A22.p, ctx->E22, &ctx->S22, sym));
+    PPH_TRY(sell_from_csr(ctx, ctx->mesh, ctx->A12.p, ctx->E12, &ctx->S12, sym_c));
     if (ctx->a21_alias) { ctx->E21.release(); ctx->S21 = ctx->S12; }
-    else PPH_TRY(sell_from_csr(ctx, ctx->mesh, ctx->A21.p, ctx->E21, &ctx->S21));
+    else PPH_TRY(sell_from_csr(ctx, ctx->mesh, ctx->A21.p, ctx->E21, &ctx->S21, 0));
     ctx->ell_ok = true;
   }
   return blocks_mono(ctx, monolithic);
@@ -1761,11 +1779,15 @@ __global__ __launch_bounds__(512) void k_asm_tile(const double* __restrict__ cx,
           o12 = (r1 != 0 || c2) ? 0.0 : -fa.b * mv;
           o21 = (r2 != 0 || c1) ? 0.0 : -fa.b * mv;
         }
-        const int64_t ko = fa.ld ? (int64_t)fa.slot_of[(dz + 1) * 9 + (dy + 1) * 3 + (dx + 1)] * fa.ld + node : kcsr;
-        fa.A11[ko] = o11;
-        fa.A22[ko] = o22;
-        if (fa.A12) fa.A12[ko] = o12;
-        if (fa.A21) fa.A21[ko] = o21;
+        const int sq = (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1);
+        const int so = fa.slot_of[sq], sc = fa.slot_of_c[sq];     // stored slots (-1: lower half of a symmetric operator)
+        const int64_t ko = fa.ld ? (so < 0 ? -1 : (int64_t)so * fa.ld + node) : kcsr;
+        const int64_t kc = fa.ld ? (sc < 0 ? -1 : (int64_t)sc * fa.ld + node) : kcsr;
+        if (ko >= 0) { fa.A11[ko] = o11; fa.A22[ko] = o22; }
+        if (kc >= 0) {
+          if (fa.A12) fa.A12[kc] = o12;
+          if (fa.A21) fa.A21[kc] = o21;
+        }
         s11 += fabs(o11); s22 += fabs(o22);
         if (diag) { d11 = o11; d22 = o22; }
       }
@@ -1900,9 +1922,9 @@ int pph_launch_fused_kernels(pph_ctx* ctx, MeshData& mesh, const FuseArgs& fa, d
 // rows, with the smoother's diagonal inverses and spectral bounds (no K/M, no coupling blocks, no lifting)
 int pph_launch_level_operators(pph_ctx* ctx, MeshData& mesh, const uint8_t* m1, const uint8_t* m2, const uint8_t* near,
                                int same, double coefK1, double coefK2, double coefM, double* A1, double* A2,
-                               double* dinv1, double* dinv2, unsigned long long* lam, int64_t ell_ld) {
+                               double* dinv1, double* dinv2, unsigned long long* lam, int64_t ell_ld, int ell_sym) {
   FuseArgs fa;
-  fuse_set_format(fa, mesh.kind, ell_ld);
+  fuse_set_format(fa, mesh.kind, ell_ld, ell_sym, ell_sym);
   fa.m1 = m1; fa.m2 = m2; fa.near = near;
   fa.g1 = nullptr; fa.g2 = nullptr;
   fa.a = coefK1; fa.b = coefM; fa.c = coefK2;
@@ -1944,7 +1966,7 @@ int pph_launch_assemble_fused(pph_ctx* ctx, int monolithic) {
   } else {
     fa.A11 = ctx->A11.p; fa.A22 = ctx->A22.p; fa.A12 = ctx->A12.p; fa.A21 = ctx->a21_alias ? nullptr : ctx->A21.p;
   }
-  fuse_set_format(fa, mesh.kind, ell ? ctx->S11.ld : 0);
+  fuse_set_format(fa, mesh.kind, ell ? ctx->S11.ld : 0, ell ? ctx->S11.sym : 0, ell ? ctx->S12.sym : 0);
   fa.rhs = ctx->rhs.p; fa.u0 = ctx->u0.p;
   fa.dinv1 = ctx->dinv0[0].p; fa.dinv2 = ctx->dinv0[1].p;
   fa.lam = ctx->lam0.p;

@@ -104,6 +104,7 @@ extern "C" int pph_comm_init_rccl(pph_ctx* ctx, int rank, int world, const uint8
   ctx->halo_cb = nullptr;
   ctx->allreduce_cb = nullptr;
   ctx->comm_status = PPH_OK;
+  ctx->asm_ok = false; ctx->ell_ok = false; ctx->csr_ok = false; ctx->mono_ok = false;   // assembled for another decomposition
   mg_release(ctx);
   return PPH_OK;
 }

@@ -61,15 +61,22 @@ struct MeshData;
 // s-th offset of the cell kind's stencil in ascending (dz,dy,dx) order - the column order of the CSR pattern -
 // and an explicit 0 where the neighbour lies outside the local box.  No column indices and no row pointers:
 // col = row + dx + px * (dy + py * dz).  8 B per stored entry instead of 12 B, every load coalesced across rows.
+//
+// Symmetric storage (sym = 1): the eliminated blocks are symmetric and the stencils are symmetric under negation
+// (slot s and S-1-s carry opposite offsets), so only the diagonal and the UPPER slots are stored: val[(s - S/2)][row]
+// for s >= S/2.  Entry (r, r + o) with o < 0 is read as entry (r + o, r) from the mirror slot of row r + o: every stored
+// value is used by two rows, S/2 + 1 instead of S streams.
 struct Sell {
   const double* val = nullptr;
   int64_t ld = 0;            // leading dimension: rows rounded up to a multiple of 64
   int kind = -1;             // PPH_CELL_*
   int px = 0, py = 0, pz = 0;  // node dims of the local box
+  int sym = 0;               // 1: upper half only (see above)
 };
 static inline int sell_slots(int kind) {
   return kind == PPH_CELL_QUAD ? 9 : kind == PPH_CELL_TRI ? 7 : kind == PPH_CELL_HEX ? 27 : 15;
 }
+static inline int sell_stored(int kind, int sym) { return sym ? sell_slots(kind) / 2 + 1 : sell_slots(kind); }
 static inline int64_t sell_ld(int64_t n) { return (n + 63) & ~(int64_t)63; }
 
 // stencil of a cell kind as (dy,dz) lines with a 3-bit mask of the dx in {-1,0,+1} present, lines in ascending
@@ -334,6 +341,8 @@ struct pph_ctx {
   int spmv_kernel = 3;                  // 3: aligned-wide CSR-vector (default); 0,1,2,4..8,10: variants kept for A/B runs
   // operator format of the scalar blocks inside the block solves / Picard sweeps: 1 stencil-ELL (pph_sell.hip), 0 CSR
   int op_format = 1;
+  int sell_sym = 1;                     // stencil-ELL operators store the diagonal and the upper slots only (symmetric blocks)
+  int sell_zwalk = 4;                   // > 0 (symmetric operators, 3D): a workgroup walks this many consecutive node planes at one in-plane position
   int sell_rpt = 2, sell_blocks = 0, sell_group = 0;   // SELL SpMV tuning: rows per thread, grid cap, XCD chunk group
   DevBuf<double> sell_tmp;              // SELL copy of the matrix last selected by pph_spmv / pph_spmv_bench
 };
@@ -359,7 +368,7 @@ int pph_launch_assemble_fused(pph_ctx* ctx, int monolithic);
 // A1, A2: CSR value arrays (ell_ld == 0) or stencil-ELL arrays with leading dimension ell_ld
 int pph_launch_level_operators(pph_ctx* ctx, MeshData& mesh, const uint8_t* m1, const uint8_t* m2, const uint8_t* near,
                                int same, double coefK1, double coefK2, double coefM, double* A1, double* A2,
-                               double* dinv1, double* dinv2, unsigned long long* lam, int64_t ell_ld);
+                               double* dinv1, double* dinv2, unsigned long long* lam, int64_t ell_ld, int ell_sym);
 void pph_launch_row_near(pph_ctx* ctx, const MeshData& mesh, const uint8_t* m1, const uint8_t* m2, uint8_t* out);
 
 // linear algebra on the context stream; all results that feed control flow go through ctx->scal
@@ -430,8 +439,11 @@ void la_reset_spmv_stats(pph_ctx* ctx);
 // stencil-ELL operator format (pph_sell.hip)
 int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x, const double* b, const double* dinv,
               const double* w /* device */, double* y, double* part, int64_t dlo = 0, int64_t dhi = 0);
-int sell_alloc(pph_ctx* ctx, const MeshData& mesh, DevBuf<double>& buf, Sell* out);
-int sell_from_csr(pph_ctx* ctx, const MeshData& mesh, const double* csr_val, DevBuf<double>& buf, Sell* out);
+int sell_alloc(pph_ctx* ctx, const MeshData& mesh, DevBuf<double>& buf, Sell* out, int sym);
+int sell_from_csr(pph_ctx* ctx, const MeshData& mesh, const double* csr_val, DevBuf<double>& buf, Sell* out, int sym);
+// symmetric storage is used for operators that are symmetric on the local box: single context (a slab's ghost rows
+// are empty, which breaks the symmetry of the local matrix) and option sell_sym on
+static inline int pph_sell_sym(const pph_ctx* ctx);
 int sell_to_csr(pph_ctx* ctx, const MeshData& mesh, const Sell& E, double* csr_val);
 
 // block values + Dirichlet elimination on any level: out = (row constrained) ? I : coefK*K + coefM*M with
@@ -450,6 +462,7 @@ bool mg_pre_smoother(pph_ctx* ctx, int which, int nsmooth, const double** dinv, 
                      bool* launch_only);
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline int pph_sell_sym(const pph_ctx* ctx) { return (ctx->sell_sym && ctx->world == 1) ? 1 : 0; }
 
 // owned index set of a vector of `nrows` entries living on slab geometry g (null: everything)
 static inline Seg pph_owned_seg(const MeshData* g, int64_t nrows) {

@@ -10,7 +10,7 @@
 #define RED_BLOCKS 1024        // grid of the BLAS-1 reduction kernels
 #define SPMV_MAX_BLOCKS 2048   // upper limit of the persistent SpMV grid (multiple of 8 XCDs)
 #define SPMV_DEF_BLOCKS 1024   // default grid: 4 workgroups per CU measured fastest (tools/spmv_probe.py)
-#define PART_STRIDE 2048       // partial sums per reduction slot
+#define PART_STRIDE 4096       // partial sums per reduction slot (>= the largest grid that writes partial sums)
 #define PART_SLOTS 32          // concurrent reduction slots (GMRES restart 30 + 2)
 
 static inline double* partials(pph_ctx* ctx) { return ctx->scal.p + PPH_MAX_SCAL; }
@@ -220,7 +220,10 @@ static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const doub
     grid = sell_spmv(ctx, A.ell, A.nrows, jdinv ? (jdot ? 4 : 3) : (DOT ? 2 : (bvec ? 1 : 0)), x, bvec, jdinv, jw, y,
                      part ? part : partials(ctx), dlo, dhi);
     if (ev) (void)hipEventRecord(ev->e1, ctx->stream);
-    const double bytes = 8.0 * sell_slots(A.ell.kind) * (double)A.nrows + 16.0 * (double)A.nrows;
+    // algorithmic bytes: every stored value once, x read once, y written once, plus the epilogue's vectors
+    // (b for the residual form; b and 1 / a_ii for the Jacobi update)
+    const double extra = jdinv ? 16.0 : (bvec ? 8.0 : 0.0);
+    const double bytes = (8.0 * sell_stored(A.ell.kind, A.ell.sym) + 16.0 + extra) * (double)A.nrows;
     ctx->n_spmv[variant]++;
     ctx->spmv_bytes[variant] += bytes;
     if (A.nrows >= ctx->mesh.n) { ctx->n_spmv_fine++; ctx->spmv_bytes_fine += bytes; }

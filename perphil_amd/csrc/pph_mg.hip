@@ -476,7 +476,7 @@ int mg_setup(pph_ctx* ctx) {
         L.maskp[f] = L.mask[f].p;
         L.ell[f] = Sell();
         if (ell_only) {
-          PPH_TRY(sell_alloc(ctx, m, L.own_ell[f], &L.ell[f]));
+          PPH_TRY(sell_alloc(ctx, m, L.own_ell[f], &L.ell[f], pph_sell_sym(ctx)));
           L.val[f] = nullptr;
         } else {
           PPH_TRY(L.own_val[f].alloc(ctx, (size_t)L.nnz));
@@ -492,12 +492,12 @@ int mg_setup(pph_ctx* ctx) {
         PPH_TRY(pph_launch_level_operators(ctx, m, L.maskp[0], L.maskp[1], L.rownear.p, ctx->a21_alias ? 1 : 0, coefK[0],
                                            coefK[1], ctx->b, ell_only ? L.own_ell[0].p : L.own_val[0].p,
                                            ell_only ? L.own_ell[1].p : L.own_val[1].p, L.dinv[0].p, L.dinv[1].p,
-                                           lamdev.p + 2 * l, ell_only ? L.ell[0].ld : 0));
+                                           lamdev.p + 2 * l, ell_only ? L.ell[0].ld : 0, ell_only ? L.ell[0].sym : 0));
         level_fused = true;
       } else {
         for (int f = 0; f < 2; ++f) {
           pph_launch_scalar_block(ctx, m, L.maskp[f], coefK[f], ctx->b, L.own_val[f].p);
-          if (use_ell) PPH_TRY(sell_from_csr(ctx, m, L.own_val[f].p, L.own_ell[f], &L.ell[f]));
+          if (use_ell) PPH_TRY(sell_from_csr(ctx, m, L.own_val[f].p, L.own_ell[f], &L.ell[f], pph_sell_sym(ctx)));
         }
       }
       L.bc_epoch = ctx->bc_epoch;
@@ -653,8 +653,8 @@ __global__ __launch_bounds__(1024) void k_coarse_cg(const int64_t* __restrict__ 
 }
 
 // the same solve on a stencil-ELL operator (no CSR values exist on a level the fused pass wrote in that form)
-__global__ __launch_bounds__(1024) void k_coarse_cg_sell(const double* __restrict__ val, int64_t ld, Stencil st, int px,
-                                                         int py, int pz, const double* __restrict__ dinv,
+__global__ __launch_bounds__(1024) void k_coarse_cg_sell(const double* __restrict__ val, int64_t ld, int sym, Stencil st,
+                                                         int px, int py, int pz, const double* __restrict__ dinv,
                                                          const double* __restrict__ b, double* __restrict__ x,
                                                          double* __restrict__ r, double* __restrict__ p,
                                                          double* __restrict__ q, int n, double rtol, int max_it) {
@@ -678,8 +678,14 @@ __global__ __launch_bounds__(1024) void k_coarse_cg_sell(const double* __restric
       double s = 0.0;
       for (int sl = 0; sl < st.count; ++sl) {
         const int a = ii + st.d[sl][0], bb = jj + st.d[sl][1], c = kk + st.d[sl][2];
-        if (a >= 0 && a < px && bb >= 0 && bb < py && c >= 0 && c < pz)
-          s += val[(int64_t)sl * ld + i] * p[a + px * (bb + py * c)];
+        if (a >= 0 && a < px && bb >= 0 && bb < py && c >= 0 && c < pz) {
+          const int jn = a + px * (bb + py * c);
+          const int c0 = st.count / 2;
+          // symmetric storage: lower entry (i, jn) = upper entry (jn, i), mirror slot, stored at row jn
+          const double v = !sym ? val[(int64_t)sl * ld + i]
+                                : (sl >= c0 ? val[(int64_t)(sl - c0) * ld + i] : val[(int64_t)(st.count - 1 - sl - c0) * ld + jn]);
+          s += v * p[jn];
+        }
       }
       q[i] = s;
       pq += p[i] * s;
@@ -719,6 +725,7 @@ __global__ __launch_bounds__(1024) void k_coarse_cg_sell(const double* __restric
 #define MG_TAIL_MATPOOL 6144       // doubles of LDS for the operators of tail levels 1..
 struct TailLevel {
   const double* A;        // stencil-ELL operator
+  int sym;                // its storage (Sell::sym)
   int64_t ld;
   const double* dinv;
   const uint8_t* mask;
@@ -785,11 +792,29 @@ __global__ __launch_bounds__(1024) void k_mg_tail(TailArgs ta, TStencil ts, int 
   double a0[ST::S];
   double dv[MG_TAIL_MAX], wl[MG_TAIL_MAX];
   for (int l = 0; l < nl; ++l) wl[l] = *ta.L[l].w;
+  // entry (row, slot) of a level's operator; symmetric storage: a lower slot is the mirror slot of the row it points to
+  auto entry = [&](const TailLevel& F, int slot, int row) -> double {
+    if (!F.sym) return F.A[(int64_t)slot * F.ld + row];
+    constexpr int C0 = ST::S / 2;
+    if (slot >= C0) return F.A[(int64_t)(slot - C0) * F.ld + row];
+    // offset of the slot: decode from the stencil lines
+    int sl = 0, off = 0;
+    for (int l = 0; l < ST::NL; ++l) {
+      const int mask = ST::mask(l);
+      for (int d = 0; d < 3; ++d) {
+        if (!((mask >> d) & 1)) continue;
+        if (sl == slot) off = (d - 1) + ST::dy(l) * F.px + ST::dz(l) * F.px * F.py;
+        ++sl;
+      }
+    }
+    const int rr = row + off;
+    return (rr >= 0 && rr < F.n) ? F.A[(int64_t)(ST::S - 1 - slot - C0) * F.ld + rr] : 0.0;
+  };
   {
     const TailLevel& F = ta.L[0];
     const bool in = tid < F.n;
 #pragma unroll
-    for (int s = 0; s < ST::S; ++s) a0[s] = in ? F.A[(int64_t)s * F.ld + tid] : 0.0;
+    for (int s = 0; s < ST::S; ++s) a0[s] = in ? entry(F, s, tid) : 0.0;
     if (in) B[0][tid] = ta.b0[tid];
   }
   for (int l = 0; l < nl; ++l) {
@@ -797,7 +822,7 @@ __global__ __launch_bounds__(1024) void k_mg_tail(TailArgs ta, TStencil ts, int 
     dv[l] = (tid < F.n) ? F.dinv[tid] : 0.0;
     if (tid < F.n) MK[l][tid] = F.mask[tid];
     if (l > 0)
-      for (int e = tid; e < ST::S * F.n; e += blockDim.x) M[l][e] = F.A[(int64_t)(e / F.n) * F.ld + e % F.n];
+      for (int e = tid; e < ST::S * F.n; e += blockDim.x) M[l][e] = entry(F, e / F.n, e % F.n);
   }
   __syncthreads();
   // ---- downward leg
@@ -1010,7 +1035,7 @@ static void mg_vcycle_fused(pph_ctx* ctx, int which, const double* rin, double* 
     for (int q = 0; q < ta.nl; ++q) {
       MgLevel& L = mg[lt + q];
       TailLevel& T = ta.L[q];
-      T.A = L.ell[which].val; T.ld = L.ell[which].ld; T.dinv = L.dinv[which].p; T.mask = L.maskp[which];
+      T.A = L.ell[which].val; T.sym = L.ell[which].sym; T.ld = L.ell[which].ld; T.dinv = L.dinv[which].p; T.mask = L.maskp[which];
       T.px = L.px; T.py = L.py; T.pz = L.pz; T.n = (int)L.n;
       T.w = cheb_wp(ctx, lt + q, which);
       ns[q] = (int)L.n;
@@ -1037,7 +1062,7 @@ static void mg_vcycle_fused(pph_ctx* ctx, int which, const double* rin, double* 
     ctx->comm_suspended = C.replicated;
     if ((!dist || C.replicated) && C.n <= 4096 && ctx->coarse_on_device)
       hipLaunchKernelGGL(k_coarse_cg_sell, dim3(1), dim3(C.n <= 256 ? 256 : 1024), 0, ctx->stream, C.ell[which].val,
-                         C.ell[which].ld, make_stencil(kind), C.px, C.py, C.pz, C.dinv[which].p, C.b.p, C.x.p, C.r.p,
+                         C.ell[which].ld, C.ell[which].sym, make_stencil(kind), C.px, C.py, C.pz, C.dinv[which].p, C.b.p, C.x.p, C.r.p,
                          C.d.p, C.t.p, (int)C.n, 1e-12, ctx->coarse_max_it);
     else
       pph_cg_jacobi(ctx, level_csr(ctx, C, which), C.b.p, C.x.p, C.dinv[which].p, 1e-12, 0.0, ctx->coarse_max_it, C.r.p, C.d.p, C.t.p,
@@ -1124,7 +1149,7 @@ void mg_vcycle(pph_ctx* ctx, int which, const double* rin, double* zout, int nsm
     ctx->comm_suspended = C.replicated;
     if ((!dist || C.replicated) && C.n <= 4096 && ctx->coarse_on_device && C.ell[which].val)
       hipLaunchKernelGGL(k_coarse_cg_sell, dim3(1), dim3(C.n <= 256 ? 256 : 1024), 0, ctx->stream, C.ell[which].val,
-                         C.ell[which].ld, make_stencil(ctx->mesh.kind), C.px, C.py, C.pz, C.dinv[which].p, C.b.p, C.x.p,
+                         C.ell[which].ld, C.ell[which].sym, make_stencil(ctx->mesh.kind), C.px, C.py, C.pz, C.dinv[which].p, C.b.p, C.x.p,
                          C.r.p, C.d.p, C.t.p, (int)C.n, 1e-12, ctx->coarse_max_it);
     else if ((!dist || C.replicated) && C.n <= 4096 && ctx->coarse_on_device)
       hipLaunchKernelGGL(k_coarse_cg, dim3(1), dim3(C.n <= 256 ? 256 : 1024), 0, ctx->stream, C.rowptr, C.col, C.val[which],

@@ -24,7 +24,7 @@ __device__ inline double sell_wave_sum(double v) {
 // MODE 2 / 4 write one partial sum per workgroup to part[blockIdx.x]; the caller finishes the sum.
 // One thread owns RPT consecutive rows; a workgroup a chunk of 256 RPT rows.  Chunks are dealt to the XCDs in groups
 // of `group` consecutive chunks (group 1 = plain grid-stride order); workgroups with equal blockIdx % 8 share an XCD.
-template <int KIND, int MODE, int RPT, bool CLAMP>
+template <int KIND, int MODE, int RPT, bool CLAMP, bool SYM = false>
 __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_t ld, const double* __restrict__ x,
                                           const double* __restrict__ b, const double* __restrict__ dinv, double w,
                                           double* __restrict__ y, int64_t n, int px, int64_t pxy, int64_t r0,
@@ -69,9 +69,20 @@ __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       if (!((mask >> d) & 1)) continue;
-      const double* vp = val + (int64_t)slot * ld + r0;
+      // symmetric storage: stored slot = slot - S/2 for the diagonal and the upper slots; a lower slot is the mirror
+      // slot S - 1 - slot of row r + o (o < 0 its offset): each stored value serves two rows
+      constexpr int C0 = ST::S / 2;
+      const double* vp = val + (int64_t)(SYM ? (slot >= C0 ? slot - C0 : 0) : slot) * ld + r0;
       double v[RPT];
-      if constexpr (RPT == 1) {
+      if (SYM && slot < C0) {
+        const int64_t off = (int64_t)(d - 1) + (int64_t)ST::dy(l) * px + (int64_t)ST::dz(l) * pxy;
+        const double* mp = val + (int64_t)(ST::S - 1 - slot - C0) * ld;
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+          const int64_t rr = r0 + i + off;
+          v[i] = (act[i] && (!CLAMP || (rr >= 0 && rr < n))) ? mp[rr] : 0.0;
+        }
+      } else if constexpr (RPT == 1) {
         v[0] = act[0] ? vp[0] : 0.0;
       } else {
         // r0 and ld are multiples of RPT and the array is 256-byte aligned: 16-byte loads; rows beyond n fall into the
@@ -103,31 +114,50 @@ __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_
   }
 }
 
-template <int KIND, int MODE, int RPT>
+template <int KIND, int MODE, int RPT, bool SYM = false>
 __global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ val, int64_t ld,
                                                    const double* __restrict__ x, const double* __restrict__ b,
                                                    const double* __restrict__ dinv, const double* __restrict__ wp,
                                                    double* __restrict__ y, int64_t n, int px, int64_t pxy, int64_t halo,
                                                    int64_t nchunks,
-                                                   int group, double* __restrict__ part, int64_t dlo, int64_t dhi) {
+                                                   int group, int zwalk, double* __restrict__ part, int64_t dlo,
+                                                   int64_t dhi) {
   constexpr int CH = 256 * RPT;
   const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, bpx = gridDim.x >> 3;   // launcher keeps gridDim.x a multiple of 8
   // the smoother weight lives in device memory (refreshed per assembly) so that captured graphs survive a re-assembly
   const double w = (MODE >= 3) ? *wp : 0.0;
   double dotacc = 0.0;
-  for (int64_t q = bx;; q += bpx) {
-    const int64_t base = ((q / group) * 8 + xcd) * (int64_t)group;
-    if (base >= nchunks) break;
-    const int64_t chunk = base + q % group;
-    if (chunk >= nchunks) continue;
+  // Chunk order.  zwalk = Z > 0 (3D): a workgroup takes Z work items in a row that sit at the same in-plane position
+  // of Z consecutive node planes (chunk, chunk + P, ..., P = chunks per plane rounded: the rows shift by pxy - P CH,
+  // one row at 256^3).  The x lines and - with symmetric storage - the operator values a plane reads at offset
+  // -pxy are the ones this workgroup loaded for the plane below a moment ago: they come from L1 / this XCD's L2
+  // instead of the fabric.  zwalk = 0: chunks dealt to the XCDs in groups of `group` (1 = plane grid-stride order).
+  const int64_t P = zwalk > 0 ? (pxy + CH / 2) / CH : 0;
+  const int64_t nitems = (zwalk > 0 && P > 0) ? ((nchunks + P * zwalk - 1) / (P * zwalk)) * P * zwalk : 0;
+  for (int64_t q = (nitems ? (int64_t)blockIdx.x * zwalk : bx);; q += (nitems ? 1 : bpx)) {
+    int64_t chunk;
+    if (nitems) {
+      // items [b Z, b Z + Z) then [(b + gridDim) Z, ...): q walks one item at a time inside a run of Z
+      const int64_t run = q / zwalk, t = q % zwalk;
+      if (run * zwalk >= nitems) break;
+      const int64_t slab = run / P, pos = run % P;
+      chunk = slab * P * zwalk + t * P + pos;
+      if (t == zwalk - 1) q += (int64_t)(gridDim.x - 1) * zwalk;   // next run of this workgroup
+      if (chunk >= nchunks) continue;
+    } else {
+      const int64_t base = ((q / group) * 8 + xcd) * (int64_t)group;
+      if (base >= nchunks) break;
+      chunk = base + q % group;
+      if (chunk >= nchunks) continue;
+    }
     const int64_t c0 = chunk * CH;
     const int64_t r0 = c0 + (int64_t)threadIdx.x * RPT;
     // a chunk whose rows and x window lie inside [0, n) needs no index clamps and no row masks (all but the first
     // and last few chunks)
     if (c0 >= halo && c0 + CH + halo <= n)
-      sell_rows<KIND, MODE, RPT, false>(val, ld, x, b, dinv, w, y, n, px, pxy, r0, dotacc, dlo, dhi);
+      sell_rows<KIND, MODE, RPT, false, SYM>(val, ld, x, b, dinv, w, y, n, px, pxy, r0, dotacc, dlo, dhi);
     else
-      sell_rows<KIND, MODE, RPT, true>(val, ld, x, b, dinv, w, y, n, px, pxy, r0, dotacc, dlo, dhi);
+      sell_rows<KIND, MODE, RPT, true, SYM>(val, ld, x, b, dinv, w, y, n, px, pxy, r0, dotacc, dlo, dhi);
   }
   if (MODE == 2 || MODE == 4) {
     __shared__ double lds[4];
@@ -144,9 +174,24 @@ static void sell_launch_mode(pph_ctx* ctx, int mode, int grid, const Sell& E, co
                              double* part, int64_t dlo, int64_t dhi) {
   const int64_t pxy = (int64_t)E.px * E.py;
   const int64_t halo = (E.pz > 1 ? pxy : 0) + E.px + 2;   // reach of the x window of a row (2D: no z lines)
+  const int zwalk = (E.sym && E.pz > 2 && ctx->sell_zwalk > 0 && nchunks >= 8192) ? ctx->sell_zwalk : 0;   // (no gain on full storage)
 #define PPH_SELL_GO(MM)                                                                                              \
   hipLaunchKernelGGL((k_spmv_sell<KIND, MM, RPT>), dim3(grid), dim3(256), 0, ctx->stream, E.val, E.ld, x, b, dinv, w, \
-                     y, n, E.px, pxy, halo, nchunks, group, part, dlo, dhi)
+                     y, n, E.px, pxy, halo, nchunks, group, zwalk, part, dlo, dhi)
+  if (E.sym) {
+#define PPH_SELL_GOS(MM)                                                                                                   \
+  hipLaunchKernelGGL((k_spmv_sell<KIND, MM, RPT, true>), dim3(grid), dim3(256), 0, ctx->stream, E.val, E.ld, x, b, dinv, w, \
+                     y, n, E.px, pxy, halo, nchunks, group, zwalk, part, dlo, dhi)
+    switch (mode) {
+      case 0: PPH_SELL_GOS(0); break;
+      case 1: PPH_SELL_GOS(1); break;
+      case 2: PPH_SELL_GOS(2); break;
+      case 3: PPH_SELL_GOS(3); break;
+      default: PPH_SELL_GOS(4); break;
+    }
+#undef PPH_SELL_GOS
+    return;
+  }
   switch (mode) {
     case 0: PPH_SELL_GO(0); break;
     case 1: PPH_SELL_GO(1); break;
@@ -162,8 +207,11 @@ int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x,
               const double* w, double* y, double* part, int64_t dlo, int64_t dhi) {
   const int rpt = (ctx->sell_rpt == 1) ? 1 : 2;
   const int64_t nchunks = ceil_div64(n, 256 * rpt);
-  int cap = (ctx->sell_blocks >= 8 && ctx->sell_blocks <= 8192) ? (ctx->sell_blocks / 8) * 8 : 2048;
-  if ((mode == 2 || mode == 4) && cap > 2048) cap = 2048;   // one partial sum per workgroup (PART_STRIDE of pph_la.hip)
+  // grid: persistent, 2048 workgroups; 4096 with the z-walk order of symmetric operators (measured on the 256^3 block:
+  // 0.58 -> 0.51 ms; profiles/r02_sell_sym_probe_256.txt)
+  const bool zw = E.sym && E.pz > 2 && ctx->sell_zwalk > 0 && nchunks >= 8192;   // (smaller levels: one chunk per workgroup anyway)
+  int cap = (ctx->sell_blocks >= 8 && ctx->sell_blocks <= 8192) ? (ctx->sell_blocks / 8) * 8 : (zw ? 4096 : 2048);
+  if ((mode == 2 || mode == 4) && cap > 4096) cap = 4096;   // one partial sum per workgroup (PART_STRIDE of pph_la.hip)
   int64_t g = nchunks < cap ? nchunks : cap;
   g = ((g + 7) / 8) * 8;
   const int grid = (int)g;
@@ -187,7 +235,8 @@ int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x,
 template <bool TO_SELL>
 __global__ __launch_bounds__(256) void k_sell_convert(const int64_t* __restrict__ rowptr, double* __restrict__ csr,
                                                       double* __restrict__ ell, int64_t ld, Stencil st, int px, int py,
-                                                      int pz, int64_t n) {
+                                                      int pz, int64_t n, int sym) {
+  const int c0 = st.count / 2;
   for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < n; row += (int64_t)gridDim.x * blockDim.x) {
     const int i = (int)(row % px);
     const int64_t t = row / px;
@@ -196,8 +245,17 @@ __global__ __launch_bounds__(256) void k_sell_convert(const int64_t* __restrict_
     for (int s = 0; s < st.count; ++s) {
       const int ii = i + st.d[s][0], jj = j + st.d[s][1], kk = k + st.d[s][2];
       const bool in = ii >= 0 && ii < px && jj >= 0 && jj < py && kk >= 0 && kk < pz;
-      if (TO_SELL) ell[(int64_t)s * ld + row] = in ? csr[o] : 0.0;
-      else if (in) csr[o] = ell[(int64_t)s * ld + row];
+      if (!sym) {
+        if (TO_SELL) ell[(int64_t)s * ld + row] = in ? csr[o] : 0.0;
+        else if (in) csr[o] = ell[(int64_t)s * ld + row];
+      } else if (s >= c0) {
+        if (TO_SELL) ell[(int64_t)(s - c0) * ld + row] = in ? csr[o] : 0.0;
+        else if (in) csr[o] = ell[(int64_t)(s - c0) * ld + row];
+      } else if (!TO_SELL && in) {
+        // lower entry (row, col) = upper entry (col, row), stored with the mirror slot at row col
+        const int64_t colr = ii + (int64_t)px * (jj + (int64_t)py * kk);
+        csr[o] = ell[(int64_t)(st.count - 1 - s - c0) * ld + colr];
+      }
       o += in ? 1 : 0;
     }
   }
@@ -208,9 +266,9 @@ static inline int sell_grid(int64_t n) {
   return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
-// (re)allocates `buf` for a SELL operator on `mesh` with the padding rows [n, ld) zeroed, returns the view
-int sell_alloc(pph_ctx* ctx, const MeshData& mesh, DevBuf<double>& buf, Sell* out) {
-  const int S = sell_slots(mesh.kind);
+// (re)allocates `buf` for a stencil-ELL operator on `mesh` with the padding rows [n, ld) zeroed, returns the view
+int sell_alloc(pph_ctx* ctx, const MeshData& mesh, DevBuf<double>& buf, Sell* out, int sym) {
+  const int S = sell_stored(mesh.kind, sym);
   const int64_t ld = sell_ld(mesh.n);
   const size_t want = (size_t)S * (size_t)ld;
   if (buf.n != want || !buf.p) {
@@ -218,21 +276,22 @@ int sell_alloc(pph_ctx* ctx, const MeshData& mesh, DevBuf<double>& buf, Sell* ou
     PPH_HIP(ctx, hipMemsetAsync(buf.p, 0, want * sizeof(double), ctx->stream));   // padding rows stay zero for good
   }
   out->val = buf.p; out->ld = ld; out->kind = mesh.kind; out->px = mesh.px; out->py = mesh.py; out->pz = mesh.pzl;
+  out->sym = sym;
   return PPH_OK;
 }
 
-int sell_from_csr(pph_ctx* ctx, const MeshData& mesh, const double* csr_val, DevBuf<double>& buf, Sell* out) {
-  PPH_TRY(sell_alloc(ctx, mesh, buf, out));
+int sell_from_csr(pph_ctx* ctx, const MeshData& mesh, const double* csr_val, DevBuf<double>& buf, Sell* out, int sym) {
+  PPH_TRY(sell_alloc(ctx, mesh, buf, out, sym));
   hipLaunchKernelGGL(k_sell_convert<true>, dim3(sell_grid(mesh.n)), dim3(256), 0, ctx->stream, mesh.rowptr.p,
                      const_cast<double*>(csr_val), buf.p, out->ld, make_stencil(mesh.kind), mesh.px, mesh.py, mesh.pzl,
-                     mesh.n);
+                     mesh.n, sym);
   PPH_HIP(ctx, hipGetLastError());
   return PPH_OK;
 }
 
 int sell_to_csr(pph_ctx* ctx, const MeshData& mesh, const Sell& E, double* csr_val) {
   hipLaunchKernelGGL(k_sell_convert<false>, dim3(sell_grid(mesh.n)), dim3(256), 0, ctx->stream, mesh.rowptr.p, csr_val,
-                     const_cast<double*>(E.val), E.ld, make_stencil(mesh.kind), mesh.px, mesh.py, mesh.pzl, mesh.n);
+                     const_cast<double*>(E.val), E.ld, make_stencil(mesh.kind), mesh.px, mesh.py, mesh.pzl, mesh.n, E.sym);
   PPH_HIP(ctx, hipGetLastError());
   return PPH_OK;
 }

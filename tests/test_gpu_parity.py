@@ -181,14 +181,15 @@ def test_G1_initial_residual_and_spmv(gpu_ctx_factory, goldens):
     rng = np.random.default_rng(20260313)
     x = rng.uniform(-1, 1, 2 * osys.n)
     ref = osys.A @ x
-    for kern in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 14, 15, 17):   # CSR-vector, with preload, CSR-stream, aligned-wide, LDS-transposed
-        ctx.set_option("spmv_kernel", kern)
-        for lanes in (0, 4, 8, 16, 32, 64):
-            ctx.set_option("spmv_lanes", lanes)
-            y = ctx.spmv(f.MAT_MONO, x)
-            assert np.abs(y - ref).max() <= 1e-13 * np.abs(ref).max(), (kern, lanes)
+    # the CSR SpMV kernel at every lanes-per-row setting (its A/B variants live behind EXPERIMENTS=1 and are refused,
+    # not silently ignored, by a build without them)
+    for lanes in (0, 4, 8, 16, 32, 64):
+        ctx.set_option("spmv_lanes", lanes)
+        y = ctx.spmv(f.MAT_MONO, x)
+        assert np.abs(y - ref).max() <= 1e-13 * np.abs(ref).max(), lanes
     ctx.set_option("spmv_lanes", 0)
-    ctx.set_option("spmv_kernel", 3)
+    with pytest.raises(ValueError):
+        ctx.set_option("spmv_kernel", 17)
     xs = x[: osys.n]
     for which, ref in ((f.MAT_A11, osys.A[: osys.n, : osys.n]), (f.MAT_A21, osys.A[osys.n:, : osys.n])):
         y = ctx.spmv(which, xs)
@@ -816,10 +817,18 @@ def test_stencil_ell_format_equals_csr(gpu_ctx_factory, dim, kind, nx, ny, nz):
         xs, info, _ = ctx.solve(_cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_MG, inner_rtol=1e-10,
                                      inner_reduction=1e-1, inner_norm=1, mg_smooth=1, picard_rtol=1e-9))
         res[fmt] = (mats, xs, info.iterations, info.inner_iterations)
+    import scipy.sparse as sps
+
     for w in res[0][0]:
         np.testing.assert_array_equal(res[1][0][w].indptr, res[0][0][w].indptr)
         np.testing.assert_array_equal(res[1][0][w].indices, res[0][0][w].indices)
-        np.testing.assert_array_equal(res[1][0][w].data, res[0][0][w].data)
+        # diagonal and upper entries: the stored values, bit for bit; lower entries are read from their mirror
+        # (symmetric storage): equal to the row-wise computed ones up to the rounding of (g_a w) g_b vs (g_b w) g_a
+        np.testing.assert_array_equal(sps.triu(res[1][0][w]).toarray(), sps.triu(res[0][0][w]).toarray())
+        scale = max(np.abs(res[0][0][w].data).max(), 1e-300)
+        np.testing.assert_allclose(res[1][0][w].data, res[0][0][w].data, rtol=0, atol=1e-14 * scale)
+        if w in (f.MAT_A11, f.MAT_A22, f.MAT_A12, f.MAT_A21):      # the blocks (K, M are integrated straight into CSR)
+            assert abs(res[1][0][w] - res[1][0][w].T).max() == 0.0  # exactly symmetric operators
     assert res[0][2:] == res[1][2:]
     np.testing.assert_allclose(res[1][1], res[0][1], rtol=0, atol=1e-10 * np.abs(res[0][1]).max())
 
@@ -863,7 +872,12 @@ def test_fused_assembly_equals_two_step(gpu_ctx_factory, dim, kind, nx, ny, nz, 
         for w in ref[0]:
             np.testing.assert_array_equal(got[0][w].indices, ref[0][w].indices)
             if exact:
-                np.testing.assert_array_equal(got[0][w].data, ref[0][w].data)
+                # same arithmetic: the stored (diagonal + upper) entries bit for bit; the fused path's lower entries are
+                # read from their mirror (symmetric stencil-ELL storage): rounding of (g_a w) g_b vs (g_b w) g_a apart
+                if w != f.MAT_MONO:      # (the monolithic matrix holds whole coupling blocks above its diagonal)
+                    np.testing.assert_array_equal(sp.triu(got[0][w]).toarray() if got[0][w].shape[0] < 3000 else sp.triu(got[0][w]).data,
+                                                  sp.triu(ref[0][w]).toarray() if ref[0][w].shape[0] < 3000 else sp.triu(ref[0][w]).data)
+                np.testing.assert_allclose(got[0][w].data, ref[0][w].data, rtol=0, atol=1e-14 * np.abs(ref[0][w].data).max())
             else:
                 np.testing.assert_allclose(got[0][w].data, ref[0][w].data, rtol=0, atol=1e-13 * np.abs(ref[0][w].data).max())
         # the lifting sums are reduced in a different lane order: last-bit differences only
@@ -951,7 +965,7 @@ def test_option_paths_agree(gpu_ctx_factory):
     f = _ffi()
     ref = None
     for opts in ({}, {"coarse_on_device": 0}, {"asm_ring": 200}, {"op_format": 0}, {"mg_fused": 0}, {"use_graphs": 0}, {"use_graphs": 2}, {"fetch_spin": 0},
-                 {"mg_tail_rows": 50}, {"mg_tail_rows": 0}, {"asm_tile": 0}, {"asm_tile": 2}, {"sell_rpt": 1},
+                 {"mg_tail_rows": 50}, {"mg_tail_rows": 0}, {"asm_tile": 0}, {"asm_tile": 2}, {"sell_rpt": 1}, {"sell_sym": 0},
                  {"sell_group": 4}):
         ctx, om, osys = _setup(gpu_ctx_factory, 3, o.CELL_HEX, 12, 8, 16)
         for k, v in opts.items():
