@@ -1523,7 +1523,7 @@ template <int DIM>
 __global__ __launch_bounds__(512) void k_asm_tile(const double* __restrict__ cx, const double* __restrict__ cy,
                                                   const double* __restrict__ cz, const int64_t* __restrict__ rowptr,
                                                   double* __restrict__ K, double* __restrict__ M, int nx, int ny, int nzl,
-                                                  int px, int py, int pz, int64_t n, FuseArgs fa) {
+                                                  int px, int py, int pz, int64_t n, FuseArgs fa, int probe) {
   using TG = TileGeo<DIM>;
   constexpr int NB = 1 << DIM;
   constexpr int TX = TG::TX, TY = TG::TY, TZ = TG::TZ;
@@ -1563,6 +1563,30 @@ __global__ __launch_bounds__(512) void k_asm_tile(const double* __restrict__ cx,
         if (f != e) d *= tile_fac((b >> f) & 1, (q >> f) & 1);
       sdN[q][b][e] = d;
     }
+  }
+  // per stencil slot: the incident cells that hold both the row node (corner cc) and the column node (corner b) - per
+  // direction d = 0 -> corner bit 0 or 1 for both, d = +1 -> (0, 1), d = -1 -> (1, 0): 8 / 4 / 2 / 1 cells for the
+  // diagonal / a face / an edge / a corner neighbour, listed in ascending cc (the summation order of k_gather_rows) -
+  // packed as 6-bit (cc | b << 3) fields, count in bits 48.., plus the flattened column offset of the slot
+  constexpr int NSLOT = (DIM == 3) ? 27 : 9;
+  __shared__ unsigned long long sCand[NSLOT];
+  __shared__ long long sOff[NSLOT];
+  if (tid < NSLOT) {
+    const int dd[3] = {tid % 3 - 1, (tid / 3) % 3 - 1, (DIM == 3) ? tid / 9 - 1 : 0};
+    unsigned long long pk = 0;
+    int cnt = 0;
+    for (int m = 0; m < NB; ++m) {
+      int b = 0;
+      bool okc = true;
+      for (int a = 0; a < DIM; ++a) {
+        const int bb = ((m >> a) & 1) + dd[a];
+        okc = okc && (bb == 0 || bb == 1);
+        b |= (bb & 1) << a;
+      }
+      if (okc) { pk |= (unsigned long long)(m | (b << 3)) << (6 * cnt); ++cnt; }
+    }
+    sCand[tid] = pk | ((unsigned long long)cnt << 48);
+    sOff[tid] = (long long)dd[0] + (long long)dd[1] * px + (long long)dd[2] * (long long)px * py;
   }
   const int tiles_x = (px + TX - 1) / TX, tiles_y = (py + TY - 1) / TY, tiles_z = (DIM == 3) ? (pz + TZ - 1) / TZ : 1;
   const int64_t ntiles = (int64_t)tiles_x * tiles_y * tiles_z;
@@ -1675,6 +1699,7 @@ __global__ __launch_bounds__(512) void k_asm_tile(const double* __restrict__ cx,
       }
     }
     __syncthreads();
+    if (probe == 1) continue;   // timing probe (asm_tile_probe): phase A only
     // ---- B: row c of the incident cell c of this lane's node
     const int gi = i0 + lx, gj = j0 + ly, gk = (DIM == 3) ? k0 + lz : 0;
     const bool innode = gi < px && gj < py && gk < pz;
@@ -1723,38 +1748,29 @@ __global__ __launch_bounds__(512) void k_asm_tile(const double* __restrict__ cx,
     }
     sOK[ln][c] = rowok ? 1 : 0;
     __syncthreads();
+    if (probe == 2) continue;   // timing probe: phases A and B
     // ---- C: stencil row of the node, lane c takes slots c, c + NB, ...; fused epilogue
     if (innode) {
-      constexpr int NSLOT = (DIM == 3) ? 27 : 9;
       const bool near = pnear != 0;
       const uint8_t r1 = near ? pr1 : 0, r2 = near ? pr2 : 0;
       double s11 = 0.0, s22 = 0.0, d11 = 0.0, d22 = 0.0, lK1 = 0.0, lK2 = 0.0, lM = 0.0;
       int64_t rp = 0;
       if (fa.ld == 0 || fa.keep_km) rp = rowptr[node];
-      for (int slot = c; slot < NSLOT; slot += NB) {
+      for (int slot = c; slot < ((probe == 5) ? 0 : NSLOT); slot += NB) {   // (timing probe 5: no slot loop at all)
         const int dx = slot % 3 - 1, dy = (slot / 3) % 3 - 1, dz = (DIM == 3) ? slot / 9 - 1 : 0;
         const int ni = gi + dx, nj = gj + dy, nk = gk + dz;
         if (ni < 0 || ni >= px || nj < 0 || nj >= py || nk < 0 || nk >= pz) continue;   // no such neighbour: pad / absent
-        const int dd[3] = {dx, dy, dz};
         double kv = 0.0, mv = 0.0;
-#pragma unroll 1
-        for (int m = 0; m < NB; ++m) {   // m: corner bits of the node in the candidate incident cell (order of k_gather_rows)
-          int cc = 0, b = 0;
-          bool okc = true;
-#pragma unroll
-          for (int a = 0; a < DIM; ++a) {
-            const int cb = (m >> a) & 1;
-            const int bb = cb + dd[a];
-            okc = okc && (bb == 0 || bb == 1);
-            cc |= cb << a;
-            b |= (bb & 1) << a;
-          }
-          if (okc && sOK[ln][cc]) {
+        const unsigned long long pk = sCand[slot];
+        const int ncand = (probe == 4) ? 0 : (int)(pk >> 48);   // (timing probe 4: no gather)
+        for (int q = 0; q < ncand; ++q) {
+          const int e = (int)(pk >> (6 * q)) & 63, cc = e & 7, b = e >> 3;
+          if (sOK[ln][cc]) {
             kv += sK[(ln * NB + cc) * RSTR + b];
             mv += sM[(ln * NB + cc) * RSTR + b];
           }
         }
-        const int32_t j = (int32_t)(node + dx + (int64_t)dy * px + (int64_t)dz * pxy);
+        const int32_t j = (int32_t)(node + sOff[slot]);
         // position of the entry in the CSR row = number of existing neighbours in the slots before this one
         int64_t kcsr = 0;
         if (fa.ld == 0 || fa.keep_km) {
@@ -1783,10 +1799,12 @@ __global__ __launch_bounds__(512) void k_asm_tile(const double* __restrict__ cx,
         const int so = fa.slot_of[sq], sc = fa.slot_of_c[sq];     // stored slots (-1: lower half of a symmetric operator)
         const int64_t ko = fa.ld ? (so < 0 ? -1 : (int64_t)so * fa.ld + node) : kcsr;
         const int64_t kc = fa.ld ? (sc < 0 ? -1 : (int64_t)sc * fa.ld + node) : kcsr;
-        if (ko >= 0) { fa.A11[ko] = o11; fa.A22[ko] = o22; }
-        if (kc >= 0) {
-          if (fa.A12) fa.A12[kc] = o12;
-          if (fa.A21) fa.A21[kc] = o21;
+        if (probe != 3) {   // (timing probe 3: everything but the operator stores)
+          if (ko >= 0) { fa.A11[ko] = o11; fa.A22[ko] = o22; }
+          if (kc >= 0) {
+            if (fa.A12) fa.A12[kc] = o12;
+            if (fa.A21) fa.A21[kc] = o21;
+          }
         }
         s11 += fabs(o11); s22 += fabs(o22);
         if (diag) { d11 = o11; d22 = o22; }
@@ -1859,10 +1877,10 @@ int pph_launch_fused_kernels(pph_ctx* ctx, MeshData& mesh, const FuseArgs& fa, d
     const int grid = (int)(ntiles < 256 * 16 ? ntiles : 256 * 16);
     if (mesh.kind == PPH_CELL_QUAD)
       hipLaunchKernelGGL(k_asm_tile<2>, dim3(grid), dim3(512), 0, ctx->stream, mesh.cx.p, mesh.cy.p, mesh.cz.p, mesh.rowptr.p,
-                         Kp, Mp, mesh.nx, mesh.ny, 0, mesh.px, mesh.py, 1, mesh.n, fa);
+                         Kp, Mp, mesh.nx, mesh.ny, 0, mesh.px, mesh.py, 1, mesh.n, fa, ctx->asm_tile_probe);
     else
       hipLaunchKernelGGL(k_asm_tile<3>, dim3(grid), dim3(512), 0, ctx->stream, mesh.cx.p, mesh.cy.p, mesh.cz.p, mesh.rowptr.p,
-                         Kp, Mp, mesh.nx, mesh.ny, mesh.nzl, mesh.px, mesh.py, mesh.pzl, mesh.n, fa);
+                         Kp, Mp, mesh.nx, mesh.ny, mesh.nzl, mesh.px, mesh.py, mesh.pzl, mesh.n, fa, ctx->asm_tile_probe);
     PPH_HIP(ctx, hipGetLastError());
     return PPH_OK;
   }

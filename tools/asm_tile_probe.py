@@ -1,0 +1,15 @@
+"""Where the tile assembly kernel spends its time: whole kernel vs phases A / A+B only (256^3 fine level)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from perphil_amd import _ffi
+import bench
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+ctx = _ffi.Context(0); ctx.mesh_build(3, _ffi.CELL_HEX, N, N, N)
+b, g1, g2 = bench.mms_boundary(N, 1.0, 1e-2, 1.0, 1.0)
+ctx.set_dirichlet(0, b, g1); ctx.set_dirichlet(1, b, g2)
+for probe in (0, 2, 3, 4, 5, 0):
+    ctx.set_option("asm_tile_probe", probe)
+    for _ in range(3):
+        ctx.set_option("invalidate_KM", 1)
+        ctx.assemble(1.0, 1e-2, 1.0, 1.0, monolithic=False)
+    print(f"probe {probe}: assemble {ctx.timers()['assemble_ms']:.3f} ms", flush=True)

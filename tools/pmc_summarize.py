@@ -14,6 +14,7 @@ import sys
 
 fetch_dir, write_dir, out, substr, steps = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5])
 label = sys.argv[6] if len(sys.argv) > 6 else substr
+symmetric = (len(sys.argv) > 7 and sys.argv[7] == "sym")
 
 
 def load(d):
@@ -36,6 +37,7 @@ for name in F:
     res["kernels"][name[:60]] = {"launches": len(f), "fetch_kb_mean": sum(f) / len(f), "write_kb_mean": sum(w) / max(len(w), 1),
                                  "fetch_kb_max": max(f), "write_kb_max": max(w) if w else 0.0}
     tot_f += sum(f); tot_w += sum(w); n += len(f)
+res["symmetric"] = symmetric
 res["launches_in_run"] = n
 res["launches_per_step"] = n // max(steps, 1)
 res["traffic_bytes_per_launch"] = (2.0 * tot_f + tot_w) * 1024.0 / max(n, 1)

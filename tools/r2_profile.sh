@@ -7,7 +7,7 @@ cp $(find $O/ks -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
 python3 tools/gap_hist.py $O/ks > $O/gaps256.txt
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pf -- python3 $B > $O/pf.json 2> $O/pf.err || { tail -5 $O/pf.err; exit 1; }
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pw -- python3 $B > $O/pw.json 2> $O/pw.err || { tail -5 $O/pw.err; exit 1; }
-python3 tools/pmc_summarize.py $O/pf $O/pw $O/pmc_spmv.json k_spmv_sell 2 k_spmv_sell > /dev/null
+python3 tools/pmc_summarize.py $O/pf $O/pw $O/pmc_spmv.json k_spmv_sell 2 k_spmv_sell sym > /dev/null
 python3 tools/pmc_summarize.py $O/pf $O/pw $O/pmc_asm.json k_asm_tile 2 k_asm_tile > /dev/null
 rocprofv3 -L > $O/counters.txt 2>&1
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $O/sq -- python3 tools/sell_probe_short.py > $O/sq.out 2> $O/sq.err || tail -5 $O/sq.err
