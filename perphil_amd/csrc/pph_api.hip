@@ -76,6 +76,10 @@ int pph_ctx_create(int device, pph_ctx** out) {
     return PPH_ERR_HIP;
   };
   if ((e = hipSetDevice(device)) != hipSuccess) return fail("hipSetDevice", e);
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->num_cus = cus;
+  }
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
   if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return fail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return fail("hipEventCreate", e);
@@ -539,6 +543,7 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
     release_system(ctx);
     return PPH_OK;
   }
+  if (!strcmp(name, "sell_zwalk_min_chunks")) { ctx->sell_zwalk_min_chunks = (int64_t)value; return PPH_OK; }
   if (!strcmp(name, "sell_zwalk")) { ctx->sell_zwalk = value > 0 ? (int)value : 0; return PPH_OK; }
   if (!strcmp(name, "sell_rpt")) { ctx->sell_rpt = (int)value; return PPH_OK; }
   if (!strcmp(name, "sell_blocks")) { ctx->sell_blocks = (int)value; return PPH_OK; }

@@ -231,6 +231,7 @@ void ilu_release(IluData& I);
 
 struct pph_ctx {
   int device = 0;
+  int num_cus = 256;                    // compute units of the device (hipDeviceProp_t::multiProcessorCount)
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::string err;
@@ -343,6 +344,7 @@ struct pph_ctx {
   // operator format of the scalar blocks inside the block solves / Picard sweeps: 1 stencil-ELL (pph_sell.hip), 0 CSR
   int op_format = 1;
   int sell_sym = 1;                     // stencil-ELL operators store the diagonal and the upper slots only (symmetric blocks)
+  int64_t sell_zwalk_min_chunks = 8192; // levels with fewer 512-row chunks keep the plain chunk order
   int sell_zwalk = 4;                   // > 0 (symmetric operators, 3D): a workgroup walks this many consecutive node planes at one in-plane position
   int sell_rpt = 2, sell_blocks = 0, sell_group = 0;   // SELL SpMV tuning: rows per thread, grid cap, XCD chunk group
   DevBuf<double> sell_tmp;              // SELL copy of the matrix last selected by pph_spmv / pph_spmv_bench

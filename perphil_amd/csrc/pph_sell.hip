@@ -174,7 +174,7 @@ static void sell_launch_mode(pph_ctx* ctx, int mode, int grid, const Sell& E, co
                              double* part, int64_t dlo, int64_t dhi) {
   const int64_t pxy = (int64_t)E.px * E.py;
   const int64_t halo = (E.pz > 1 ? pxy : 0) + E.px + 2;   // reach of the x window of a row (2D: no z lines)
-  const int zwalk = (E.sym && E.pz > 2 && ctx->sell_zwalk > 0 && nchunks >= 8192) ? ctx->sell_zwalk : 0;   // (no gain on full storage)
+  const int zwalk = (E.sym && E.pz > 2 && ctx->sell_zwalk > 0 && nchunks >= ctx->sell_zwalk_min_chunks) ? ctx->sell_zwalk : 0;   // (no gain on full storage)
 #define PPH_SELL_GO(MM)                                                                                              \
   hipLaunchKernelGGL((k_spmv_sell<KIND, MM, RPT>), dim3(grid), dim3(256), 0, ctx->stream, E.val, E.ld, x, b, dinv, w, \
                      y, n, E.px, pxy, halo, nchunks, group, zwalk, part, dlo, dhi)
@@ -207,10 +207,13 @@ int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x,
               const double* w, double* y, double* part, int64_t dlo, int64_t dhi) {
   const int rpt = (ctx->sell_rpt == 1) ? 1 : 2;
   const int64_t nchunks = ceil_div64(n, 256 * rpt);
-  // grid: persistent, 2048 workgroups; 4096 with the z-walk order of symmetric operators (measured on the 256^3 block:
-  // 0.58 -> 0.51 ms; profiles/r02_sell_sym_probe_256.txt)
-  const bool zw = E.sym && E.pz > 2 && ctx->sell_zwalk > 0 && nchunks >= 8192;   // (smaller levels: one chunk per workgroup anyway)
-  int cap = (ctx->sell_blocks >= 8 && ctx->sell_blocks <= 8192) ? (ctx->sell_blocks / 8) * 8 : (zw ? 4096 : 2048);
+  // grid: persistent, 2048 workgroups; with the z-walk order of symmetric operators ONE workgroup per CU: the value a
+  // plane reads a second time must still be in the XCD's 4 MB L2, and every resident workgroup streams 57 KB per plane
+  // step (measured on the 256^3 block: 0.58 ms plain order, 0.51 ms z-walk with 4096 workgroups, 0.47 ms with 256;
+  // profiles/r02_sell_sym_probe_256.txt, r02_sell_sym_probe2_256.txt)
+  const bool zw = E.sym && E.pz > 2 && ctx->sell_zwalk > 0 && nchunks >= ctx->sell_zwalk_min_chunks;   // (smaller levels: too few chunks per workgroup)
+  int cap = (ctx->sell_blocks >= 8 && ctx->sell_blocks <= 8192) ? (ctx->sell_blocks / 8) * 8
+                                                                 : (zw ? ((ctx->num_cus + 7) / 8) * 8 : 2048);
   if ((mode == 2 || mode == 4) && cap > 4096) cap = 4096;   // one partial sum per workgroup (PART_STRIDE of pph_la.hip)
   int64_t g = nchunks < cap ? nchunks : cap;
   g = ((g + 7) / 8) * 8;
