@@ -34,11 +34,11 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def picard_cfg(_ffi, inner_rtol=1e-10, smooth=2, reduction=0.0, inner_norm=0):
+def picard_cfg(_ffi, inner_rtol=1e-10, smooth=2, reduction=0.0, inner_norm=0, inner_max_it=50000):
     cfg = _ffi.SolverCfg()
     cfg.ksp_type, cfg.pc_type, cfg.restart, cfg.max_it = _ffi.KSP_GMRES, _ffi.PC_FIELDSPLIT, 30, 50000
     cfg.rtol, cfg.atol = 1e-8, 1e-12
-    cfg.inner_ksp_type, cfg.inner_pc_type, cfg.inner_max_it = _ffi.KSP_CG, _ffi.PC_MG, 50000
+    cfg.inner_ksp_type, cfg.inner_pc_type, cfg.inner_max_it = _ffi.KSP_CG, _ffi.PC_MG, inner_max_it
     cfg.inner_rtol, cfg.inner_atol = inner_rtol, 1e-300
     cfg.picard, cfg.picard_rtol, cfg.picard_atol, cfg.picard_max_it = 1, 1e-8, 1e-12, 100
     cfg.mg_smooth = smooth
@@ -170,8 +170,10 @@ def main():
     ap.add_argument("--inner-rtol", type=float, default=1e-10)
     ap.add_argument("--smooth", type=int, default=1)
     ap.add_argument("--inner-reduction", type=float, default=1e-1)
-    ap.add_argument("--inner-norm", type=int, default=1, choices=(0, 1),
-                    help="norm tested by the block solves: 0 preconditioned, 1 unpreconditioned")
+    ap.add_argument("--inner-norm", type=int, default=1, choices=(0, 1, 2),
+                    help="norm tested by the block solves: 0 preconditioned, 1 unpreconditioned, 2 none (exactly "
+                         "--inner-max-it iterations per block solve: launch-only sweeps)")
+    ap.add_argument("--inner-max-it", type=int, default=50000, help="iteration limit of a block solve (A/B experiments)")
     ap.add_argument("--asm-kernel", type=int, default=2)
     ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
                     help="extra pph_set_option settings for A/B runs (e.g. spmv_kernel=8)")
@@ -230,7 +232,7 @@ def main():
         b, g1, g2 = mms_boundary(N, k1, k2, beta, mu)
         ctx.set_dirichlet(0, b, g1)
         ctx.set_dirichlet(1, b, g2)
-        cfg = picard_cfg(_ffi, args.inner_rtol, args.smooth, args.inner_reduction, args.inner_norm)
+        cfg = picard_cfg(_ffi, args.inner_rtol, args.smooth, args.inner_reduction, args.inner_norm, args.inner_max_it)
         ctx.set_option("asm_kernel", args.asm_kernel)
         for kv in args.set:
             ctx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
@@ -386,9 +388,11 @@ def main():
             "workload": f"3D UnitCube {N}^3 Q1, two-pressure DPP (k1=1, k2=1e-2, beta=mu=1), manufactured Dirichlet data, "
                         f"assemble + block Picard (fixed-stress) to snes_rtol 1e-8 (true residual), warm-started block solves = "
                         f"CG + geometric multigrid (Chebyshev-Jacobi V({args.smooth},{args.smooth})) on {'stencil-ELL' if sell else 'CSR'} "
-                        f"scalar blocks, each to a "
-                        f"reduction of the {'unpreconditioned' if args.inner_norm else 'preconditioned'} residual by "
-                        f"{args.inner_reduction:g} (or rtol {args.inner_rtol:g})",
+                        f"scalar blocks, each "
+                        + (f"of exactly {args.inner_max_it} CG iteration(s), no inner convergence test (launch-only sweeps)"
+                           if args.inner_norm == 2 else
+                           f"to a reduction of the {'unpreconditioned' if args.inner_norm else 'preconditioned'} residual by "
+                           f"{args.inner_reduction:g} (or rtol {args.inner_rtol:g})"),
             "preallocation": "outside the timed step: mesh, sparsity pattern, boundary-data upload (setup_ms) and the first "
                              "step's buffer / multigrid-hierarchy allocation (cold_step_ms = that first step)",
             "setup_ms": round(setup_ms, 2), "cold_step_ms": None if cold_ms is None else round(cold_ms, 2),

@@ -88,7 +88,9 @@ typedef struct {
                           * preconditioned ||P^-1 r|| (PETSc's default for left-preconditioned CG), 1 =
                           * unpreconditioned ||r||_2 (KSP_NORM_UNPRECONDITIONED): the recurrence residual is
                           * known before the preconditioner runs, so a block solve of k iterations costs k
-                          * preconditioner applications instead of k + 1                          */
+                          * preconditioner applications instead of k + 1; 2 = none (KSP_NORM_NONE): no convergence
+                          * test, every block solve runs exactly inner_max_it CG iterations - a Picard sweep then
+                          * holds no host decision and is enqueued (replayed from a hipGraph) in one go              */
   int32_t reserved0;
 } pph_solver_cfg;
 

@@ -555,6 +555,30 @@ static ksp_out pcg(csys* S, int which, int pc, int smooth, const double* b, doub
   const double* dinv = S->H[which].nlev ? S->H[which].lv[0].dinv : NULL;
   double *r = w, *z = w + n, *p = w + 2 * n, *q = w + 3 * n;
   ksp_out out = {0, 0.0, 0};
+  if (norm == 2) {
+    /* KSP_NORM_NONE: exactly max_it iterations, no convergence test (PETSc: ksp_norm_type none + ksp_max_it);
+     * no preconditioner application after the last update */
+    if (warm) resid(M, A, x, b, r);
+    else { vzero(n, x); vcopy(n, b, r); }
+    apply_pc(S, which, pc, smooth, dinv, r, z);
+    vcopy(n, z, p);
+    double rz = dot(n, r, z);
+    while (out.its < max_it) {
+      spmv(M, A, p, q);
+      const double alpha = rz / dot(n, p, q);
+      axpy(n, alpha, p, x);
+      axpy(n, -alpha, q, r);
+      out.its++;
+      if (out.its == max_it) break;
+      apply_pc(S, which, pc, smooth, dinv, r, z);
+      const double rzn = dot(n, r, z);
+      xpby(n, z, rzn / rz, p);
+      rz = rzn;
+    }
+    out.res = sqrt(dot(n, r, r));
+    out.converged = 1;
+    return out;
+  }
   if (norm == 1) {
     const double bnorm = sqrt(dot(n, b, b));
     if (warm) resid(M, A, x, b, r);

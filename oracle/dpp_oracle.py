@@ -375,6 +375,24 @@ def pcg(A, b, M_apply: Optional[Callable] = None, rtol=1e-8, atol=1e-12, max_it=
     prec = (lambda v: v) if M_apply is None else M_apply
     x = np.zeros_like(b) if x0 is None else x0.copy()
     r = b - A @ x if x0 is not None else b.copy()
+    if norm == "none":
+        # KSP_NORM_NONE: exactly max_it iterations, no test (ksp_norm_type none + ksp_max_it)
+        z = prec(r)
+        p = z.copy()
+        rz = float(np.dot(r, z))
+        for it in range(max_it):
+            Ap = A @ p
+            alpha = rz / float(np.dot(p, Ap))
+            x += alpha * p
+            r -= alpha * Ap
+            if it == max_it - 1:
+                break
+            z = prec(r)
+            rz_new = float(np.dot(r, z))
+            p = z + (rz_new / rz) * p
+            rz = rz_new
+        res = float(np.linalg.norm(r))
+        return KspResult(x, max_it, res, [res], True)
     if norm == "unpreconditioned":
         res = float(np.linalg.norm(r))
         tol = max(rtol * float(np.linalg.norm(b)), atol, reduction * res)

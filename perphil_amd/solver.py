@@ -90,9 +90,13 @@ def _inner_cfg(cfg: _ffi.SolverCfg, subs: List[Dict], notes: List[str]) -> None:
     # inexact block solves: ksp_norm_type of the sub-solvers (PETSc's option name) and the residual reduction each
     # block solve has to reach from its own starting residual (pph_reduction; 0 = ksp_rtol only)
     norms = {str(s.get("ksp_norm_type", "preconditioned")).lower() for s in subs}
-    if len(norms) != 1 or norms - {"preconditioned", "unpreconditioned"}:
-        raise NotImplementedError("fieldsplit ksp_norm_type must be preconditioned or unpreconditioned on both blocks")
-    cfg.inner_norm = 1 if norms.pop() == "unpreconditioned" else 0
+    if len(norms) != 1 or norms - {"preconditioned", "unpreconditioned", "none"}:
+        raise NotImplementedError("fieldsplit ksp_norm_type must be preconditioned, unpreconditioned or none on both blocks")
+    cfg.inner_norm = {"preconditioned": 0, "unpreconditioned": 1, "none": 2}[norms.pop()]
+    if cfg.inner_norm == 2:
+        # PETSc's KSP_NORM_NONE: no convergence test, exactly ksp_max_it iterations per block solve
+        if cfg.inner_ksp_type != _ffi.KSP_CG or not maxits:
+            raise NotImplementedError("ksp_norm_type none needs ksp_type cg and a ksp_max_it on both blocks")
     reds = [float(s["pph_reduction"]) for s in subs if "pph_reduction" in s]
     cfg.inner_reduction = max(reds) if reds else 0.0
 

@@ -78,6 +78,14 @@ PICARD_MG_INEXACT_SOLVER_PARAMS: dict = {
     **_PICARD_BASE, **_FIELDSPLIT_BASE, "pph_mg_smooth": 1,
     "fieldsplit_0": dict(_INEXACT_BLOCK), "fieldsplit_1": dict(_INEXACT_BLOCK),
 }
+# the launch-only variant: block solves of exactly one multigrid-preconditioned CG iteration, no inner convergence
+# test (PETSc: ksp_norm_type none + ksp_max_it 1) - a sweep holds no host decision and is replayed from a hipGraph;
+# fastest where kernels are short (<= 128^3), 8 instead of 6 sweeps at the same number of CG iterations
+_FIXED_BLOCK = {"ksp_type": "cg", "pc_type": "mg", "ksp_norm_type": "none", "ksp_max_it": 1}
+PICARD_MG_FIXED_SOLVER_PARAMS: dict = {
+    **_PICARD_BASE, **_FIELDSPLIT_BASE, "pph_mg_smooth": 1,
+    "fieldsplit_0": dict(_FIXED_BLOCK), "fieldsplit_1": dict(_FIXED_BLOCK),
+}
 PICARD_JACOBI_SOLVER_PARAMS: dict = {
     **_PICARD_BASE, **_FIELDSPLIT_BASE,
     "fieldsplit_0": {"ksp_type": "cg", "pc_type": "jacobi", "ksp_rtol": 1e-10},

@@ -723,11 +723,14 @@ def test_config5_256cubed_tets_gmres_fieldsplit(gpu_ctx_factory, goldens):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("hexa,N,norm,red", [(True, 96, 0, 1e-2), (False, 48, 0, 1e-2), (True, 96, 1, 1e-1), (False, 48, 1, 1e-1),
-                                             (True, 40, 1, 3e-2)])
+                                             (True, 40, 1, 3e-2),
+                                             # no inner convergence test (ksp_norm_type none): exactly `red` CG iterations
+                                             # per block solve, sweeps replayed from a graph
+                                             (True, 96, 2, 1), (False, 48, 2, 1), (True, 40, 2, 2), (True, 64, 2, 3)])
 def test_hip_matches_cpu_port_mid_size(gpu_ctx_factory, hexa, N, norm, red):
     """HIP path vs the C/OpenMP restatement (oracle/dpp_cpu.c) at sizes the NumPy oracle cannot reach in seconds:
     K/M/blocks entry for entry, right-hand side, and the bench's inexact-Picard solve (same sweeps, same number
-    of CG iterations, same solution)."""
+    of CG iterations, same solution); norm 2 = the launch-only variant with a fixed iteration count per block solve."""
     from oracle import dpp_cpu as cpu
 
     cpu.set_threads(8)     # fixed reduction order of the C port, whatever the host offers
@@ -756,9 +759,15 @@ def test_hip_matches_cpu_port_mid_size(gpu_ctx_factory, hexa, N, norm, red):
     r, _ = ctx.rhs()
     np.testing.assert_allclose(r, r_ref, rtol=0, atol=1e-12 * np.abs(r_ref).max())
     S.mg_setup()
-    x_ref, sweeps, inner, res = S.picard(reduction=red, inner_norm=norm)
-    xs, info, _ = ctx.solve(_cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_MG, inner_rtol=1e-10,
-                                 inner_reduction=red, inner_norm=norm, mg_smooth=1, picard_rtol=1e-8, picard_max_it=100))
+    if norm == 2:
+        kits = int(red)
+        x_ref, sweeps, inner, res = S.picard(reduction=0.0, inner_norm=2, inner_max_it=kits)
+        xs, info, _ = ctx.solve(_cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_MG, inner_rtol=1e-10,
+                                     inner_max_it=kits, inner_norm=2, mg_smooth=1, picard_rtol=1e-8, picard_max_it=100))
+    else:
+        x_ref, sweeps, inner, res = S.picard(reduction=red, inner_norm=norm)
+        xs, info, _ = ctx.solve(_cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_MG, inner_rtol=1e-10,
+                                     inner_reduction=red, inner_norm=norm, mg_smooth=1, picard_rtol=1e-8, picard_max_it=100))
     assert info.converged and info.iterations == sweeps and info.inner_iterations == inner
     assert np.abs(xs - x_ref).max() <= 1e-9 * np.abs(x_ref).max()
     assert info.resnorm == pytest.approx(res, rel=1e-3)

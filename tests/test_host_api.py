@@ -99,6 +99,11 @@ def test_option_translation():
     assert cfg.inner_reduction == 0.1 and cfg.inner_rtol == 1e-10
     cfg, _ = translate_options(sp.PICARD_MG_SOLVER_PARAMS, nonlinear=True)
     assert cfg.inner_norm == 0 and cfg.inner_reduction == 0.0
+    cfg, _ = translate_options(sp.PICARD_MG_FIXED_SOLVER_PARAMS, nonlinear=True)     # ksp_norm_type none + ksp_max_it 1
+    assert (cfg.inner_norm, cfg.inner_max_it, cfg.mg_smooth, cfg.inner_ksp_type) == (2, 1, 1, _ffi.KSP_CG)
+    with pytest.raises(NotImplementedError):
+        translate_options({**sp.PICARD_MG_SOLVER_PARAMS, "fieldsplit_0_ksp_norm_type": "none",
+                           "fieldsplit_1_ksp_norm_type": "none"}, nonlinear=True)       # no ksp_max_it given
     with pytest.raises(NotImplementedError):
         translate_options({**sp.PICARD_MG_SOLVER_PARAMS, "fieldsplit_0_ksp_norm_type": "natural"}, nonlinear=True)
     cfg, info = translate_options(sp.GMRES_ILU_PARAMS)          # the stated preconditioner, no substitution
