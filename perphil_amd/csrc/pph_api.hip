@@ -544,6 +544,7 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
     return PPH_OK;
   }
   if (!strcmp(name, "sell_zwalk_min_chunks")) { ctx->sell_zwalk_min_chunks = (int64_t)value; return PPH_OK; }
+  if (!strcmp(name, "sell_xmap")) { ctx->sell_xmap = value != 0; la_release_graphs(ctx); return PPH_OK; }
   if (!strcmp(name, "sell_zwalk")) { ctx->sell_zwalk = value > 0 ? (int)value : 0; return PPH_OK; }
   if (!strcmp(name, "sell_rpt")) { ctx->sell_rpt = (int)value; return PPH_OK; }
   if (!strcmp(name, "sell_blocks")) { ctx->sell_blocks = (int)value; return PPH_OK; }

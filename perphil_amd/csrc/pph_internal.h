@@ -66,6 +66,7 @@ struct MeshData;
 // (slot s and S-1-s carry opposite offsets), so only the diagonal and the UPPER slots are stored: val[(s - S/2)][row]
 // for s >= S/2.  Entry (r, r + o) with o < 0 is read as entry (r + o, r) from the mirror slot of row r + o: every stored
 // value is used by two rows, S/2 + 1 instead of S streams.
+#define PPH_SELL_COLUMN_WALK 1000   // sell_zwalk >= this: balanced column walk (pph_sell.hip)
 struct Sell {
   const double* val = nullptr;
   int64_t ld = 0;            // leading dimension: rows rounded up to a multiple of 64
@@ -332,6 +333,8 @@ struct pph_ctx {
   int device_scalars = 0;               // 1: the device-scalar CG branch also over the callback transport (tests)
   int mg_fused = 1;                     // V(1,1) cycles on stencil-ELL levels: fused smoother / transfer kernels and the
                                         // single-workgroup tail (pph_mg.hip); 0: the general kernel-per-operation cycle
+  DevBuf<double> mg_tail_pack[2];       // operators / inverse diagonals / masks of the tail levels, packed per assembly
+  int mg_tail_lt[2] = {-1, -1};         // first tail level the pack was built for
   int64_t mg_tail_rows = 5000;          // levels with at most this many rows are handled inside the tail kernel
   int coarse_max_it = 500;              // iteration limit of the coarsest-level Jacobi-CG (to rtol 1e-12)
   int coarse_failed = 0;                // host-driven coarsest solves of the last solve that stopped at their iteration limit
@@ -346,6 +349,7 @@ struct pph_ctx {
   int sell_sym = 1;                     // stencil-ELL operators store the diagonal and the upper slots only (symmetric blocks)
   int64_t sell_zwalk_min_chunks = 8192; // levels with fewer 512-row chunks keep the plain chunk order
   int sell_zwalk = 4;                   // > 0 (symmetric operators, 3D): a workgroup walks this many consecutive node planes at one in-plane position
+  int sell_xmap = 1;                    // z-walk: consecutive in-plane positions on one XCD
   int sell_rpt = 2, sell_blocks = 0, sell_group = 0;   // SELL SpMV tuning: rows per thread, grid cap, XCD chunk group
   DevBuf<double> sell_tmp;              // SELL copy of the matrix last selected by pph_spmv / pph_spmv_bench
 };
@@ -379,6 +383,11 @@ void la_spmv(pph_ctx* ctx, const Csr& A, const double* x, double* y);
 void la_spmv_resid(pph_ctx* ctx, const Csr& A, const double* x, const double* b, double* y);  // y = b - A x
 // dot_slot >= 0: also scal[dot_slot] = b . y over the rows [dlo, dhi)
 // x_ghosts_valid: the ghost planes of x already hold the owners' values (no exchange before the product)
+// t = (b ? b - A x : A x) ;  R += sign (t - told) ;  told = t ;  scal[slot] = sum of R^2 over [dlo, dhi)   (sign = +1 with
+// b, -1 without: the Picard sweeps' coupling product + residual bookkeeping + norm in one pass; `tmp`: n doubles,
+// used when A has no stencil-ELL copy)
+void la_spmv_shift(pph_ctx* ctx, const Csr& A, const double* x, const double* b, double* R, double* told, double* tmp,
+                   int slot, int64_t dlo, int64_t dhi);
 void la_spmv_jacobi(pph_ctx* ctx, const Csr& A, const double* x, const double* b, const double* dinv,
                     const double* w /* device */, double* y, int dot_slot = -1, int64_t dlo = 0, int64_t dhi = 0,
                     bool x_ghosts_valid = false);

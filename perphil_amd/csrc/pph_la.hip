@@ -317,6 +317,24 @@ void la_spmv_jacobi(pph_ctx* ctx, const Csr& A, const double* x, const double* b
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, ctx->stream, partials(ctx), grid, ctx->scal.p + dot_slot);
 }
 
+void la_spmv_shift(pph_ctx* ctx, const Csr& A, const double* x, const double* b, double* R, double* told, double* tmp,
+                   int slot, int64_t dlo, int64_t dhi) {
+  if (!A.ell.val) {
+    if (b) la_spmv_resid(ctx, A, x, b, tmp); else la_spmv(ctx, A, x, tmp);
+    la_shift(ctx, R, told, tmp, b ? 1.0 : -1.0, A.nrows);
+    la_dot(ctx, R + dlo, R + dlo, dhi - dlo, slot);
+    return;
+  }
+  if (A.geom) (void)la_halo(ctx, *A.geom, const_cast<double*>(x));
+  double* part = partials(ctx);
+  const int grid = sell_spmv(ctx, A.ell, A.nrows, b ? 5 : 6, x, b, nullptr, nullptr, told, part, dlo, dhi, R);
+  const double bytes = (8.0 * sell_stored(A.ell.kind, A.ell.sym) + 16.0 + (b ? 8.0 : 0.0) + 24.0) * (double)A.nrows;
+  ctx->n_spmv[0]++;
+  ctx->spmv_bytes[0] += bytes;
+  if (A.nrows >= ctx->mesh.n) { ctx->n_spmv_fine++; ctx->spmv_bytes_fine += bytes; }
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, ctx->stream, part, grid, ctx->scal.p + slot);
+}
+
 void la_spmv_dot(pph_ctx* ctx, const Csr& A, const double* x, double* y, int slot, int copy_src, int copy_dst) {
   double* part = partials(ctx);
   const int grid = spmv_dispatch<true>(ctx, A, x, nullptr, y, part);

@@ -351,6 +351,7 @@ void mg_release(pph_ctx* ctx) {
   }
   ctx->mg.clear();
   ctx->mg_w.release();
+  for (int f = 0; f < 2; ++f) { ctx->mg_tail_pack[f].release(); ctx->mg_tail_lt[f] = -1; }
   la_release_graphs(ctx);   // captured iteration bodies hold the hierarchy's pointers
   ctx->mg_epoch++;
   ctx->mg_ok = false;
@@ -386,6 +387,8 @@ static int comm_max_double(pph_ctx* ctx, double v, double* out) {
 // same global hierarchy; level l is DISTRIBUTED (each rank a sub-slab with ghost planes) while the owned
 // cell range of every rank is divisible by 2^l and keeps >= 2 layers, and REPLICATED (whole coarse mesh on
 // every rank, right-hand side summed by one all-reduce) below that, so the cycle equals the 1-GPU one.
+static int mg_tail_pack(pph_ctx* ctx, int which);
+
 int mg_setup(pph_ctx* ctx) {
   if (ctx->mg_ok) return PPH_OK;
   const bool build = !ctx->mg_struct_ok;  // level meshes / patterns / buffers survive re-assembly
@@ -562,6 +565,7 @@ int mg_setup(pph_ctx* ctx) {
   if (build) ctx->mg_epoch++;
   ctx->mg_struct_ok = true;
   ctx->mg_ok = true;
+  for (int f = 0; f < 2; ++f) PPH_TRY(mg_tail_pack(ctx, f));
   return PPH_OK;
 }
 
@@ -723,21 +727,101 @@ __global__ __launch_bounds__(1024) void k_coarse_cg_sell(const double* __restric
 #define MG_TAIL_MAX 4
 #define MG_TAIL_ROWS 1024          // rows of the largest tail level = threads of the workgroup
 #define MG_TAIL_MATPOOL 6144       // doubles of LDS for the operators of tail levels 1..
+// The operators, inverse diagonals and masks of the tail levels are the same for every cycle of a solve: mg_setup
+// packs them once per assembly (k_tail_pack) into one buffer in the order the kernel consumes them - level 0 as full
+// rows, slot-major (symmetric storage resolved: thread i reads its S entries coalesced), the operators of levels
+// 1.. as the LDS image (one flat copy), then the inverse diagonals, then the masks as bytes.
 struct TailLevel {
-  const double* A;        // stencil-ELL operator
-  int sym;                // its storage (Sell::sym)
-  int64_t ld;
-  const double* dinv;
-  const uint8_t* mask;
   int px, py, pz, n;
   const double* w;        // 1 / theta of the one-step Chebyshev smoother (device)
 };
 struct TailArgs {
-  int nl;
   TailLevel L[MG_TAIL_MAX];
+  const double* pack;
   const double* b0;       // right-hand side of tail level 0 (global)
   double* x0;             // its solution (global)
 };
+struct TailSrc {          // source of the pack: the level's stencil-ELL operator
+  const double* A;
+  int sym;
+  int64_t ld;
+  const double* dinv;
+  const uint8_t* mask;
+  int px, py, pz, n;
+};
+struct TailPackArgs {
+  int nl;
+  TailSrc L[MG_TAIL_MAX];
+};
+
+// doubles of the pack in front of the masks / bytes of the masks (each level padded to 8)
+__host__ __device__ inline int tail_pack_doubles(const int* n, int nl, int S) {
+  int d = 0;
+  for (int l = 0; l < nl; ++l) d += (S + 1) * n[l];
+  return d;
+}
+__host__ __device__ inline int tail_pack_maskbytes(const int* n, int nl) {
+  int b = 0;
+  for (int l = 0; l < nl; ++l) b += (n[l] + 7) & ~7;
+  return b;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_tail_pack(TailPackArgs pa, double* __restrict__ pack) {
+  using ST = SellSt<KIND>;
+  constexpr int S = ST::S;
+  const int nl = pa.nl;
+  int ns[MG_TAIL_MAX];
+  for (int l = 0; l < MG_TAIL_MAX; ++l) ns[l] = l < nl ? pa.L[l].n : 0;
+  const int gt = blockIdx.x * blockDim.x + threadIdx.x, gn = gridDim.x * blockDim.x;
+  // operators: level 0 at 0, its inverse diagonal behind it, then levels 1.., then their inverse diagonals
+  int offA = 0, offD = 0;
+  for (int l = 1; l < nl; ++l) offD += S * ns[l];
+  offD += (S + 1) * ns[0];
+  for (int l = 0; l < nl; ++l) {
+    const TailSrc F = pa.L[l];
+    const int base = (l == 0) ? 0 : offA;
+    for (int e = gt; e < S * F.n; e += gn) {
+      const int slot = e / F.n, row = e % F.n;
+      double v;
+      if (!F.sym) v = F.A[(int64_t)slot * F.ld + row];
+      else {
+        constexpr int C0 = S / 2;
+        if (slot >= C0) v = F.A[(int64_t)(slot - C0) * F.ld + row];
+        else {
+          // lower entry = the mirror slot of the row it points to
+          int sl = 0, off = 0;
+          for (int q = 0; q < ST::NL; ++q) {
+            const int mask = ST::mask(q);
+            for (int d = 0; d < 3; ++d) {
+              if (!((mask >> d) & 1)) continue;
+              if (sl == slot) off = (d - 1) + ST::dy(q) * F.px + ST::dz(q) * F.px * F.py;
+              ++sl;
+            }
+          }
+          const int rr = row + off;
+          v = (rr >= 0 && rr < F.n) ? F.A[(int64_t)(S - 1 - slot - C0) * F.ld + rr] : 0.0;
+        }
+      }
+      pack[base + e] = v;
+    }
+    if (l == 0) {
+      for (int i = gt; i < F.n; i += gn) pack[S * F.n + i] = F.dinv[i];
+      offA = (S + 1) * F.n;
+    } else {
+      for (int i = gt; i < F.n; i += gn) pack[offD + i] = F.dinv[i];
+      offA += S * F.n;
+      offD += F.n;
+    }
+  }
+  uint8_t* mb = reinterpret_cast<uint8_t*>(pack + tail_pack_doubles(ns, nl, S));
+  for (int l = 0; l < nl; ++l) {
+    const TailSrc F = pa.L[l];
+    const int padded = (F.n + 7) & ~7;
+    for (int i = gt; i < padded; i += gn) mb[i] = i < F.n ? F.mask[i] : 0;
+    mb += padded;
+  }
+}
 
 // row i of A v with the operator row in a[] (stride astride between slots: 1 for registers, n for an LDS operator
 // stored slot-major) and v in LDS; neighbours outside the box carry a zero entry, their index is clamped
@@ -763,77 +847,100 @@ __device__ __forceinline__ double tail_row(const double* a, int astride, const d
   return s;
 }
 
-template <int KIND>
+// weight of the transfer tap (dx, dy, dz) of make_transfer_stencil(kind); 0: not a tap
+__host__ __device__ constexpr double tail_tap_weight(int kind, int dx, int dy, int dz) {
+  const int nzc = (dx != 0) + (dy != 0) + (dz != 0);
+  if (kind == PPH_CELL_QUAD || kind == PPH_CELL_HEX) return nzc == 0 ? 1.0 : (nzc == 1 ? 0.5 : (nzc == 2 ? 0.25 : 0.125));
+  if (kind == PPH_CELL_TRI) return (dx * dy > 0) ? 0.0 : (nzc == 0 ? 1.0 : 0.5);
+  const bool pos = dx >= 0 && dy >= 0 && dz >= 0, neg = dx <= 0 && dy <= 0 && dz <= 0;
+  return (pos || neg) ? (nzc == 0 ? 1.0 : 0.5) : 0.0;
+}
+
+// sum over the first wave only (coarsest level of at most 64 rows: the other waves hold zeros - the result equals
+// coarse_block_sum's, which adds their zeros in order)
+__device__ __forceinline__ double tail_wave_sum(double v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return __shfl(v, 0, 64);
+}
+#define TAIL_WAVE_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+template <int KIND, int NL>
 __global__ __launch_bounds__(1024) void k_mg_tail(TailArgs ta, TStencil ts, int tk, double cg_rtol, int cg_max_it) {
   using ST = SellSt<KIND>;
+  constexpr int S = ST::S;
   extern __shared__ double sm[];
   __shared__ double red[16];
   const int tid = threadIdx.x;
-  const int nl = ta.nl;
   // LDS layout: per level x, b, t (t = residual on the way down, interpolated iterate on the way up); the coarsest
   // level also p, q of its CG; then the operators of levels 1.. (slot-major), then the masks as bytes
-  double *X[MG_TAIL_MAX], *B[MG_TAIL_MAX], *T[MG_TAIL_MAX], *M[MG_TAIL_MAX];
+  double *X[NL], *B[NL], *T[NL], *M[NL];
+  uint8_t* MK[NL];
+  int ns[NL];
   int off = 0;
-  for (int l = 0; l < nl; ++l) {
-    const int n = ta.L[l].n;
-    X[l] = sm + off; B[l] = X[l] + n; T[l] = B[l] + n;
-    off += 3 * n;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    ns[l] = ta.L[l].n;
+    X[l] = sm + off; B[l] = X[l] + ns[l]; T[l] = B[l] + ns[l];
+    off += 3 * ns[l];
   }
-  double* P = sm + off; double* Q = P + ta.L[nl - 1].n;
-  off += 2 * ta.L[nl - 1].n;
+  double* P = sm + off; double* Q = P + ns[NL - 1];
+  off += 2 * ns[NL - 1];
+  double* const Mbase = sm + off;
+  int mat_tot = 0;
   M[0] = nullptr;
-  for (int l = 1; l < nl; ++l) { M[l] = sm + off; off += ST::S * ta.L[l].n; }
-  uint8_t* MK[MG_TAIL_MAX];
+#pragma unroll
+  for (int l = 1; l < NL; ++l) { M[l] = Mbase + mat_tot; mat_tot += S * ns[l]; }
+  uint8_t* const MKbase = reinterpret_cast<uint8_t*>(Mbase + mat_tot);
+  int mk_tot = 0;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) { MK[l] = MKbase + mk_tot; mk_tot += (ns[l] + 7) & ~7; }
+  // ---- load from the pack: operator row of level 0 into registers, the other operators and the masks into LDS
+  const double* pk = ta.pack;
+  const int n0 = ns[0];
+  double a0[S];
+  double dv[NL], wl[NL];
   {
-    uint8_t* mb = reinterpret_cast<uint8_t*>(sm + off);
-    for (int l = 0; l < nl; ++l) { MK[l] = mb; mb += (ta.L[l].n + 7) & ~7; }
-  }
-  // ---- load: operator row of level 0 into registers, the other operators, the masks and b0 into LDS
-  double a0[ST::S];
-  double dv[MG_TAIL_MAX], wl[MG_TAIL_MAX];
-  for (int l = 0; l < nl; ++l) wl[l] = *ta.L[l].w;
-  // entry (row, slot) of a level's operator; symmetric storage: a lower slot is the mirror slot of the row it points to
-  auto entry = [&](const TailLevel& F, int slot, int row) -> double {
-    if (!F.sym) return F.A[(int64_t)slot * F.ld + row];
-    constexpr int C0 = ST::S / 2;
-    if (slot >= C0) return F.A[(int64_t)(slot - C0) * F.ld + row];
-    // offset of the slot: decode from the stencil lines
-    int sl = 0, off = 0;
-    for (int l = 0; l < ST::NL; ++l) {
-      const int mask = ST::mask(l);
-      for (int d = 0; d < 3; ++d) {
-        if (!((mask >> d) & 1)) continue;
-        if (sl == slot) off = (d - 1) + ST::dy(l) * F.px + ST::dz(l) * F.px * F.py;
-        ++sl;
+    const bool in = tid < n0;
+#pragma unroll
+    for (int s = 0; s < S; ++s) a0[s] = in ? pk[s * n0 + tid] : 0.0;
+    dv[0] = in ? pk[S * n0 + tid] : 0.0;
+    const double* mats = pk + (S + 1) * n0;
+    // (batches of eight loads in flight: one memory round trip for the usual sizes instead of one per element)
+    for (int e0 = tid; e0 < mat_tot; e0 += 8 * (int)blockDim.x) {
+      double tmp[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int e = e0 + k * (int)blockDim.x;
+        tmp[k] = e < mat_tot ? mats[e] : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int e = e0 + k * (int)blockDim.x;
+        if (e < mat_tot) Mbase[e] = tmp[k];
       }
     }
-    const int rr = row + off;
-    return (rr >= 0 && rr < F.n) ? F.A[(int64_t)(ST::S - 1 - slot - C0) * F.ld + rr] : 0.0;
-  };
-  {
-    const TailLevel& F = ta.L[0];
-    const bool in = tid < F.n;
+    const double* dl = mats + mat_tot;
 #pragma unroll
-    for (int s = 0; s < ST::S; ++s) a0[s] = in ? entry(F, s, tid) : 0.0;
-    if (in) B[0][tid] = ta.b0[tid];
-  }
-  for (int l = 0; l < nl; ++l) {
-    const TailLevel& F = ta.L[l];
-    dv[l] = (tid < F.n) ? F.dinv[tid] : 0.0;
-    if (tid < F.n) MK[l][tid] = F.mask[tid];
-    if (l > 0)
-      for (int e = tid; e < ST::S * F.n; e += blockDim.x) M[l][e] = entry(F, e / F.n, e % F.n);
+    for (int l = 1; l < NL; ++l) { dv[l] = (tid < ns[l]) ? dl[tid] : 0.0; dl += ns[l]; }
+    const unsigned long long* mw = reinterpret_cast<const unsigned long long*>(dl);
+    unsigned long long* mkw = reinterpret_cast<unsigned long long*>(MKbase);
+    for (int e = tid; e < (mk_tot >> 3); e += blockDim.x) mkw[e] = mw[e];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) wl[l] = *ta.L[l].w;
+    if (in) {
+      const double b = ta.b0[tid];
+      B[0][tid] = b;
+      X[0][tid] = dv[0] * b * wl[0];                               // pre-smoothing from a zero guess
+    }
   }
   __syncthreads();
   // ---- downward leg
-  for (int l = 0; l + 1 < nl; ++l) {
-    const TailLevel& F = ta.L[l];
-    const TailLevel& C = ta.L[l + 1];
+#pragma unroll
+  for (int l = 0; l + 1 < NL; ++l) {
+    const TailLevel F = ta.L[l];
+    const TailLevel C = ta.L[l + 1];
     const int n = F.n, pxy = F.px * F.py;
-    const bool in = tid < n;
-    if (in) X[l][tid] = dv[l] * B[l][tid] * wl[l];               // pre-smoothing from a zero guess
-    __syncthreads();
-    if (in) {                                                     // residual
+    if (tid < n) {                                                // residual
       const double ax = (l == 0) ? tail_row<KIND>(a0, 1, X[l], tid, F.px, pxy, n)
                                  : tail_row<KIND>(M[l] + tid, n, X[l], tid, F.px, pxy, n);
       T[l][tid] = B[l][tid] - ax;
@@ -843,63 +950,112 @@ __global__ __launch_bounds__(1024) void k_mg_tail(TailArgs ta, TStencil ts, int 
       const int I = tid % C.px, t = tid / C.px, J = t % C.py, K = t / C.py;
       double s = 0.0;
       if (MK[l + 1][tid] == 0) {
-        for (int q = 0; q < ts.count; ++q) {
-          const int i = 2 * I + ts.d[q][0], j = 2 * J + ts.d[q][1], k = 2 * K + ts.d[q][2];
-          if (i >= 0 && i < F.px && j >= 0 && j < F.py && k >= 0 && k < F.pz) {
-            const int f = i + F.px * (j + F.py * k);
-            if ((MK[l][f] & 1) == 0) s += ts.w[q] * T[l][f];
-          }
-        }
+        // the taps of make_transfer_stencil(KIND), same order, as compile-time constants
+#pragma unroll
+        for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+          for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+              constexpr bool dim3 = (KIND == PPH_CELL_HEX || KIND == PPH_CELL_TET);
+              if (!dim3 && dz != 0) continue;
+              const double w = tail_tap_weight(KIND, dx, dy, dz);
+              if (w == 0.0) continue;
+              const int i = 2 * I + dx, j = 2 * J + dy, k = 2 * K + dz;
+              const bool ok = i >= 0 && i < F.px && j >= 0 && j < F.py && k >= 0 && k < F.pz;
+              const int f = ok ? i + F.px * (j + F.py * k) : 0;
+              const double tv = T[l][f];
+              const bool use = ok && (MK[l][f] & 1) == 0;
+              if (use) s += w * tv;
+            }
       }
       B[l + 1][tid] = s;
+      if (l + 2 < NL) X[l + 1][tid] = dv[l + 1] * s * wl[l + 1];   // the coarse level's pre-smoothing rides along
     }
     __syncthreads();
   }
   // ---- coarsest level: Jacobi-preconditioned CG (the algorithm of k_coarse_cg), vectors in LDS
   {
-    const int lc = nl - 1;
-    const TailLevel& C = ta.L[lc];
+    constexpr int lc = NL - 1;
+    const TailLevel C = ta.L[lc];
     const int n = C.n, pxy = C.px * C.py;
     const bool in = tid < n;
     double* x = X[lc]; double* r = T[lc]; const double* b = B[lc];
-    double ri = 0.0, zi = 0.0;
-    if (in) { ri = b[tid]; zi = dv[lc] * ri; x[tid] = 0.0; r[tid] = ri; P[tid] = zi; }
-    double zz = coarse_block_sum(zi * zi, red);
-    double rz = coarse_block_sum(ri * zi, red);
-    const double tol = cg_rtol * sqrt(zz);
-    bool go = sqrt(zz) > tol;
-    for (int it = 0; go && it < cg_max_it; ++it) {
-      __syncthreads();
-      double s = 0.0, pi = 0.0;
-      if (in) {
-        s = (lc == 0) ? tail_row<KIND>(a0, 1, P, tid, C.px, pxy, n) : tail_row<KIND>(M[lc] + tid, n, P, tid, C.px, pxy, n);
-        pi = P[tid];
-        Q[tid] = s;
+    if (n <= 64) {
+      // one wave: no workgroup barriers (LDS operations of a wave complete in order)
+      if (tid < 64) {
+        double ri = 0.0, zi = 0.0;
+        if (in) { ri = b[tid]; zi = dv[lc] * ri; x[tid] = 0.0; r[tid] = ri; P[tid] = zi; }
+        const double zz = tail_wave_sum(zi * zi);
+        double rz = tail_wave_sum(ri * zi);
+        const double tol = cg_rtol * sqrt(zz);
+        bool go = sqrt(zz) > tol;
+        double rr = ri, pi = zi;
+        for (int it = 0; go && it < cg_max_it; ++it) {
+          TAIL_WAVE_FENCE();
+          double s = 0.0;
+          if (in) s = (lc == 0) ? tail_row<KIND>(a0, 1, P, tid, C.px, pxy, n) : tail_row<KIND>(M[lc] + tid, n, P, tid, C.px, pxy, n);
+          const double pq = tail_wave_sum(pi * s);
+          if (!(pq > 0.0)) break;
+          const double alpha = rz / pq;
+          double r2 = 0.0, z2 = 0.0;
+          if (in) {
+            x[tid] += alpha * pi;
+            r2 = rr - alpha * s;
+            z2 = dv[lc] * r2;
+            rr = r2;
+          }
+          const double zz2 = tail_wave_sum(z2 * z2);
+          const double rz2 = tail_wave_sum(r2 * z2);
+          if (sqrt(zz2) <= tol) break;
+          const double beta = rz2 / rz;
+          TAIL_WAVE_FENCE();   // every lane has read P of this iteration's product
+          pi = z2 + beta * pi;
+          if (in) P[tid] = pi;
+          rz = rz2;
+        }
       }
-      const double pq = coarse_block_sum(pi * s, red);
-      if (!(pq > 0.0)) break;
-      const double alpha = rz / pq;
-      double r2 = 0.0, z2 = 0.0;
-      if (in) {
-        x[tid] += alpha * pi;
-        r2 = r[tid] - alpha * s;
-        z2 = dv[lc] * r2;
-        r[tid] = r2;
+    } else {
+      double ri = 0.0, zi = 0.0;
+      if (in) { ri = b[tid]; zi = dv[lc] * ri; x[tid] = 0.0; r[tid] = ri; P[tid] = zi; }
+      double zz = coarse_block_sum(zi * zi, red);
+      double rz = coarse_block_sum(ri * zi, red);
+      const double tol = cg_rtol * sqrt(zz);
+      bool go = sqrt(zz) > tol;
+      for (int it = 0; go && it < cg_max_it; ++it) {
+        __syncthreads();
+        double s = 0.0, pi = 0.0;
+        if (in) {
+          s = (lc == 0) ? tail_row<KIND>(a0, 1, P, tid, C.px, pxy, n) : tail_row<KIND>(M[lc] + tid, n, P, tid, C.px, pxy, n);
+          pi = P[tid];
+          Q[tid] = s;
+        }
+        const double pq = coarse_block_sum(pi * s, red);
+        if (!(pq > 0.0)) break;
+        const double alpha = rz / pq;
+        double r2 = 0.0, z2 = 0.0;
+        if (in) {
+          x[tid] += alpha * pi;
+          r2 = r[tid] - alpha * s;
+          z2 = dv[lc] * r2;
+          r[tid] = r2;
+        }
+        const double zz2 = coarse_block_sum(z2 * z2, red);
+        const double rz2 = coarse_block_sum(r2 * z2, red);
+        if (sqrt(zz2) <= tol) break;
+        const double beta = rz2 / rz;
+        __syncthreads();   // every thread has read P of this iteration's product
+        if (in) P[tid] = z2 + beta * pi;
+        rz = rz2;
       }
-      const double zz2 = coarse_block_sum(z2 * z2, red);
-      const double rz2 = coarse_block_sum(r2 * z2, red);
-      if (sqrt(zz2) <= tol) break;
-      const double beta = rz2 / rz;
-      __syncthreads();   // every thread has read P of this iteration's product
-      if (in) P[tid] = z2 + beta * pi;
-      rz = rz2;
     }
   }
   __syncthreads();
   // ---- upward leg
-  for (int l = nl - 2; l >= 0; --l) {
-    const TailLevel& F = ta.L[l];
-    const TailLevel& C = ta.L[l + 1];
+#pragma unroll
+  for (int l = NL - 2; l >= 0; --l) {
+    const TailLevel F = ta.L[l];
+    const TailLevel C = ta.L[l + 1];
     const int n = F.n, pxy = F.px * F.py;
     const bool in = tid < n;
     if (in) {                                                     // t = x + P x_c (k_prolong_to)
@@ -932,11 +1088,13 @@ __global__ __launch_bounds__(1024) void k_mg_tail(TailArgs ta, TStencil ts, int 
     if (in) {                                                     // post-smoothing (la_spmv_jacobi)
       const double at = (l == 0) ? tail_row<KIND>(a0, 1, T[l], tid, F.px, pxy, n)
                                  : tail_row<KIND>(M[l] + tid, n, T[l], tid, F.px, pxy, n);
-      X[l][tid] = T[l][tid] + dv[l] * (B[l][tid] - at) * wl[l];
+      const double xn = T[l][tid] + dv[l] * (B[l][tid] - at) * wl[l];
+      if (l == 0) ta.x0[tid] = xn;
+      else X[l][tid] = xn;
     }
-    __syncthreads();
+    if (l > 0) __syncthreads();
   }
-  if (tid < ta.L[0].n) ta.x0[tid] = X[0][tid];
+  if (NL == 1 && tid < ns[0]) ta.x0[tid] = X[0][tid];
 }
 
 // LDS bytes of the tail kernel for the given level sizes; 0 when the levels do not fit its limits
@@ -970,6 +1128,43 @@ static int mg_tail_begin(const pph_ctx* ctx, int which) {
     lt = l;
   }
   return lt;
+}
+
+// packs the tail levels of block `which` for k_mg_tail (after every assembly of the level operators)
+static int mg_tail_pack(pph_ctx* ctx, int which) {
+  std::vector<MgLevel>& mg = ctx->mg;
+  const int nlev = (int)mg.size();
+  ctx->mg_tail_lt[which] = -1;
+  if (!ctx->mg_fused || nlev < 2) return PPH_OK;
+  for (const MgLevel& L : mg)
+    if (!L.ell[which].val) return PPH_OK;
+  const int lt = mg_tail_begin(ctx, which);
+  if (lt >= nlev) return PPH_OK;
+  const int kind = ctx->mesh.kind;
+  const int S = sell_slots(kind);
+  TailPackArgs pa;
+  int ns[MG_TAIL_MAX];
+  pa.nl = nlev - lt;
+  for (int q = 0; q < pa.nl; ++q) {
+    MgLevel& L = mg[lt + q];
+    TailSrc& T = pa.L[q];
+    T.A = L.ell[which].val; T.sym = L.ell[which].sym; T.ld = L.ell[which].ld; T.dinv = L.dinv[which].p; T.mask = L.maskp[which];
+    T.px = L.px; T.py = L.py; T.pz = L.pz; T.n = (int)L.n;
+    ns[q] = (int)L.n;
+  }
+  const size_t want = (size_t)tail_pack_doubles(ns, pa.nl, S) + (size_t)tail_pack_maskbytes(ns, pa.nl) / 8;
+  if (ctx->mg_tail_pack[which].n != want) PPH_TRY(ctx->mg_tail_pack[which].alloc(ctx, want));
+  double* pack = ctx->mg_tail_pack[which].p;
+#define PPH_PACK_GO(KK) hipLaunchKernelGGL(k_tail_pack<KK>, dim3(16), dim3(256), 0, ctx->stream, pa, pack)
+  switch (kind) {
+    case PPH_CELL_QUAD: PPH_PACK_GO(PPH_CELL_QUAD); break;
+    case PPH_CELL_TRI: PPH_PACK_GO(PPH_CELL_TRI); break;
+    case PPH_CELL_HEX: PPH_PACK_GO(PPH_CELL_HEX); break;
+    default: PPH_PACK_GO(PPH_CELL_TET); break;
+  }
+#undef PPH_PACK_GO
+  ctx->mg_tail_lt[which] = lt;
+  return PPH_OK;
 }
 
 static bool mg_can_fuse(const pph_ctx* ctx, int which, int nsmooth) {
@@ -1029,31 +1224,44 @@ static void mg_vcycle_fused(pph_ctx* ctx, int which, const double* rin, double* 
     }
   }
   if (lt < nlev) {
+    if (ctx->mg_tail_lt[which] != lt) (void)mg_tail_pack(ctx, which);   // (an option moved the tail after the set-up)
     TailArgs ta;
     int ns[MG_TAIL_MAX];
-    ta.nl = nlev - lt;
-    for (int q = 0; q < ta.nl; ++q) {
-      MgLevel& L = mg[lt + q];
+    const int nl = nlev - lt;
+    for (int q = 0; q < MG_TAIL_MAX; ++q) {
       TailLevel& T = ta.L[q];
-      T.A = L.ell[which].val; T.sym = L.ell[which].sym; T.ld = L.ell[which].ld; T.dinv = L.dinv[which].p; T.mask = L.maskp[which];
-      T.px = L.px; T.py = L.py; T.pz = L.pz; T.n = (int)L.n;
-      T.w = cheb_wp(ctx, lt + q, which);
-      ns[q] = (int)L.n;
+      if (q < nl) {
+        MgLevel& L = mg[lt + q];
+        T.px = L.px; T.py = L.py; T.pz = L.pz; T.n = (int)L.n;
+        T.w = cheb_wp(ctx, lt + q, which);
+        ns[q] = (int)L.n;
+      } else {
+        T.px = T.py = T.pz = 1; T.n = 0; T.w = nullptr; ns[q] = 0;
+      }
     }
+    ta.pack = ctx->mg_tail_pack[which].p;
     ta.b0 = mg[lt].b.p;
     ta.x0 = mg[lt].x.p;
     const int tk = (kind == PPH_CELL_QUAD || kind == PPH_CELL_HEX) ? 0 : (kind == PPH_CELL_TET ? 1 : 2);
     int threads = (int)((mg[lt].n + 63) / 64) * 64;
     if (threads < 64) threads = 64;
-    const size_t lds = mg_tail_lds(ns, ta.nl, sell_slots(kind));
-#define PPH_TAIL_GO(KK) \
-  hipLaunchKernelGGL(k_mg_tail<KK>, dim3(1), dim3(threads), lds, ctx->stream, ta, st, tk, 1e-12, ctx->coarse_max_it)
+    const size_t lds = mg_tail_lds(ns, nl, sell_slots(kind));
+#define PPH_TAIL_GO(KK, NN) \
+  hipLaunchKernelGGL((k_mg_tail<KK, NN>), dim3(1), dim3(threads), lds, ctx->stream, ta, st, tk, 1e-12, ctx->coarse_max_it)
+#define PPH_TAIL_NL(KK)                                                                       \
+  switch (nl) {                                                                               \
+    case 1: PPH_TAIL_GO(KK, 1); break;                                                        \
+    case 2: PPH_TAIL_GO(KK, 2); break;                                                        \
+    case 3: PPH_TAIL_GO(KK, 3); break;                                                        \
+    default: PPH_TAIL_GO(KK, 4); break;                                                       \
+  }
     switch (kind) {
-      case PPH_CELL_QUAD: PPH_TAIL_GO(PPH_CELL_QUAD); break;
-      case PPH_CELL_TRI: PPH_TAIL_GO(PPH_CELL_TRI); break;
-      case PPH_CELL_HEX: PPH_TAIL_GO(PPH_CELL_HEX); break;
-      default: PPH_TAIL_GO(PPH_CELL_TET); break;
+      case PPH_CELL_QUAD: PPH_TAIL_NL(PPH_CELL_QUAD); break;
+      case PPH_CELL_TRI: PPH_TAIL_NL(PPH_CELL_TRI); break;
+      case PPH_CELL_HEX: PPH_TAIL_NL(PPH_CELL_HEX); break;
+      default: PPH_TAIL_NL(PPH_CELL_TET); break;
     }
+#undef PPH_TAIL_NL
 #undef PPH_TAIL_GO
   } else {
     // no tail (coarsest level too large or distributed): the host-driven / single-level solve of the general cycle

@@ -21,27 +21,31 @@ __device__ inline double sell_wave_sum(double v) {
 // MODE 0: y = A x      1: y = b - A x      2: y = A x and per-workgroup partial sums of x.y
 // MODE 3: y = x + w * dinv .* (b - A x)   (one damped-Jacobi / one-step Chebyshev sweep, out of place)
 // MODE 4: MODE 3 and the dot product b . y over the rows [dlo, dhi) (CG: r . z from the last kernel of the V-cycle)
-// MODE 2 / 4 write one partial sum per workgroup to part[blockIdx.x]; the caller finishes the sum.
+// MODE 5: t = b - A x ;  aux += t - y ;  y = t      MODE 6: t = A x ;  aux -= t - y ;  y = t      (the residual
+//         bookkeeping of the Picard sweeps, k_shift, in the epilogue of the coupling product) and the sum of
+//         aux^2 over the rows [dlo, dhi)
+// MODE 2 / 4 / 5 / 6 write one partial sum per workgroup to part[blockIdx.x]; the caller finishes the sum.
 // One thread owns RPT consecutive rows; a workgroup a chunk of 256 RPT rows.  Chunks are dealt to the XCDs in groups
 // of `group` consecutive chunks (group 1 = plain grid-stride order); workgroups with equal blockIdx % 8 share an XCD.
 template <int KIND, int MODE, int RPT, bool CLAMP, bool SYM = false>
 __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_t ld, const double* __restrict__ x,
                                           const double* __restrict__ b, const double* __restrict__ dinv, double w,
-                                          double* __restrict__ y, int64_t n, int px, int64_t pxy, int64_t r0,
-                                          double& dotacc, int64_t dlo, int64_t dhi) {
+                                          double* __restrict__ y, double* __restrict__ aux, int64_t n, int px,
+                                          int64_t pxy, int64_t r0, double& dotacc, int64_t dlo, int64_t dhi) {
   using ST = SellSt<KIND>;
   double acc[RPT];
-  double bv[RPT], xr[RPT], dv[RPT];
+  double bv[RPT], xr[RPT], dv[RPT], tv[RPT], av[RPT];
   bool act[RPT];
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
-    acc[i] = 0.0; bv[i] = 0.0; xr[i] = 0.0; dv[i] = 0.0;
+    acc[i] = 0.0; bv[i] = 0.0; xr[i] = 0.0; dv[i] = 0.0; tv[i] = 0.0; av[i] = 0.0;
     act[i] = !CLAMP || (r0 + i < n);
     // operands of the epilogue are requested before the matrix stream, not after the sums
     if (act[i]) {
-      if (MODE == 1 || MODE >= 3) bv[i] = b[r0 + i];
-      if (MODE >= 2) xr[i] = x[r0 + i];
-      if (MODE >= 3) dv[i] = dinv[r0 + i];
+      if (MODE == 1 || (MODE >= 3 && MODE <= 5)) bv[i] = b[r0 + i];
+      if (MODE >= 2 && MODE <= 4) xr[i] = x[r0 + i];
+      if (MODE == 3 || MODE == 4) dv[i] = dinv[r0 + i];
+      if (MODE >= 5) { tv[i] = y[r0 + i]; av[i] = aux[r0 + i]; }
     }
   }
   int slot = 0;
@@ -51,6 +55,12 @@ __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_
     if (mask == 0) continue;
     const int64_t L = r0 + (int64_t)ST::dy(l) * px + (int64_t)ST::dz(l) * pxy;
     double xs[RPT + 2];
+#ifdef PPH_SELL_PROBE
+    if (!CLAMP && RPT == 2) {   // timing probe (wrong results): one aligned 16-byte load per x line
+      const double2 t = *reinterpret_cast<const double2*>(x + (L & ~(int64_t)1));
+      xs[0] = t.x; xs[1] = t.x; xs[2] = t.y; xs[3] = t.y;
+    } else
+#endif
 #pragma unroll
     for (int e = 0; e < RPT + 2; ++e) {
       bool need = false;
@@ -77,6 +87,12 @@ __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_
       if (SYM && slot < C0) {
         const int64_t off = (int64_t)(d - 1) + (int64_t)ST::dy(l) * px + (int64_t)ST::dz(l) * pxy;
         const double* mp = val + (int64_t)(ST::S - 1 - slot - C0) * ld;
+#if defined(PPH_SELL_PROBE) && PPH_SELL_PROBE >= 2
+        if (!CLAMP && RPT == 2) {   // timing probe (wrong results): mirror values as one aligned 16-byte load
+          const double2 t = *reinterpret_cast<const double2*>(mp + ((r0 + off) & ~(int64_t)1));
+          v[0] = t.x; v[1] = t.y;
+        } else
+#endif
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
           const int64_t rr = r0 + i + off;
@@ -106,7 +122,13 @@ __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_
     if (MODE == 0) y[r] = acc[i];
     else if (MODE == 1) y[r] = bv[i] - acc[i];
     else if (MODE == 2) { y[r] = acc[i]; dotacc += acc[i] * xr[i]; }
-    else {
+    else if (MODE >= 5) {
+      const double tn = (MODE == 5) ? bv[i] - acc[i] : acc[i];
+      const double rn = av[i] + ((MODE == 5) ? 1.0 : -1.0) * (tn - tv[i]);   // k_shift
+      aux[r] = rn;
+      y[r] = tn;
+      if (r >= dlo && r < dhi) dotacc += rn * rn;
+    } else {
       const double yn = xr[i] + dv[i] * (bv[i] - acc[i]) * w;   // the order of k_cheb_init: dinv * r / theta
       y[r] = yn;
       if (MODE == 4 && r >= dlo && r < dhi) dotacc += bv[i] * yn;
@@ -118,14 +140,15 @@ template <int KIND, int MODE, int RPT, bool SYM = false>
 __global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ val, int64_t ld,
                                                    const double* __restrict__ x, const double* __restrict__ b,
                                                    const double* __restrict__ dinv, const double* __restrict__ wp,
-                                                   double* __restrict__ y, int64_t n, int px, int64_t pxy, int64_t halo,
+                                                   double* __restrict__ y, double* __restrict__ aux, int64_t n, int px,
+                                                   int64_t pxy, int64_t halo,
                                                    int64_t nchunks,
-                                                   int group, int zwalk, double* __restrict__ part, int64_t dlo,
-                                                   int64_t dhi) {
+                                                   int group, int zwalk, int xmap, double* __restrict__ part,
+                                                   int64_t dlo, int64_t dhi) {
   constexpr int CH = 256 * RPT;
   const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, bpx = gridDim.x >> 3;   // launcher keeps gridDim.x a multiple of 8
   // the smoother weight lives in device memory (refreshed per assembly) so that captured graphs survive a re-assembly
-  const double w = (MODE >= 3) ? *wp : 0.0;
+  const double w = (MODE == 3 || MODE == 4) ? *wp : 0.0;
   double dotacc = 0.0;
   // Chunk order.  zwalk = Z > 0 (3D): a workgroup takes Z work items in a row that sit at the same in-plane position
   // of Z consecutive node planes (chunk, chunk + P, ..., P = chunks per plane rounded: the rows shift by pxy - P CH,
@@ -133,10 +156,26 @@ __global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ va
   // -pxy are the ones this workgroup loaded for the plane below a moment ago: they come from L1 / this XCD's L2
   // instead of the fabric.  zwalk = 0: chunks dealt to the XCDs in groups of `group` (1 = plane grid-stride order).
   const int64_t P = zwalk > 0 ? (pxy + CH / 2) / CH : 0;
-  const int64_t nitems = (zwalk > 0 && P > 0) ? ((nchunks + P * zwalk - 1) / (P * zwalk)) * P * zwalk : 0;
-  for (int64_t q = (nitems ? (int64_t)blockIdx.x * zwalk : bx);; q += (nitems ? 1 : bpx)) {
+  const bool column = zwalk >= PPH_SELL_COLUMN_WALK && P > 0;
+  const int64_t nitems = (zwalk > 0 && P > 0 && !column) ? ((nchunks + P * zwalk - 1) / (P * zwalk)) * P * zwalk : 0;
+  // column walk: the P x planes work items in (position-major, plane-minor) order are cut into gridDim.x equal
+  // contiguous ranges - a workgroup climbs (a part of) one z column plane by plane, every workgroup the same number
+  // of planes, and a cold start (mirror values of the plane below not in L2) happens once per range
+  const int64_t planes = column ? (nchunks + P - 1) / P : 0;
+  const int64_t ctot = planes * P;
+  // xmap: the workgroups of one XCD (equal blockIdx % 8) take CONSECUTIVE in-plane positions, so that the rows a
+  // chunk reads from its in-plane neighbours (mirror values and x of the lines next to the chunk) were loaded into
+  // the same L2 by the neighbour workgroup in the same plane step
+  const int64_t vb = xmap ? (int64_t)xcd * bpx + bx : (int64_t)blockIdx.x;
+  const int64_t cq1 = column ? (ctot * (vb + 1)) / gridDim.x : 0;
+  for (int64_t q = column ? (ctot * vb) / gridDim.x : (nitems ? vb * zwalk : bx);;
+       q += ((nitems || column) ? 1 : bpx)) {
     int64_t chunk;
-    if (nitems) {
+    if (column) {
+      if (q >= cq1) break;
+      chunk = (q % planes) * P + q / planes;
+      if (chunk >= nchunks) continue;
+    } else if (nitems) {
       // items [b Z, b Z + Z) then [(b + gridDim) Z, ...): q walks one item at a time inside a run of Z
       const int64_t run = q / zwalk, t = q % zwalk;
       if (run * zwalk >= nitems) break;
@@ -155,11 +194,11 @@ __global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ va
     // a chunk whose rows and x window lie inside [0, n) needs no index clamps and no row masks (all but the first
     // and last few chunks)
     if (c0 >= halo && c0 + CH + halo <= n)
-      sell_rows<KIND, MODE, RPT, false, SYM>(val, ld, x, b, dinv, w, y, n, px, pxy, r0, dotacc, dlo, dhi);
+      sell_rows<KIND, MODE, RPT, false, SYM>(val, ld, x, b, dinv, w, y, aux, n, px, pxy, r0, dotacc, dlo, dhi);
     else
-      sell_rows<KIND, MODE, RPT, true, SYM>(val, ld, x, b, dinv, w, y, n, px, pxy, r0, dotacc, dlo, dhi);
+      sell_rows<KIND, MODE, RPT, true, SYM>(val, ld, x, b, dinv, w, y, aux, n, px, pxy, r0, dotacc, dlo, dhi);
   }
-  if (MODE == 2 || MODE == 4) {
+  if (MODE == 2 || MODE >= 4) {
     __shared__ double lds[4];
     dotacc = sell_wave_sum(dotacc);
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = dotacc;
@@ -170,24 +209,26 @@ __global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ va
 
 template <int KIND, int RPT>
 static void sell_launch_mode(pph_ctx* ctx, int mode, int grid, const Sell& E, const double* x, const double* b,
-                             const double* dinv, const double* w, double* y, int64_t n, int64_t nchunks, int group,
-                             double* part, int64_t dlo, int64_t dhi) {
+                             const double* dinv, const double* w, double* y, double* aux, int64_t n, int64_t nchunks,
+                             int group, double* part, int64_t dlo, int64_t dhi) {
   const int64_t pxy = (int64_t)E.px * E.py;
   const int64_t halo = (E.pz > 1 ? pxy : 0) + E.px + 2;   // reach of the x window of a row (2D: no z lines)
   const int zwalk = (E.sym && E.pz > 2 && ctx->sell_zwalk > 0 && nchunks >= ctx->sell_zwalk_min_chunks) ? ctx->sell_zwalk : 0;   // (no gain on full storage)
 #define PPH_SELL_GO(MM)                                                                                              \
   hipLaunchKernelGGL((k_spmv_sell<KIND, MM, RPT>), dim3(grid), dim3(256), 0, ctx->stream, E.val, E.ld, x, b, dinv, w, \
-                     y, n, E.px, pxy, halo, nchunks, group, zwalk, part, dlo, dhi)
+                     y, aux, n, E.px, pxy, halo, nchunks, group, zwalk, ctx->sell_xmap, part, dlo, dhi)
   if (E.sym) {
 #define PPH_SELL_GOS(MM)                                                                                                   \
   hipLaunchKernelGGL((k_spmv_sell<KIND, MM, RPT, true>), dim3(grid), dim3(256), 0, ctx->stream, E.val, E.ld, x, b, dinv, w, \
-                     y, n, E.px, pxy, halo, nchunks, group, zwalk, part, dlo, dhi)
+                     y, aux, n, E.px, pxy, halo, nchunks, group, zwalk, ctx->sell_xmap, part, dlo, dhi)
     switch (mode) {
       case 0: PPH_SELL_GOS(0); break;
       case 1: PPH_SELL_GOS(1); break;
       case 2: PPH_SELL_GOS(2); break;
       case 3: PPH_SELL_GOS(3); break;
-      default: PPH_SELL_GOS(4); break;
+      case 4: PPH_SELL_GOS(4); break;
+      case 5: PPH_SELL_GOS(5); break;
+      default: PPH_SELL_GOS(6); break;
     }
 #undef PPH_SELL_GOS
     return;
@@ -197,14 +238,16 @@ static void sell_launch_mode(pph_ctx* ctx, int mode, int grid, const Sell& E, co
     case 1: PPH_SELL_GO(1); break;
     case 2: PPH_SELL_GO(2); break;
     case 3: PPH_SELL_GO(3); break;
-    default: PPH_SELL_GO(4); break;
+    case 4: PPH_SELL_GO(4); break;
+    case 5: PPH_SELL_GO(5); break;
+    default: PPH_SELL_GO(6); break;
   }
 #undef PPH_SELL_GO
 }
 
 // launches the product; returns the grid (= number of partial sums written in mode 2)
 int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x, const double* b, const double* dinv,
-              const double* w, double* y, double* part, int64_t dlo, int64_t dhi) {
+              const double* w, double* y, double* part, int64_t dlo, int64_t dhi, double* aux) {
   const int rpt = (ctx->sell_rpt == 1) ? 1 : 2;
   const int64_t nchunks = ceil_div64(n, 256 * rpt);
   // grid: persistent, 2048 workgroups; with the z-walk order of symmetric operators ONE workgroup per CU: the value a
@@ -214,14 +257,14 @@ int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x,
   const bool zw = E.sym && E.pz > 2 && ctx->sell_zwalk > 0 && nchunks >= ctx->sell_zwalk_min_chunks;   // (smaller levels: too few chunks per workgroup)
   int cap = (ctx->sell_blocks >= 8 && ctx->sell_blocks <= 8192) ? (ctx->sell_blocks / 8) * 8
                                                                  : (zw ? ((ctx->num_cus + 7) / 8) * 8 : 2048);
-  if ((mode == 2 || mode == 4) && cap > 4096) cap = 4096;   // one partial sum per workgroup (PART_STRIDE of pph_la.hip)
+  if ((mode == 2 || mode >= 4) && cap > 4096) cap = 4096;   // one partial sum per workgroup (PART_STRIDE of pph_la.hip)
   int64_t g = nchunks < cap ? nchunks : cap;
   g = ((g + 7) / 8) * 8;
   const int grid = (int)g;
   int group = ctx->sell_group > 0 ? ctx->sell_group : 1;
 #define PPH_SELL_KIND(KK)                                                                                     \
-  if (rpt == 1) sell_launch_mode<KK, 1>(ctx, mode, grid, E, x, b, dinv, w, y, n, nchunks, group, part, dlo, dhi); \
-  else sell_launch_mode<KK, 2>(ctx, mode, grid, E, x, b, dinv, w, y, n, nchunks, group, part, dlo, dhi)
+  if (rpt == 1) sell_launch_mode<KK, 1>(ctx, mode, grid, E, x, b, dinv, w, y, aux, n, nchunks, group, part, dlo, dhi); \
+  else sell_launch_mode<KK, 2>(ctx, mode, grid, E, x, b, dinv, w, y, aux, n, nchunks, group, part, dlo, dhi)
   switch (E.kind) {
     case PPH_CELL_QUAD: PPH_SELL_KIND(PPH_CELL_QUAD); break;
     case PPH_CELL_TRI: PPH_SELL_KIND(PPH_CELL_TRI); break;
