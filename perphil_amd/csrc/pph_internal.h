@@ -450,7 +450,7 @@ void la_reset_spmv_stats(pph_ctx* ctx);
 
 // stencil-ELL operator format (pph_sell.hip)
 int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x, const double* b, const double* dinv,
-              const double* w /* device */, double* y, double* part, int64_t dlo = 0, int64_t dhi = 0);
+              const double* w /* device */, double* y, double* part, int64_t dlo = 0, int64_t dhi = 0, double* aux = nullptr);
 int sell_alloc(pph_ctx* ctx, const MeshData& mesh, DevBuf<double>& buf, Sell* out, int sym);
 int sell_from_csr(pph_ctx* ctx, const MeshData& mesh, const double* csr_val, DevBuf<double>& buf, Sell* out, int sym);
 // symmetric storage is used for operators that are symmetric on the local box: single context (a slab's ghost rows

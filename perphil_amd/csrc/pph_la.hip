@@ -327,7 +327,22 @@ void la_spmv_shift(pph_ctx* ctx, const Csr& A, const double* x, const double* b,
   }
   if (A.geom) (void)la_halo(ctx, *A.geom, const_cast<double*>(x));
   double* part = partials(ctx);
+  pph_ctx::EvPair* ev = nullptr;
+  if (ctx->time_spmv) {   // (as spmv_dispatch: the instrumented step of bench.py times every product)
+    if (ctx->ev_used == ctx->ev_pool.size()) {
+      pph_ctx::EvPair p;
+      p.variant = 0;
+      if (hipEventCreate(&p.e0) == hipSuccess && hipEventCreate(&p.e1) == hipSuccess) ctx->ev_pool.push_back(p);
+    }
+    if (ctx->ev_used < ctx->ev_pool.size()) {
+      ev = &ctx->ev_pool[ctx->ev_used++];
+      ev->variant = 0;
+      ev->fine = A.nrows >= ctx->mesh.n;
+      (void)hipEventRecord(ev->e0, ctx->stream);
+    }
+  }
   const int grid = sell_spmv(ctx, A.ell, A.nrows, b ? 5 : 6, x, b, nullptr, nullptr, told, part, dlo, dhi, R);
+  if (ev) (void)hipEventRecord(ev->e1, ctx->stream);
   const double bytes = (8.0 * sell_stored(A.ell.kind, A.ell.sym) + 16.0 + (b ? 8.0 : 0.0) + 24.0) * (double)A.nrows;
   ctx->n_spmv[0]++;
   ctx->spmv_bytes[0] += bytes;

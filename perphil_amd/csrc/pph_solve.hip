@@ -88,7 +88,7 @@ struct MgPre {
 static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double* x, const double* dinv, const ApplyFn& pc,
                             double rtol, double atol, int max_it, bool warm, double* r, double* z, double* p, double* q,
                             int slot, KspOut* out, double* hist, int hist_cap, double bnorm_hint, double reduction,
-                            const double* r_init, const MgPre& pre) {
+                            const double* r_init, const MgPre& pre, double rnorm_hint = -1.0) {
   const int64_t n = A.nrows;
   const Seg sg = pph_owned_seg(A.geom, n);
   auto apply_pc = [&](const double* in, double* o) {
@@ -111,9 +111,14 @@ static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double*
     la_set(ctx, x, 0.0, n);
     la_copy(ctx, r, b, n);
   }
-  la_mdot_seg(ctx, r, 0, 1, r, sg, slot);
-  PPH_TRY(la_fetch(ctx, slot, 1));
-  double res = std::sqrt(ctx->h_scal[slot]);
+  double res;
+  if (rnorm_hint >= 0.0 && warm && r_init) {
+    res = rnorm_hint;   // the caller knows ||r_init|| (Picard bookkeeping): no reduction, no host round trip
+  } else {
+    la_mdot_seg(ctx, r, 0, 1, r, sg, slot);
+    PPH_TRY(la_fetch(ctx, slot, 1));
+    res = std::sqrt(ctx->h_scal[slot]);
+  }
   if (bnorm < 0.0) bnorm = res;
   const double tol = std::fmax(std::fmax(rtol * bnorm, atol), reduction > 0.0 ? reduction * res : 0.0);
   out->its = 0; out->res = res; out->converged = false; out->breakdown = false; out->bnorm = bnorm;
@@ -277,7 +282,7 @@ static int cg_solve(pph_ctx* ctx, const Csr& A, const double* b, double* x, cons
                     double rtol, double atol, int max_it, bool warm, double* r, double* z, double* p, double* q,
                     int slot, KspOut* out, double* hist, int hist_cap, double bnorm_hint = -1.0,
                     double reduction = 0.0, const double* r_init = nullptr, int norm_type = 0,
-                    const MgPre& pre = MgPre()) {
+                    const MgPre& pre = MgPre(), double rnorm_hint = -1.0) {
   const int64_t n = A.nrows;
   if (norm_type == 2 && la_device_scalars(ctx))
     return cg_solve_fixed(ctx, A, b, x, dinv, pc, max_it, warm, r, z, p, q, slot, out, r_init, pre);
@@ -290,7 +295,7 @@ static int cg_solve(pph_ctx* ctx, const Csr& A, const double* b, double* x, cons
   }
   if (norm_type == 1)
     return cg_solve_natural(ctx, A, b, x, dinv, pc, rtol, atol, max_it, warm, r, z, p, q, slot, out, hist, hist_cap,
-                            bnorm_hint, reduction, r_init, pre);
+                            bnorm_hint, reduction, r_init, pre, rnorm_hint);
   // reductions run over the owned entries of a slab (whole vector on a single GPU)
   const Seg sg = pph_owned_seg(A.geom, n);
   const bool fused = (dinv != nullptr) || !pc;
@@ -552,7 +557,12 @@ struct BlockSolver {
 
   // r_io (optional): vector the CG uses as its residual - on entry b - A z when warm and r_known, on return the
   // recurrence residual of the solve (the Picard loop keeps its block residuals there: no copies in or out)
-  int solve(int which, const double* rhs, double* z, bool warm, const double* r_init = nullptr, double* r_io = nullptr) {
+  // rnorm_hint >= 0: ||r_init|| over the owned rows, known to the caller.  last_res: residual norm the block's CG ended
+  // with (unpreconditioned-norm CG only; -1 otherwise)
+  double last_res = -1.0;
+  int solve(int which, const double* rhs, double* z, bool warm, const double* r_init = nullptr, double* r_io = nullptr,
+            double rnorm_hint = -1.0) {
+    last_res = -1.0;
     const int64_t n = ctx->n;
     double *r, *zz, *p, *q;
     PPH_TRY(work(ctx, W_IR, (size_t)n, &r));
@@ -601,8 +611,9 @@ struct BlockSolver {
     pre.tag = 16 * ns + which;
     PPH_TRY(cg_solve(ctx, A[which], rhs, z, dinv[which], pc, cfg->inner_rtol, cfg->inner_atol, cfg->inner_max_it,
                      warm, r, zz, p, q, S_INNER, &ko, nullptr, 0, warm ? bnorm_cache[which] : -1.0,
-                     cfg->inner_reduction, warm ? r_init : nullptr, cfg->inner_norm, pre));
+                     cfg->inner_reduction, warm ? r_init : nullptr, cfg->inner_norm, pre, rnorm_hint));
     if (!warm) bnorm_cache[which] = ko.bnorm;
+    if (cfg->inner_norm == 1) last_res = ko.res;
     last_resid = r;
     total_its += ko.its;
     if (ko.breakdown || !ko.converged) failed = true;
@@ -718,18 +729,16 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
     // decision per sweep is the outer convergence test.
     const bool launch_only = recur && cfg->inner_norm == 2 && cfg->inner_pc_type != PPH_PC_ILU && la_device_scalars(ctx) &&
                              ctx->world == 1 && ctx->fetch_spin && !ctx->time_spmv;
+    double rn0 = -1.0;   // ||R0|| at the start of a warm sweep
     while (res > tol && its < cfg->picard_max_it) {
       const bool warm = its > 0;
       if (warm && launch_only) {
         auto sweep = [&]() -> int {
-          la_sub(ctx, pb, b1, t12, n);
+          // (the block solves start from the residuals R0 / R1: their right-hand sides are not read)
           PPH_TRY(bs.solve(0, pb, du1, true, R0, R0));
-          la_spmv_resid(ctx, A21, du1, b2, tn);
-          la_shift(ctx, R1, rhs1, tn, 1.0, n);
+          la_spmv_shift(ctx, A21, du1, b2, R1, rhs1, tn, S_B, pob, pob + pon);   // rhs1 = b2 - A21 du1 ; R1 follows
           PPH_TRY(bs.solve(1, rhs1, du2, true, R1, R1));
-          la_spmv(ctx, A12, du2, tn);
-          la_shift(ctx, R0, t12, tn, -1.0, n);
-          la_dot(ctx, R0 + pob, R0 + pob, pon, S_A);
+          la_spmv_shift(ctx, A12, du2, nullptr, R0, t12, tn, S_A, pob, pob + pon);    // t12 = A12 du2 ; R0 follows ; ||R0||^2
           la_dot(ctx, R1 + pob, R1 + pob, pon, S_A + 1);
           la_publish(ctx, S_A, 2);
           return PPH_OK;
@@ -757,24 +766,39 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
         }
         continue;
       }
-      la_sub(ctx, pb, b1, t12, n);                                   // rhs of the macro block
-      PPH_TRY(bs.solve(0, pb, du1, warm, (warm && recur) ? R0 : nullptr, recur ? R0 : nullptr));
+      // a warm CG block solve starts from its carried residual (R0 / R1) and a cached ||b||: its right-hand side is
+      // not read; with the unpreconditioned-norm test the host also knows the residual norms already (hints)
+      const bool hints = warm && recur && cfg->inner_norm == 1;
+      if (!(warm && recur)) la_sub(ctx, pb, b1, t12, n);             // rhs of the macro block
+      PPH_TRY(bs.solve(0, pb, du1, warm, (warm && recur) ? R0 : nullptr, recur ? R0 : nullptr, hints ? rn0 : -1.0));
+      double rn1 = -1.0;
       if (warm && recur) {
-        la_spmv_resid(ctx, A21, du1, b2, tn);                        // new rhs of the micro block
-        la_shift(ctx, R1, rhs1, tn, 1.0, n);                         // R1 += rhs1_new - rhs1_old ; rhs1 = rhs1_new
+        // new rhs of the micro block, R1 += rhs1_new - rhs1_old, ||R1||^2 - one pass
+        la_spmv_shift(ctx, A21, du1, b2, R1, rhs1, tn, S_B, pob, pob + pon);
+        if (hints) {
+          PPH_TRY(la_fetch(ctx, S_B, 1));
+          rn1 = std::sqrt(ctx->h_scal[S_B]);
+        }
       } else {
         la_spmv_resid(ctx, A21, du1, b2, rhs1);
       }
-      PPH_TRY(bs.solve(1, rhs1, du2, warm, (warm && recur) ? R1 : nullptr, recur ? R1 : nullptr));
+      PPH_TRY(bs.solve(1, rhs1, du2, warm, (warm && recur) ? R1 : nullptr, recur ? R1 : nullptr, rn1));
       ++its;
-      la_spmv(ctx, A12, du2, tn);                                    // new coupling term
       if (recur) {
-        la_shift(ctx, R0, t12, tn, -1.0, n);                         // R0 += A12 du2_old - A12 du2_new ; t12 = new
-        la_dot(ctx, R0 + pob, R0 + pob, pon, S_A);
-        la_dot(ctx, R1 + pob, R1 + pob, pon, S_A + 1);
-        PPH_TRY(la_fetch(ctx, S_A, 2));
+        // new coupling term, R0 += A12 du2_old - A12 du2_new, ||R0||^2 - one pass (the first sweep: t12 = 0)
+        la_spmv_shift(ctx, A12, du2, nullptr, R0, t12, tn, S_A, pob, pob + pon);
+        const double r1known = (cfg->inner_norm == 1) ? bs.last_res : -1.0;   // the CG's own final ||R1||
+        if (r1known >= 0.0) {
+          PPH_TRY(la_fetch(ctx, S_A, 1));
+          ctx->h_scal[S_A + 1] = r1known * r1known;
+        } else {
+          la_dot(ctx, R1 + pob, R1 + pob, pon, S_A + 1);
+          PPH_TRY(la_fetch(ctx, S_A, 2));
+        }
         res = std::sqrt(ctx->h_scal[S_A] + ctx->h_scal[S_A + 1]);
+        rn0 = std::sqrt(ctx->h_scal[S_A]);
       } else {
+        la_spmv(ctx, A12, du2, tn);                                  // new coupling term
         la_copy(ctx, t12, tn, n);
         PPH_TRY(true_residual());
       }
