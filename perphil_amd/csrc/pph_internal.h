@@ -386,8 +386,10 @@ void la_spmv_resid(pph_ctx* ctx, const Csr& A, const double* x, const double* b,
 // t = (b ? b - A x : A x) ;  R += sign (t - told) ;  told = t ;  scal[slot] = sum of R^2 over [dlo, dhi)   (sign = +1 with
 // b, -1 without: the Picard sweeps' coupling product + residual bookkeeping + norm in one pass; `tmp`: n doubles,
 // used when A has no stencil-ELL copy)
+// z0 != null (stencil-ELL operators): also z0 = dinv0 .* R * (*w0), the first pre-smoothing of the solve that starts from R
 void la_spmv_shift(pph_ctx* ctx, const Csr& A, const double* x, const double* b, double* R, double* told, double* tmp,
-                   int slot, int64_t dlo, int64_t dhi);
+                   int slot, int64_t dlo, int64_t dhi, double* z0 = nullptr, const double* dinv0 = nullptr,
+                   const double* w0 = nullptr);
 void la_spmv_jacobi(pph_ctx* ctx, const Csr& A, const double* x, const double* b, const double* dinv,
                     const double* w /* device */, double* y, int dot_slot = -1, int64_t dlo = 0, int64_t dhi = 0,
                     bool x_ghosts_valid = false);
@@ -450,7 +452,7 @@ void la_reset_spmv_stats(pph_ctx* ctx);
 
 // stencil-ELL operator format (pph_sell.hip)
 int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x, const double* b, const double* dinv,
-              const double* w /* device */, double* y, double* part, int64_t dlo = 0, int64_t dhi = 0, double* aux = nullptr);
+              const double* w /* device */, double* y, double* part, int64_t dlo = 0, int64_t dhi = 0, double* aux = nullptr, double* z0 = nullptr);
 int sell_alloc(pph_ctx* ctx, const MeshData& mesh, DevBuf<double>& buf, Sell* out, int sym);
 int sell_from_csr(pph_ctx* ctx, const MeshData& mesh, const double* csr_val, DevBuf<double>& buf, Sell* out, int sym);
 // symmetric storage is used for operators that are symmetric on the local box: single context (a slab's ghost rows

@@ -318,8 +318,8 @@ void la_spmv_jacobi(pph_ctx* ctx, const Csr& A, const double* x, const double* b
 }
 
 void la_spmv_shift(pph_ctx* ctx, const Csr& A, const double* x, const double* b, double* R, double* told, double* tmp,
-                   int slot, int64_t dlo, int64_t dhi) {
-  if (!A.ell.val) {
+                   int slot, int64_t dlo, int64_t dhi, double* z0, const double* dinv0, const double* w0) {
+  if (!A.ell.val) {   // (callers offer z0 only for stencil-ELL operators)
     if (b) la_spmv_resid(ctx, A, x, b, tmp); else la_spmv(ctx, A, x, tmp);
     la_shift(ctx, R, told, tmp, b ? 1.0 : -1.0, A.nrows);
     la_dot(ctx, R + dlo, R + dlo, dhi - dlo, slot);
@@ -341,9 +341,9 @@ void la_spmv_shift(pph_ctx* ctx, const Csr& A, const double* x, const double* b,
       (void)hipEventRecord(ev->e0, ctx->stream);
     }
   }
-  const int grid = sell_spmv(ctx, A.ell, A.nrows, b ? 5 : 6, x, b, nullptr, nullptr, told, part, dlo, dhi, R);
+  const int grid = sell_spmv(ctx, A.ell, A.nrows, b ? 5 : 6, x, b, z0 ? dinv0 : nullptr, z0 ? w0 : nullptr, told, part, dlo, dhi, R, z0);
   if (ev) (void)hipEventRecord(ev->e1, ctx->stream);
-  const double bytes = (8.0 * sell_stored(A.ell.kind, A.ell.sym) + 16.0 + (b ? 8.0 : 0.0) + 24.0) * (double)A.nrows;
+  const double bytes = (8.0 * sell_stored(A.ell.kind, A.ell.sym) + 16.0 + (b ? 8.0 : 0.0) + 24.0 + (z0 ? 16.0 : 0.0)) * (double)A.nrows;
   ctx->n_spmv[0]++;
   ctx->spmv_bytes[0] += bytes;
   if (A.nrows >= ctx->mesh.n) { ctx->n_spmv_fine++; ctx->spmv_bytes_fine += bytes; }

@@ -23,15 +23,16 @@ __device__ inline double sell_wave_sum(double v) {
 // MODE 4: MODE 3 and the dot product b . y over the rows [dlo, dhi) (CG: r . z from the last kernel of the V-cycle)
 // MODE 5: t = b - A x ;  aux += t - y ;  y = t      MODE 6: t = A x ;  aux -= t - y ;  y = t      (the residual
 //         bookkeeping of the Picard sweeps, k_shift, in the epilogue of the coupling product) and the sum of
-//         aux^2 over the rows [dlo, dhi)
+//         aux^2 over the rows [dlo, dhi); z0 != null: also z0 = dinv .* aux * w (pre-smoothing of the new residual)
 // MODE 2 / 4 / 5 / 6 write one partial sum per workgroup to part[blockIdx.x]; the caller finishes the sum.
 // One thread owns RPT consecutive rows; a workgroup a chunk of 256 RPT rows.  Chunks are dealt to the XCDs in groups
 // of `group` consecutive chunks (group 1 = plain grid-stride order); workgroups with equal blockIdx % 8 share an XCD.
 template <int KIND, int MODE, int RPT, bool CLAMP, bool SYM = false>
 __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_t ld, const double* __restrict__ x,
                                           const double* __restrict__ b, const double* __restrict__ dinv, double w,
-                                          double* __restrict__ y, double* __restrict__ aux, int64_t n, int px,
-                                          int64_t pxy, int64_t r0, double& dotacc, int64_t dlo, int64_t dhi) {
+                                          double* __restrict__ y, double* __restrict__ aux, double* __restrict__ z0,
+                                          int64_t n, int px, int64_t pxy, int64_t r0, double& dotacc, int64_t dlo,
+                                          int64_t dhi) {
   using ST = SellSt<KIND>;
   double acc[RPT];
   double bv[RPT], xr[RPT], dv[RPT], tv[RPT], av[RPT];
@@ -45,7 +46,7 @@ __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_
       if (MODE == 1 || (MODE >= 3 && MODE <= 5)) bv[i] = b[r0 + i];
       if (MODE >= 2 && MODE <= 4) xr[i] = x[r0 + i];
       if (MODE == 3 || MODE == 4) dv[i] = dinv[r0 + i];
-      if (MODE >= 5) { tv[i] = y[r0 + i]; av[i] = aux[r0 + i]; }
+      if (MODE >= 5) { tv[i] = y[r0 + i]; av[i] = aux[r0 + i]; if (z0) dv[i] = dinv[r0 + i]; }
     }
   }
   int slot = 0;
@@ -127,6 +128,7 @@ __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_
       const double rn = av[i] + ((MODE == 5) ? 1.0 : -1.0) * (tn - tv[i]);   // k_shift
       aux[r] = rn;
       y[r] = tn;
+      if (z0) z0[r] = dv[i] * rn * w;   // the next block solve's first pre-smoothing (k_cg_update_dev's order)
       if (r >= dlo && r < dhi) dotacc += rn * rn;
     } else {
       const double yn = xr[i] + dv[i] * (bv[i] - acc[i]) * w;   // the order of k_cheb_init: dinv * r / theta
@@ -140,15 +142,15 @@ template <int KIND, int MODE, int RPT, bool SYM = false>
 __global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ val, int64_t ld,
                                                    const double* __restrict__ x, const double* __restrict__ b,
                                                    const double* __restrict__ dinv, const double* __restrict__ wp,
-                                                   double* __restrict__ y, double* __restrict__ aux, int64_t n, int px,
-                                                   int64_t pxy, int64_t halo,
+                                                   double* __restrict__ y, double* __restrict__ aux,
+                                                   double* __restrict__ z0, int64_t n, int px, int64_t pxy, int64_t halo,
                                                    int64_t nchunks,
                                                    int group, int zwalk, int xmap, double* __restrict__ part,
                                                    int64_t dlo, int64_t dhi) {
   constexpr int CH = 256 * RPT;
   const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, bpx = gridDim.x >> 3;   // launcher keeps gridDim.x a multiple of 8
   // the smoother weight lives in device memory (refreshed per assembly) so that captured graphs survive a re-assembly
-  const double w = (MODE == 3 || MODE == 4) ? *wp : 0.0;
+  const double w = (MODE == 3 || MODE == 4 || (MODE >= 5 && z0)) ? *wp : 0.0;
   double dotacc = 0.0;
   // Chunk order.  zwalk = Z > 0 (3D): a workgroup takes Z work items in a row that sit at the same in-plane position
   // of Z consecutive node planes (chunk, chunk + P, ..., P = chunks per plane rounded: the rows shift by pxy - P CH,
@@ -194,9 +196,9 @@ __global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ va
     // a chunk whose rows and x window lie inside [0, n) needs no index clamps and no row masks (all but the first
     // and last few chunks)
     if (c0 >= halo && c0 + CH + halo <= n)
-      sell_rows<KIND, MODE, RPT, false, SYM>(val, ld, x, b, dinv, w, y, aux, n, px, pxy, r0, dotacc, dlo, dhi);
+      sell_rows<KIND, MODE, RPT, false, SYM>(val, ld, x, b, dinv, w, y, aux, z0, n, px, pxy, r0, dotacc, dlo, dhi);
     else
-      sell_rows<KIND, MODE, RPT, true, SYM>(val, ld, x, b, dinv, w, y, aux, n, px, pxy, r0, dotacc, dlo, dhi);
+      sell_rows<KIND, MODE, RPT, true, SYM>(val, ld, x, b, dinv, w, y, aux, z0, n, px, pxy, r0, dotacc, dlo, dhi);
   }
   if (MODE == 2 || MODE >= 4) {
     __shared__ double lds[4];
@@ -209,18 +211,18 @@ __global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ va
 
 template <int KIND, int RPT>
 static void sell_launch_mode(pph_ctx* ctx, int mode, int grid, const Sell& E, const double* x, const double* b,
-                             const double* dinv, const double* w, double* y, double* aux, int64_t n, int64_t nchunks,
+                             const double* dinv, const double* w, double* y, double* aux, double* z0, int64_t n, int64_t nchunks,
                              int group, double* part, int64_t dlo, int64_t dhi) {
   const int64_t pxy = (int64_t)E.px * E.py;
   const int64_t halo = (E.pz > 1 ? pxy : 0) + E.px + 2;   // reach of the x window of a row (2D: no z lines)
   const int zwalk = (E.sym && E.pz > 2 && ctx->sell_zwalk > 0 && nchunks >= ctx->sell_zwalk_min_chunks) ? ctx->sell_zwalk : 0;   // (no gain on full storage)
 #define PPH_SELL_GO(MM)                                                                                              \
   hipLaunchKernelGGL((k_spmv_sell<KIND, MM, RPT>), dim3(grid), dim3(256), 0, ctx->stream, E.val, E.ld, x, b, dinv, w, \
-                     y, aux, n, E.px, pxy, halo, nchunks, group, zwalk, ctx->sell_xmap, part, dlo, dhi)
+                     y, aux, z0, n, E.px, pxy, halo, nchunks, group, zwalk, ctx->sell_xmap, part, dlo, dhi)
   if (E.sym) {
 #define PPH_SELL_GOS(MM)                                                                                                   \
   hipLaunchKernelGGL((k_spmv_sell<KIND, MM, RPT, true>), dim3(grid), dim3(256), 0, ctx->stream, E.val, E.ld, x, b, dinv, w, \
-                     y, aux, n, E.px, pxy, halo, nchunks, group, zwalk, ctx->sell_xmap, part, dlo, dhi)
+                     y, aux, z0, n, E.px, pxy, halo, nchunks, group, zwalk, ctx->sell_xmap, part, dlo, dhi)
     switch (mode) {
       case 0: PPH_SELL_GOS(0); break;
       case 1: PPH_SELL_GOS(1); break;
@@ -247,7 +249,7 @@ static void sell_launch_mode(pph_ctx* ctx, int mode, int grid, const Sell& E, co
 
 // launches the product; returns the grid (= number of partial sums written in mode 2)
 int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x, const double* b, const double* dinv,
-              const double* w, double* y, double* part, int64_t dlo, int64_t dhi, double* aux) {
+              const double* w, double* y, double* part, int64_t dlo, int64_t dhi, double* aux, double* z0) {
   const int rpt = (ctx->sell_rpt == 1) ? 1 : 2;
   const int64_t nchunks = ceil_div64(n, 256 * rpt);
   // grid: persistent, 2048 workgroups; with the z-walk order of symmetric operators ONE workgroup per CU: the value a
@@ -263,8 +265,8 @@ int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x,
   const int grid = (int)g;
   int group = ctx->sell_group > 0 ? ctx->sell_group : 1;
 #define PPH_SELL_KIND(KK)                                                                                     \
-  if (rpt == 1) sell_launch_mode<KK, 1>(ctx, mode, grid, E, x, b, dinv, w, y, aux, n, nchunks, group, part, dlo, dhi); \
-  else sell_launch_mode<KK, 2>(ctx, mode, grid, E, x, b, dinv, w, y, aux, n, nchunks, group, part, dlo, dhi)
+  if (rpt == 1) sell_launch_mode<KK, 1>(ctx, mode, grid, E, x, b, dinv, w, y, aux, z0, n, nchunks, group, part, dlo, dhi); \
+  else sell_launch_mode<KK, 2>(ctx, mode, grid, E, x, b, dinv, w, y, aux, z0, n, nchunks, group, part, dlo, dhi)
   switch (E.kind) {
     case PPH_CELL_QUAD: PPH_SELL_KIND(PPH_CELL_QUAD); break;
     case PPH_CELL_TRI: PPH_SELL_KIND(PPH_CELL_TRI); break;

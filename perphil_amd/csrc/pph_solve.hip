@@ -88,7 +88,7 @@ struct MgPre {
 static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double* x, const double* dinv, const ApplyFn& pc,
                             double rtol, double atol, int max_it, bool warm, double* r, double* z, double* p, double* q,
                             int slot, KspOut* out, double* hist, int hist_cap, double bnorm_hint, double reduction,
-                            const double* r_init, const MgPre& pre, double rnorm_hint = -1.0) {
+                            const double* r_init, const MgPre& pre, double rnorm_hint = -1.0, bool first_x0_ready = false) {
   const int64_t n = A.nrows;
   const Seg sg = pph_owned_seg(A.geom, n);
   auto apply_pc = [&](const double* in, double* o) {
@@ -154,7 +154,7 @@ static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double*
       la_p_update_dev(ctx, p, z, sRZn, sRZc, n);                          // p = z + (r.z_new / r.z) p
       return PPH_OK;
     };
-    pc_and_rz(p, sRZc, false);                        // first direction p = z_0: written in place
+    pc_and_rz(p, sRZc, first_x0_ready && pre.on);     // first direction p = z_0: written in place (pre-smoothed by the caller?)
     PPH_TRY(la_reduce_device(ctx, sRZc, 1));
     // Iterations after the first are one hipGraph each (direction half, product half, publication of p.Ap and r.r):
     // on small meshes the kernels are shorter than the 3.5 us the host needs to enqueue one, so an eager iteration
@@ -236,7 +236,7 @@ static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double*
 // ------------------------------------------------------------------------------------------------
 static int cg_solve_fixed(pph_ctx* ctx, const Csr& A, const double* b, double* x, const double* dinv, const ApplyFn& pc,
                           int its, bool warm, double* r, double* z, double* p, double* q, int slot, KspOut* out,
-                          const double* r_init, const MgPre& pre) {
+                          const double* r_init, const MgPre& pre, bool first_x0_ready = false) {
   const int64_t n = A.nrows;
   const Seg sg = pph_owned_seg(A.geom, n);
   auto apply_pc = [&](const double* in, double* o) {
@@ -260,7 +260,7 @@ static int cg_solve_fixed(pph_ctx* ctx, const Csr& A, const double* b, double* x
     ctx->mg_x0_ready = false;
     if (!delivered) la_mdot_seg(ctx, r, 0, 1, zz, sg, slot_rz);
   };
-  pc_and_rz(p, sRZc, false);
+  pc_and_rz(p, sRZc, first_x0_ready && pre.on);
   PPH_TRY(la_reduce_device(ctx, sRZc, 1));
   for (int it = 0; it < its; ++it) {
     const bool last = (it == its - 1);
@@ -282,10 +282,10 @@ static int cg_solve(pph_ctx* ctx, const Csr& A, const double* b, double* x, cons
                     double rtol, double atol, int max_it, bool warm, double* r, double* z, double* p, double* q,
                     int slot, KspOut* out, double* hist, int hist_cap, double bnorm_hint = -1.0,
                     double reduction = 0.0, const double* r_init = nullptr, int norm_type = 0,
-                    const MgPre& pre = MgPre(), double rnorm_hint = -1.0) {
+                    const MgPre& pre = MgPre(), double rnorm_hint = -1.0, bool first_x0_ready = false) {
   const int64_t n = A.nrows;
   if (norm_type == 2 && la_device_scalars(ctx))
-    return cg_solve_fixed(ctx, A, b, x, dinv, pc, max_it, warm, r, z, p, q, slot, out, r_init, pre);
+    return cg_solve_fixed(ctx, A, b, x, dinv, pc, max_it, warm, r, z, p, q, slot, out, r_init, pre, first_x0_ready && warm && r_init);
   if (norm_type == 2) {
     // host-scalar transport: the natural-norm loop with an unreachable tolerance does the same iterations
     const int st = cg_solve_natural(ctx, A, b, x, dinv, pc, 0.0, 0.0, max_it, warm, r, z, p, q, slot, out, hist, hist_cap,
@@ -295,7 +295,7 @@ static int cg_solve(pph_ctx* ctx, const Csr& A, const double* b, double* x, cons
   }
   if (norm_type == 1)
     return cg_solve_natural(ctx, A, b, x, dinv, pc, rtol, atol, max_it, warm, r, z, p, q, slot, out, hist, hist_cap,
-                            bnorm_hint, reduction, r_init, pre, rnorm_hint);
+                            bnorm_hint, reduction, r_init, pre, rnorm_hint, first_x0_ready && warm && r_init);
   // reductions run over the owned entries of a slab (whole vector on a single GPU)
   const Seg sg = pph_owned_seg(A.geom, n);
   const bool fused = (dinv != nullptr) || !pc;
@@ -560,8 +560,17 @@ struct BlockSolver {
   // rnorm_hint >= 0: ||r_init|| over the owned rows, known to the caller.  last_res: residual norm the block's CG ended
   // with (unpreconditioned-norm CG only; -1 otherwise)
   double last_res = -1.0;
+  // where a caller that produces the residual a warm CG solve of block `which` starts from may leave its first
+  // pre-smoothing z0 = dinv .* r * w (then: solve(..., z0_ready = true)); false: this solve has no use for it
+  bool presmooth_target(int which, double** z0, const double** d, const double** w) {
+    if (cfg->inner_ksp_type != PPH_KSP_CG || cfg->inner_pc_type != PPH_PC_MG || cfg->inner_norm == 0 || !A[which].ell.val) return false;
+    const int ns = cfg->mg_smooth > 0 ? cfg->mg_smooth : 2;
+    bool lo = false;
+    if (!mg_pre_smoother(ctx, which, ns, d, w, &lo)) return false;
+    return work(ctx, W_IP, (size_t)ctx->n, z0) == PPH_OK;
+  }
   int solve(int which, const double* rhs, double* z, bool warm, const double* r_init = nullptr, double* r_io = nullptr,
-            double rnorm_hint = -1.0) {
+            double rnorm_hint = -1.0, bool z0_ready = false) {
     last_res = -1.0;
     const int64_t n = ctx->n;
     double *r, *zz, *p, *q;
@@ -611,7 +620,7 @@ struct BlockSolver {
     pre.tag = 16 * ns + which;
     PPH_TRY(cg_solve(ctx, A[which], rhs, z, dinv[which], pc, cfg->inner_rtol, cfg->inner_atol, cfg->inner_max_it,
                      warm, r, zz, p, q, S_INNER, &ko, nullptr, 0, warm ? bnorm_cache[which] : -1.0,
-                     cfg->inner_reduction, warm ? r_init : nullptr, cfg->inner_norm, pre, rnorm_hint));
+                     cfg->inner_reduction, warm ? r_init : nullptr, cfg->inner_norm, pre, rnorm_hint, z0_ready));
     if (!warm) bnorm_cache[which] = ko.bnorm;
     if (cfg->inner_norm == 1) last_res = ko.res;
     last_resid = r;
@@ -730,15 +739,23 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
     const bool launch_only = recur && cfg->inner_norm == 2 && cfg->inner_pc_type != PPH_PC_ILU && la_device_scalars(ctx) &&
                              ctx->world == 1 && ctx->fetch_spin && !ctx->time_spmv;
     double rn0 = -1.0;   // ||R0|| at the start of a warm sweep
+    // the coupling products also write the first pre-smoothing of the block solve that follows them (fused cycle)
+    double* z0p[2] = {nullptr, nullptr};
+    const double *z0d[2] = {nullptr, nullptr}, *z0w[2] = {nullptr, nullptr};
+    bool z0r[2] = {false, false};   // block 0: written by the previous sweep's last product
+    if (recur && A12.ell.val && A21.ell.val)
+      for (int f = 0; f < 2; ++f)
+        if (!bs.presmooth_target(f, &z0p[f], &z0d[f], &z0w[f])) z0p[f] = nullptr;
     while (res > tol && its < cfg->picard_max_it) {
       const bool warm = its > 0;
       if (warm && launch_only) {
         auto sweep = [&]() -> int {
           // (the block solves start from the residuals R0 / R1: their right-hand sides are not read)
-          PPH_TRY(bs.solve(0, pb, du1, true, R0, R0));
-          la_spmv_shift(ctx, A21, du1, b2, R1, rhs1, tn, S_B, pob, pob + pon);   // rhs1 = b2 - A21 du1 ; R1 follows
-          PPH_TRY(bs.solve(1, rhs1, du2, true, R1, R1));
-          la_spmv_shift(ctx, A12, du2, nullptr, R0, t12, tn, S_A, pob, pob + pon);    // t12 = A12 du2 ; R0 follows ; ||R0||^2
+          PPH_TRY(bs.solve(0, pb, du1, true, R0, R0, -1.0, z0r[0]));
+          la_spmv_shift(ctx, A21, du1, b2, R1, rhs1, tn, S_B, pob, pob + pon, z0p[1], z0d[1], z0w[1]);   // rhs1 = b2 - A21 du1 ; R1 follows
+          PPH_TRY(bs.solve(1, rhs1, du2, true, R1, R1, -1.0, z0p[1] != nullptr));
+          la_spmv_shift(ctx, A12, du2, nullptr, R0, t12, tn, S_A, pob, pob + pon, z0p[0], z0d[0], z0w[0]);    // t12 = A12 du2 ; R0 follows ; ||R0||^2
+          z0r[0] = z0p[0] != nullptr;
           la_dot(ctx, R1 + pob, R1 + pob, pon, S_A + 1);
           la_publish(ctx, S_A, 2);
           return PPH_OK;
@@ -770,11 +787,12 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
       // not read; with the unpreconditioned-norm test the host also knows the residual norms already (hints)
       const bool hints = warm && recur && cfg->inner_norm == 1;
       if (!(warm && recur)) la_sub(ctx, pb, b1, t12, n);             // rhs of the macro block
-      PPH_TRY(bs.solve(0, pb, du1, warm, (warm && recur) ? R0 : nullptr, recur ? R0 : nullptr, hints ? rn0 : -1.0));
+      PPH_TRY(bs.solve(0, pb, du1, warm, (warm && recur) ? R0 : nullptr, recur ? R0 : nullptr, hints ? rn0 : -1.0,
+                       warm && z0r[0]));
       double rn1 = -1.0;
       if (warm && recur) {
         // new rhs of the micro block, R1 += rhs1_new - rhs1_old, ||R1||^2 - one pass
-        la_spmv_shift(ctx, A21, du1, b2, R1, rhs1, tn, S_B, pob, pob + pon);
+        la_spmv_shift(ctx, A21, du1, b2, R1, rhs1, tn, S_B, pob, pob + pon, z0p[1], z0d[1], z0w[1]);
         if (hints) {
           PPH_TRY(la_fetch(ctx, S_B, 1));
           rn1 = std::sqrt(ctx->h_scal[S_B]);
@@ -782,11 +800,13 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
       } else {
         la_spmv_resid(ctx, A21, du1, b2, rhs1);
       }
-      PPH_TRY(bs.solve(1, rhs1, du2, warm, (warm && recur) ? R1 : nullptr, recur ? R1 : nullptr, rn1));
+      PPH_TRY(bs.solve(1, rhs1, du2, warm, (warm && recur) ? R1 : nullptr, recur ? R1 : nullptr, rn1,
+                       warm && recur && z0p[1] != nullptr));
       ++its;
       if (recur) {
         // new coupling term, R0 += A12 du2_old - A12 du2_new, ||R0||^2 - one pass (the first sweep: t12 = 0)
-        la_spmv_shift(ctx, A12, du2, nullptr, R0, t12, tn, S_A, pob, pob + pon);
+        la_spmv_shift(ctx, A12, du2, nullptr, R0, t12, tn, S_A, pob, pob + pon, z0p[0], z0d[0], z0w[0]);
+        z0r[0] = z0p[0] != nullptr;
         const double r1known = (cfg->inner_norm == 1) ? bs.last_res : -1.0;   // the CG's own final ||R1||
         if (r1known >= 0.0) {
           PPH_TRY(la_fetch(ctx, S_A, 1));
