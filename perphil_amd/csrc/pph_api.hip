@@ -550,6 +550,7 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
   if (!strcmp(name, "sell_blocks")) { ctx->sell_blocks = (int)value; return PPH_OK; }
   if (!strcmp(name, "sell_group")) { ctx->sell_group = (int)value; return PPH_OK; }
   if (!strcmp(name, "asm_tile")) { ctx->asm_tile = (value == 2.0) ? 2 : (value != 0.0 ? 1 : 0); return PPH_OK; }
+  if (!strcmp(name, "asm_affine")) { ctx->asm_affine = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "asm_tile_probe")) { ctx->asm_tile_probe = (int)value; return PPH_OK; }
   if (!strcmp(name, "asm_tile_min_nodes")) { ctx->asm_tile_min_nodes = (int64_t)value; return PPH_OK; }
   if (!strcmp(name, "asm_fused")) { ctx->asm_fused = value != 0.0 ? 1 : 0; return PPH_OK; }

@@ -1515,12 +1515,52 @@ __host__ __device__ constexpr double tile_dN(int q, int b, int e) {
   return v;
 }
 
+// geometry factor of one Gauss point from the Jacobian J[e][d] = sum_b dN[b][e] x_b[d]: packed symmetric
+// D = |det J| J^-1 J^-T and the weight |det J| (the arithmetic of the general pass of k_asm_tile)
+template <int DIM>
+__device__ __forceinline__ void tile_factor(const double (&J)[DIM][DIM], double* out) {
+  if constexpr (DIM == 2) {
+    const double det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+    const double r = 1.0 / det;
+    const double I00 = J[1][1] * r, I01 = -J[0][1] * r, I10 = -J[1][0] * r, I11 = J[0][0] * r;
+    const double w = fabs(det);
+    out[0] = w * (I00 * I00 + I10 * I10);
+    out[1] = w * (I00 * I01 + I10 * I11);
+    out[2] = w * (I01 * I01 + I11 * I11);
+    out[3] = w;
+  } else {
+    const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+    const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+    const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+    const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+    const double r = 1.0 / det;
+    double I[3][3];
+    I[0][0] = c00 * r;
+    I[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
+    I[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
+    I[1][0] = c01 * r;
+    I[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
+    I[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
+    I[2][0] = c02 * r;
+    I[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
+    I[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
+    const double w = fabs(det);
+    out[0] = w * (I[0][0] * I[0][0] + I[1][0] * I[1][0] + I[2][0] * I[2][0]);
+    out[1] = w * (I[0][0] * I[0][1] + I[1][0] * I[1][1] + I[2][0] * I[2][1]);
+    out[2] = w * (I[0][0] * I[0][2] + I[1][0] * I[1][2] + I[2][0] * I[2][2]);
+    out[3] = w * (I[0][1] * I[0][1] + I[1][1] * I[1][1] + I[2][1] * I[2][1]);
+    out[4] = w * (I[0][1] * I[0][2] + I[1][1] * I[1][2] + I[2][1] * I[2][2]);
+    out[5] = w * (I[0][2] * I[0][2] + I[1][2] * I[1][2] + I[2][2] * I[2][2]);
+    out[6] = w;
+  }
+}
+
 template <int DIM> struct TileGeo;
 template <> struct TileGeo<3> { static constexpr int TX = 8, TY = 4, TZ = 2; };
 template <> struct TileGeo<2> { static constexpr int TX = 16, TY = 8, TZ = 1; };
 
 template <int DIM>
-__global__ __launch_bounds__(512) void k_asm_tile(const double* __restrict__ cx, const double* __restrict__ cy,
+__global__ __launch_bounds__(512, 4) void k_asm_tile(const double* __restrict__ cx, const double* __restrict__ cy,
                                                   const double* __restrict__ cz, const int64_t* __restrict__ rowptr,
                                                   double* __restrict__ K, double* __restrict__ M, int nx, int ny, int nzl,
                                                   int px, int py, int pz, int64_t n, FuseArgs fa, int probe) {
@@ -1545,6 +1585,7 @@ __global__ __launch_bounds__(512) void k_asm_tile(const double* __restrict__ cx,
   __shared__ double sdN[NB][NB][DIM];
   __shared__ double sNq[NB][NB];
   __shared__ uint8_t sOK[NT][NB];
+  __shared__ uint8_t sAff[NC];
   double* const sD = sU;
   double* const sK = sU;
   double* const sM = sU + NT * NB * RSTR;
@@ -1640,62 +1681,114 @@ __global__ __launch_bounds__(512) void k_asm_tile(const double* __restrict__ cx,
       }
     }
     __syncthreads();
-    // ---- A: geometry factors, lane (cell, q)
-    for (int task = tid; task < NC * NB; task += 512) {
-      const int cl = task / NB, q = task % NB;
+    // ---- A: geometry factors.  A cell whose parallel edges are equal vectors (every cell of a structured box mesh:
+    // its vertices share coordinate values exactly) has a constant Jacobian J = [e_x e_y e_z] / 2: one lane per CELL
+    // computes the factor once and stores it for all Gauss points; the other cells take the general pass, lane (cell, q)
+    int any_general = 0;
+    for (int cl = tid; cl < NC; cl += 512) {
       const int ccx = cl % CX, ccy = (cl / CX) % CY, ccz = cl / (CX * CY);
       const int gi = i0 - 1 + ccx, gj = j0 - 1 + ccy, gk = (DIM == 3) ? k0 - 1 + ccz : 0;
       const bool incell = gi >= 0 && gi < nx && gj >= 0 && gj < ny && (DIM == 2 || (gk >= 0 && gk < nzl));
-      if (!incell) continue;
-      double J[DIM][DIM];
+      uint8_t aff = 1;
+      if (incell) {
+        double X[NB][DIM];
 #pragma unroll
-      for (int e = 0; e < DIM; ++e)
+        for (int b = 0; b < NB; ++b) {
+          const int v = (ccx + (b & 1)) + VX * ((ccy + ((b >> 1) & 1)) + VY * ((DIM == 3) ? ccz + ((b >> 2) & 1) : 0));
 #pragma unroll
-        for (int d = 0; d < DIM; ++d) J[e][d] = 0.0;
+          for (int d = 0; d < DIM; ++d) X[b][d] = sXv[v][d];
+        }
+        // edge vectors from vertex 0 along each reference direction e; affine iff every parallel edge equals it
+        double E[DIM][DIM];   // E[e][d] = x_{2^e}[d] - x_0[d]
+        bool ok = (probe != 6);   // (option asm_affine 0: every cell takes the general pass)
 #pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int v = (ccx + (b & 1)) + VX * ((ccy + ((b >> 1) & 1)) + VY * ((DIM == 3) ? ccz + ((b >> 2) & 1) : 0));
+        for (int e = 0; e < DIM; ++e) {
+#pragma unroll
+          for (int d = 0; d < DIM; ++d) E[e][d] = X[1 << e][d] - X[0][d];
+#pragma unroll
+          for (int b = 1; b < NB; ++b) {
+            if ((b >> e) & 1) continue;
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) ok = ok && (X[b | (1 << e)][d] - X[b][d] == E[e][d]);
+          }
+        }
+        if (ok) {
+          // J[e][d] = dx_d / dxi_e = E[e][d] / 2  (the convention of the general pass: J[e][d] = sum_b dN[b][e] x_b[d])
+          double J[DIM][DIM];
+#pragma unroll
+          for (int e = 0; e < DIM; ++e)
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) J[e][d] = 0.5 * E[e][d];
+          double o[ND];
+          tile_factor<DIM>(J, o);
+          double* out = sD + cl * DSTR;   // slot of Gauss point 0: phase B reads it for every q of such a cell
+#pragma unroll
+          for (int f = 0; f < ND; ++f) out[f] = o[f];
+        } else {
+          aff = 0;
+          any_general = 1;
+        }
+      }
+      sAff[cl] = aff;
+    }
+    any_general = __syncthreads_or(any_general);
+    if (any_general) {
+    for (int task = tid; task < NC * NB; task += 512) {
+        const int cl = task / NB, q = task % NB;
+        const int ccx = cl % CX, ccy = (cl / CX) % CY, ccz = cl / (CX * CY);
+        const int gi = i0 - 1 + ccx, gj = j0 - 1 + ccy, gk = (DIM == 3) ? k0 - 1 + ccz : 0;
+        const bool incell = gi >= 0 && gi < nx && gj >= 0 && gj < ny && (DIM == 2 || (gk >= 0 && gk < nzl));
+        if (!incell || sAff[cl]) continue;
+        double J[DIM][DIM];
 #pragma unroll
         for (int e = 0; e < DIM; ++e)
 #pragma unroll
-          for (int d = 0; d < DIM; ++d) J[e][d] += sdN[q][b][e] * sXv[v][d];
-      }
-      double* out = sD + cl * DSTR + q * ND;
-      if constexpr (DIM == 2) {
-        const double det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
-        const double r = 1.0 / det;
-        // I = J^-1 in the convention of k_elem_rows: g[b][d] = sum_e I[d][e] dN[b][e]
-        const double I00 = J[1][1] * r, I01 = -J[0][1] * r, I10 = -J[1][0] * r, I11 = J[0][0] * r;
-        const double w = fabs(det);
-        out[0] = w * (I00 * I00 + I10 * I10);
-        out[1] = w * (I00 * I01 + I10 * I11);
-        out[2] = w * (I01 * I01 + I11 * I11);
-        out[3] = w;
-      } else {
-        const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
-        const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
-        const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
-        const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
-        const double r = 1.0 / det;
-        double I[3][3];
-        I[0][0] = c00 * r;
-        I[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
-        I[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
-        I[1][0] = c01 * r;
-        I[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
-        I[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
-        I[2][0] = c02 * r;
-        I[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
-        I[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
-        const double w = fabs(det);
-        // D[e][f] = w sum_d I[d][e] I[d][f], packed 00 01 02 11 12 22
-        out[0] = w * (I[0][0] * I[0][0] + I[1][0] * I[1][0] + I[2][0] * I[2][0]);
-        out[1] = w * (I[0][0] * I[0][1] + I[1][0] * I[1][1] + I[2][0] * I[2][1]);
-        out[2] = w * (I[0][0] * I[0][2] + I[1][0] * I[1][2] + I[2][0] * I[2][2]);
-        out[3] = w * (I[0][1] * I[0][1] + I[1][1] * I[1][1] + I[2][1] * I[2][1]);
-        out[4] = w * (I[0][1] * I[0][2] + I[1][1] * I[1][2] + I[2][1] * I[2][2]);
-        out[5] = w * (I[0][2] * I[0][2] + I[1][2] * I[1][2] + I[2][2] * I[2][2]);
-        out[6] = w;
+          for (int d = 0; d < DIM; ++d) J[e][d] = 0.0;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          const int v = (ccx + (b & 1)) + VX * ((ccy + ((b >> 1) & 1)) + VY * ((DIM == 3) ? ccz + ((b >> 2) & 1) : 0));
+#pragma unroll
+          for (int e = 0; e < DIM; ++e)
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) J[e][d] += sdN[q][b][e] * sXv[v][d];
+        }
+        double* out = sD + cl * DSTR + q * ND;
+        if constexpr (DIM == 2) {
+          const double det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+          const double r = 1.0 / det;
+          // I = J^-1 in the convention of k_elem_rows: g[b][d] = sum_e I[d][e] dN[b][e]
+          const double I00 = J[1][1] * r, I01 = -J[0][1] * r, I10 = -J[1][0] * r, I11 = J[0][0] * r;
+          const double w = fabs(det);
+          out[0] = w * (I00 * I00 + I10 * I10);
+          out[1] = w * (I00 * I01 + I10 * I11);
+          out[2] = w * (I01 * I01 + I11 * I11);
+          out[3] = w;
+        } else {
+          const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+          const double c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+          const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+          const double det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+          const double r = 1.0 / det;
+          double I[3][3];
+          I[0][0] = c00 * r;
+          I[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) * r;
+          I[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) * r;
+          I[1][0] = c01 * r;
+          I[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) * r;
+          I[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) * r;
+          I[2][0] = c02 * r;
+          I[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) * r;
+          I[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
+          const double w = fabs(det);
+          // D[e][f] = w sum_d I[d][e] I[d][f], packed 00 01 02 11 12 22
+          out[0] = w * (I[0][0] * I[0][0] + I[1][0] * I[1][0] + I[2][0] * I[2][0]);
+          out[1] = w * (I[0][0] * I[0][1] + I[1][0] * I[1][1] + I[2][0] * I[2][1]);
+          out[2] = w * (I[0][0] * I[0][2] + I[1][0] * I[1][2] + I[2][0] * I[2][2]);
+          out[3] = w * (I[0][1] * I[0][1] + I[1][1] * I[1][1] + I[2][1] * I[2][1]);
+          out[4] = w * (I[0][1] * I[0][2] + I[1][1] * I[1][2] + I[2][1] * I[2][2]);
+          out[5] = w * (I[0][2] * I[0][2] + I[1][2] * I[1][2] + I[2][2] * I[2][2]);
+          out[6] = w;
+        }
       }
     }
     __syncthreads();
@@ -1714,9 +1807,10 @@ __global__ __launch_bounds__(512) void k_asm_tile(const double* __restrict__ cx,
       if (rowok) {
         const int cl = (ci - (i0 - 1)) + CX * ((cj - (j0 - 1)) + CY * ((DIM == 3) ? ck - (k0 - 1) : 0));
         const double* dc = sD + cl * DSTR;
+        const int qstr = sAff[cl] ? 0 : ND;   // constant factor of a cell with equal parallel edges: one slot
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
-          const double* dq = dc + q * ND;
+          const double* dq = dc + q * qstr;
           double t[DIM];
           if constexpr (DIM == 2) {
             const double g0 = sdN[q][c][0], g1 = sdN[q][c][1];
@@ -1877,10 +1971,10 @@ int pph_launch_fused_kernels(pph_ctx* ctx, MeshData& mesh, const FuseArgs& fa, d
     const int grid = (int)(ntiles < 256 * 16 ? ntiles : 256 * 16);
     if (mesh.kind == PPH_CELL_QUAD)
       hipLaunchKernelGGL(k_asm_tile<2>, dim3(grid), dim3(512), 0, ctx->stream, mesh.cx.p, mesh.cy.p, mesh.cz.p, mesh.rowptr.p,
-                         Kp, Mp, mesh.nx, mesh.ny, 0, mesh.px, mesh.py, 1, mesh.n, fa, ctx->asm_tile_probe);
+                         Kp, Mp, mesh.nx, mesh.ny, 0, mesh.px, mesh.py, 1, mesh.n, fa, ctx->asm_tile_probe ? ctx->asm_tile_probe : (ctx->asm_affine ? 0 : 6));
     else
       hipLaunchKernelGGL(k_asm_tile<3>, dim3(grid), dim3(512), 0, ctx->stream, mesh.cx.p, mesh.cy.p, mesh.cz.p, mesh.rowptr.p,
-                         Kp, Mp, mesh.nx, mesh.ny, mesh.nzl, mesh.px, mesh.py, mesh.pzl, mesh.n, fa, ctx->asm_tile_probe);
+                         Kp, Mp, mesh.nx, mesh.ny, mesh.nzl, mesh.px, mesh.py, mesh.pzl, mesh.n, fa, ctx->asm_tile_probe ? ctx->asm_tile_probe : (ctx->asm_affine ? 0 : 6));
     PPH_HIP(ctx, hipGetLastError());
     return PPH_OK;
   }

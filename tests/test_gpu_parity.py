@@ -843,7 +843,7 @@ def test_stencil_ell_format_equals_csr(gpu_ctx_factory, dim, kind, nx, ny, nz):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tile", [0, 1])
+@pytest.mark.parametrize("tile", [0, 1, 2])
 @pytest.mark.parametrize("dim,kind,nx,ny,nz", [(2, o.CELL_QUAD, 9, 6, 0), (3, o.CELL_HEX, 6, 5, 4), (3, o.CELL_HEX, 16, 16, 16),
                                                (2, o.CELL_QUAD, 37, 19, 0), (3, o.CELL_HEX, 19, 9, 5),
                                                (2, o.CELL_TRI, 8, 6, 0), (3, o.CELL_TET, 6, 4, 8)])
@@ -853,7 +853,11 @@ def test_fused_assembly_equals_two_step(gpu_ctx_factory, dim, kind, nx, ny, nz, 
     multigrid-preconditioned solve takes the same iterations; with asm_keep_km = 0 K and M are integrated on demand.
     tile = 0: the two-pass fused kernels (same arithmetic as the two-step path: bitwise equal); tile = 1: the
     single-pass tile kernel, which forms the element rows from geometry factors (another association order: equal to
-    1e-13 of the largest entry; simplices have no tile kernel and stay bitwise)."""
+    1e-13 of the largest entry; simplices have no tile kernel and stay bitwise); tile = 2: the tile kernel with
+    asm_affine = 0, i.e. its general pass (Jacobian per Gauss point) instead of the once-per-cell factor of cells with
+    equal parallel edges - which every cell of these box meshes is."""
+    if tile == 2 and kind in (o.CELL_TRI, o.CELL_TET):
+        pytest.skip("simplices have no tile kernel")
     f = _ffi()
     om = o.build_mesh(dim, kind, nx, ny, nz)
     b = o.boundary_nodes(om)
@@ -862,7 +866,8 @@ def test_fused_assembly_equals_two_step(gpu_ctx_factory, dim, kind, nx, ny, nz, 
     exact = (tile == 0) or kind in (o.CELL_TRI, o.CELL_TET)
     for mode, (fused, keep) in {"two-step": (0, 1), "fused": (1, 1), "fused-nokeep": (1, 0)}.items():
         ctx = gpu_ctx_factory()
-        ctx.set_option("asm_tile", 2 * tile)   # 2: the tile kernel on every level, whatever its size
+        ctx.set_option("asm_tile", 2 * min(tile, 1))   # 2: the tile kernel on every level, whatever its size
+        ctx.set_option("asm_affine", 0 if tile == 2 else 1)
         ctx.set_option("asm_fused", fused)
         ctx.set_option("asm_keep_km", keep)
         ctx.mesh_build(dim, kind, nx, ny, nz)
