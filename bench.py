@@ -179,6 +179,10 @@ def main():
                     help="extra pph_set_option settings for A/B runs (e.g. spmv_kernel=8)")
     ap.add_argument("--skip-fine-bench", action="store_true", help="omit the isolated fine-level SpMV loop (PMC passes)")
     ap.add_argument("--skip-csr", action="store_true", help="omit the extra untimed step on the CSR operator format")
+    ap.add_argument("--halo-overlap", type=int, default=0, choices=(0, 1, 2),
+                    help="N > 1: products of large levels as interior + boundary launches with the halo exchange of the "
+                         "operand on a second stream behind the interior rows (1), or the same launches serially (2); "
+                         "default 0: exchange, then one launch (the RCCL neighbour exchange has not run on hardware yet)")
     ap.add_argument("--allow-fallback", action="store_true",
                     help="N > 1: continue on the torch.distributed callback transport when the RCCL transport fails its "
                          "self-test (default: exit non-zero - no silent downgrade of a scaling run)")
@@ -221,6 +225,7 @@ def main():
                             allow_fallback=args.allow_fallback)
         transport, ranks_seen = solver.transport_label, solver.ranks_seen
         solver.ctx.set_option("asm_kernel", args.asm_kernel)
+        solver.ctx.set_option("halo_overlap", args.halo_overlap)
         for kv in args.set:
             solver.ctx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
         dofs_global = solver.global_dofs
@@ -399,6 +404,7 @@ def main():
             "operator_format": ("stencil-ELL, symmetric storage" if sym else "stencil-ELL") if sell else "CSR",
             "transport": transport, "ranks_seen": int(ranks_seen),
             "allreduces_per_step": int(cs["allreduces"]),
+            "halo_overlap": int(args.halo_overlap), "split_products_per_step": int(tm.get("split_products", 0)),
             "cells": N ** 3, "dofs": int(dofs_global), "parallelism": f"slab{world}" if world > 1 else "single",
             "picard_sweeps": int(info.iterations), "inner_cg_iterations": int(info.inner_iterations),
             "picard_ms_per_sweep": round(tm["solve_ms"] / max(int(info.iterations), 1), 3),

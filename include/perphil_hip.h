@@ -228,19 +228,26 @@ int pph_comm_stats(pph_ctx* ctx, int64_t* halo_exchanges, int64_t* allreduces, i
  * out[4+3v] sum of per-launch durations in ms (0 unless option "time_spmv" is on), out[5+3v] launches,
  * out[6+3v] algorithmic bytes (12 nnz + 20 nrows per launch); out[10] halo exchanges of the last solve;
  * out[11..13] the same three figures (ms, launches, bytes; both variants together) for the launches on
- * fine-level operators only (rows >= nodes of the mesh), i.e. without the coarser multigrid levels. */
+ * fine-level operators only (rows >= nodes of the mesh), i.e. without the coarser multigrid levels;
+ * out[14] products of the last solve launched as interior + boundary rows (option "halo_overlap", slabs only). */
 int pph_get_timers(pph_ctx* ctx, double* out, int n);
 /* tuning / profiling switches (no reference counterpart; defaults in brackets):
  *   "op_format" [1]      operator format of the scalar blocks inside block solves / Picard sweeps: 1 stencil-ELL
  *                        (values only, val[slot][row]; written directly by the fused assembly), 0 CSR.  pph_get_csr /
  *                        pph_spmv export CSR either way (converted on demand).
  *   "sell_rpt" [2], "sell_blocks" [2048], "sell_group" [1]   stencil-ELL SpMV: rows per thread, grid cap, XCD chunk group
+ *   "sell_sym" [1]       symmetric blocks store the diagonal and the upper stencil slots only (single context)
+ *   "sell_zwalk" [4], "sell_zwalk_min_chunks" [8192], "sell_xmap" [1]   symmetric product on large 3D levels: a workgroup
+ *                        walks this many node planes at one in-plane position (>= 1000: a balanced share of a whole z
+ *                        column); the in-plane positions of one XCD's workgroups are consecutive
  *   "spmv_kernel" [3]    CSR SpMV variant; values other than 3 need a library built with EXPERIMENTS=1
  *   "spmv_lanes" [0 = automatic, 4..64 lanes per CSR row], "spmv_blocks" [0 = 1024 workgroups], "spmv_bench_mode" [0]
  *   "time_spmv" [0]      1: bracket every SpMV launch of a solve with a HIP event pair on the context stream
  *   "asm_kernel" [2]     multilinear assembly: 0 cell-centred scatter-add (atomics), 1 node-centred gather, 2 fused kernels
  *   "asm_tile" [1]       fused multilinear assembly: 1 single-pass tile kernel on levels of at least
  *                        "asm_tile_min_nodes" [500000] nodes (2: on every level), 0 two-pass (element rows + gather)
+ *   "asm_affine" [1]     tile kernel: a cell whose parallel edges are equal vectors gets its constant geometry factor once
+ *                        per cell; 0: Jacobian at every Gauss point of every cell (the general pass)
  *   "asm_fused" [1]      the node-centred pass writes the eliminated blocks, lifted right-hand side and smoother
  *                        diagonal directly; 0: K and M first, then separate elimination kernels
  *   "asm_keep_km" [0]    1: the fused pass also stores K and M (otherwise they are integrated on demand)
@@ -252,7 +259,11 @@ int pph_get_timers(pph_ctx* ctx, double* out, int n);
  *                        operators (CSR only), replication threshold of coarse levels on slabs, coarsest solve on the device
  *   "fetch_spin" [1]     reduction results reach the host through a mapped mirror the host polls; 0: D2H copy + sync
  *   "use_graphs" [1]     Krylov iteration bodies / ILU sweeps replayed from captured hipGraphs on small systems (2: always)
- *   "device_scalars" [0] 1: the device-scalar CG branch also over the callback transport (tests) */
+ *   "device_scalars" [0] 1: the device-scalar CG branch also over the callback transport (tests)
+ *   "halo_overlap" [0]   slabs: products on levels of at least "halo_overlap_min_rows" [200000] rows are launched as
+ *                        interior rows + boundary rows; 1: the exchange of the operand's ghost planes runs on a second
+ *                        stream while the interior rows are computed, 2: the same launches, exchange first (the two
+ *                        give bit-identical results) */
 int pph_set_option(pph_ctx* ctx, const char* name, double value);
 
 #ifdef __cplusplus

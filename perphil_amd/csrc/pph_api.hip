@@ -81,6 +81,9 @@ int pph_ctx_create(int device, pph_ctx** out) {
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->num_cus = cus;
   }
   if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+  if ((e = hipStreamCreateWithFlags(&ctx->comm_stream, hipStreamNonBlocking)) != hipSuccess) return fail("hipStreamCreate", e);
+  if ((e = hipEventCreateWithFlags(&ctx->ev_x, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
+  if ((e = hipEventCreateWithFlags(&ctx->ev_h, hipEventDisableTiming)) != hipSuccess) return fail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev0)) != hipSuccess) return fail("hipEventCreate", e);
   if ((e = hipEventCreate(&ctx->ev1)) != hipSuccess) return fail("hipEventCreate", e);
   // host mirror of the reduction results: pinned, mapped and coherent, so that a one-wave kernel can publish results
@@ -148,6 +151,9 @@ int pph_ctx_destroy(pph_ctx* ctx) {
   if (ctx->h_scal) (void)hipHostFree(ctx->h_scal);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->ev_x) (void)hipEventDestroy(ctx->ev_x);
+  if (ctx->ev_h) (void)hipEventDestroy(ctx->ev_h);
+  if (ctx->comm_stream) (void)hipStreamDestroy(ctx->comm_stream);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return PPH_OK;
@@ -544,6 +550,8 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
     return PPH_OK;
   }
   if (!strcmp(name, "sell_zwalk_min_chunks")) { ctx->sell_zwalk_min_chunks = (int64_t)value; return PPH_OK; }
+  if (!strcmp(name, "halo_overlap")) { ctx->halo_overlap = (value == 2.0) ? 2 : (value != 0.0 ? 1 : 0); la_release_graphs(ctx); return PPH_OK; }
+  if (!strcmp(name, "halo_overlap_min_rows")) { ctx->halo_overlap_min_rows = (int64_t)value; la_release_graphs(ctx); return PPH_OK; }
   if (!strcmp(name, "sell_xmap")) { ctx->sell_xmap = value != 0; la_release_graphs(ctx); return PPH_OK; }
   if (!strcmp(name, "sell_zwalk")) { ctx->sell_zwalk = value > 0 ? (int)value : 0; return PPH_OK; }
   if (!strcmp(name, "sell_rpt")) { ctx->sell_rpt = (int)value; return PPH_OK; }
@@ -595,11 +603,11 @@ int pph_comm_set_callbacks(pph_ctx* ctx, int rank, int world, pph_halo_fn halo, 
 int pph_get_timers(pph_ctx* ctx, double* out, int n) {
   if (!ctx || !out) return PPH_ERR_INVALID;
   la_harvest_spmv_times(ctx);
-  const double v[14] = {ctx->t_mesh, ctx->t_asm, ctx->t_bc, ctx->t_solve,
+  const double v[15] = {ctx->t_mesh, ctx->t_asm, ctx->t_bc, ctx->t_solve,
                         ctx->t_spmv[0], (double)ctx->n_spmv[0], ctx->spmv_bytes[0],
                         ctx->t_spmv[1], (double)ctx->n_spmv[1], ctx->spmv_bytes[1], (double)ctx->n_halo,
-                        ctx->t_spmv_fine, (double)ctx->n_spmv_fine, ctx->spmv_bytes_fine};
-  for (int i = 0; i < n && i < 14; ++i) out[i] = v[i];
+                        ctx->t_spmv_fine, (double)ctx->n_spmv_fine, ctx->spmv_bytes_fine, (double)ctx->n_split};
+  for (int i = 0; i < n && i < 15; ++i) out[i] = v[i];
   return PPH_OK;
 }
 

@@ -131,8 +131,12 @@ static int comm_fail(pph_ctx* ctx, const char* what, const char* detail) {
 
 static const char* rccl_errstr(int r) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"; }
 
-int la_halo(pph_ctx* ctx, const MeshData& g, double* v) {
+// `on` (default: the context's stream): stream the RCCL exchange is issued on.  `x_ready` (callback transport): the
+// event after which v holds the planes to send - waited for instead of the whole stream, which may already carry
+// the interior rows of the product that consumes v (halo_overlap, pph_la.hip)
+int la_halo(pph_ctx* ctx, const MeshData& g, double* v, hipStream_t on, hipEvent_t x_ready) {
   if (ctx->world <= 1 || (!g.glo && !g.ghi)) return PPH_OK;
+  if (!on) on = ctx->stream;
   if (ctx->comm_status != PPH_OK) return ctx->comm_status;
   const int64_t pl = g.plane();
   const int64_t send_lo = g.glo ? pl : -1, recv_lo = g.glo ? 0 : -1;
@@ -141,15 +145,15 @@ int la_halo(pph_ctx* ctx, const MeshData& g, double* v) {
     // every call of the group is issued and the group is always closed, also after a failed call
     int bad = g_rccl.GroupStart();
     if (g.glo) {
-      int r = g_rccl.Send(v + send_lo, (size_t)pl, RCCL_DOUBLE, ctx->rank - 1, ctx->nccl_comm, ctx->stream);
+      int r = g_rccl.Send(v + send_lo, (size_t)pl, RCCL_DOUBLE, ctx->rank - 1, ctx->nccl_comm, on);
       bad = bad ? bad : r;
-      r = g_rccl.Recv(v + recv_lo, (size_t)pl, RCCL_DOUBLE, ctx->rank - 1, ctx->nccl_comm, ctx->stream);
+      r = g_rccl.Recv(v + recv_lo, (size_t)pl, RCCL_DOUBLE, ctx->rank - 1, ctx->nccl_comm, on);
       bad = bad ? bad : r;
     }
     if (g.ghi) {
-      int r = g_rccl.Send(v + send_hi, (size_t)pl, RCCL_DOUBLE, ctx->rank + 1, ctx->nccl_comm, ctx->stream);
+      int r = g_rccl.Send(v + send_hi, (size_t)pl, RCCL_DOUBLE, ctx->rank + 1, ctx->nccl_comm, on);
       bad = bad ? bad : r;
-      r = g_rccl.Recv(v + recv_hi, (size_t)pl, RCCL_DOUBLE, ctx->rank + 1, ctx->nccl_comm, ctx->stream);
+      r = g_rccl.Recv(v + recv_hi, (size_t)pl, RCCL_DOUBLE, ctx->rank + 1, ctx->nccl_comm, on);
       bad = bad ? bad : r;
     }
     const int re = g_rccl.GroupEnd();
@@ -159,7 +163,8 @@ int la_halo(pph_ctx* ctx, const MeshData& g, double* v) {
     return PPH_OK;
   }
   if (!ctx->halo_cb) return PPH_OK;
-  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return comm_fail(ctx, "halo exchange", "hipStreamSynchronize");
+  if ((x_ready ? hipEventSynchronize(x_ready) : hipStreamSynchronize(ctx->stream)) != hipSuccess)
+    return comm_fail(ctx, "halo exchange", "synchronisation before the callback");
   if (ctx->halo_cb(ctx->comm_user, v, pl, send_lo, recv_lo, send_hi, recv_hi) != 0)
     return comm_fail(ctx, "halo exchange", "callback returned an error");
   ctx->n_halo++;

@@ -235,6 +235,13 @@ struct pph_ctx {
   int num_cus = 256;                    // compute units of the device (hipDeviceProp_t::multiProcessorCount)
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // halo_overlap: the exchange of a product's operand runs on comm_stream while the rows that need no ghost value
+  // are computed; 0 off (one launch after the exchange), 1 overlapped, 2 the same three launches without overlap
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_x = nullptr, ev_h = nullptr;
+  int halo_overlap = 0;
+  int64_t halo_overlap_min_rows = 200000;
+  int64_t n_split = 0;                  // products launched split (statistics)
   std::string err;
 
   // mesh (local box)
@@ -441,7 +448,7 @@ int la_padded_experiment(pph_ctx* ctx, const Csr& A, int reps, double* avg_ms); 
 // fetch `count` reduction results starting at slot into ctx->h_scal (synchronises the stream)
 int la_fetch(pph_ctx* ctx, int slot, int count);
 // ghost planes of v <- owner's values (no-op without neighbours / communicator)
-int la_halo(pph_ctx* ctx, const MeshData& g, double* v);
+int la_halo(pph_ctx* ctx, const MeshData& g, double* v, hipStream_t on = nullptr, hipEvent_t x_ready = nullptr);
 // element-wise sum over all ranks of a device vector (small coarse-level vectors)
 int la_allreduce_vec(pph_ctx* ctx, double* v, int64_t n);
 int comm_allreduce_device(pph_ctx* ctx, double* dev, int64_t count);
@@ -453,7 +460,8 @@ void la_reset_spmv_stats(pph_ctx* ctx);
 
 // stencil-ELL operator format (pph_sell.hip)
 int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x, const double* b, const double* dinv,
-              const double* w /* device */, double* y, double* part, int64_t dlo = 0, int64_t dhi = 0, double* aux = nullptr, double* z0 = nullptr);
+              const double* w /* device */, double* y, double* part, int64_t dlo = 0, int64_t dhi = 0, double* aux = nullptr, double* z0 = nullptr,
+              int64_t cbeg = 0, int64_t cend = -1);
 int sell_alloc(pph_ctx* ctx, const MeshData& mesh, DevBuf<double>& buf, Sell* out, int sym);
 int sell_from_csr(pph_ctx* ctx, const MeshData& mesh, const double* csr_val, DevBuf<double>& buf, Sell* out, int sym);
 // symmetric storage is used for operators that are symmetric on the local box: single context (a slab's ghost rows

@@ -188,6 +188,58 @@ static int stream_T(int max_row) {
 #include "pph_spmv_experiments.inc"   // the A/B kernel variants of DESIGN.md section 4 (not part of the shipped library)
 #endif
 
+// Stencil-ELL product of a slab whose operand needs its ghost planes refreshed.  halo_overlap 0: exchange, then one
+// launch.  1 / 2: three launches - the chunks whose rows read no ghost value ("interior": everything but the two node
+// planes next to each ghost plane), then the boundary chunks below and above - and with 1 the exchange runs on the
+// communication stream WHILE the interior rows are computed: x is complete at ev_x; the exchange waits for ev_x
+// only, the boundary launches wait for the exchange (ev_h).  The rows' results do not depend on the split; the
+// partial sums of the dot-product modes are laid out launch after launch, so modes 1 and 2 are bit-identical.
+// Returns the number of partial sums written.
+static int sell_product(pph_ctx* ctx, const Csr& A, int mode, const double* x, const double* b, const double* dinv,
+                        const double* w, double* y, double* part, int64_t dlo, int64_t dhi, double* aux, double* z0,
+                        bool need_halo) {
+  const MeshData* g = A.geom;
+  const bool ghosts = g && ctx->world > 1 && (g->glo || g->ghi) && need_halo;
+  const bool one_field = g && A.nrows == g->n;
+  if (ghosts && one_field && ctx->halo_overlap > 0 && A.nrows >= ctx->halo_overlap_min_rows && ctx->comm_status == PPH_OK) {
+    const int64_t CH = 256 * ((ctx->sell_rpt == 1) ? 1 : 2);
+    const int64_t nchunks = ceil_div64(A.nrows, CH);
+    const int64_t pl = g->plane();
+    const int64_t reach = pl + g->px + 2;   // rows beyond its own a chunk reads x from
+    const int64_t c_lo = g->glo ? ceil_div64(pl + reach, CH) : 0;                                  // first interior chunk
+    const int64_t c_hi = g->ghi ? (A.nrows - pl - reach) / CH : nchunks;                           // one past the last
+    if (c_lo < c_hi) {
+      const bool overlap = ctx->halo_overlap == 1;
+      double* xv = const_cast<double*>(x);
+      int total = 0;
+      ctx->n_split++;
+      if (overlap) {
+        (void)hipEventRecord(ctx->ev_x, ctx->stream);
+        if (ctx->nccl_comm) {
+          (void)hipStreamWaitEvent(ctx->comm_stream, ctx->ev_x, 0);
+          (void)la_halo(ctx, *g, xv, ctx->comm_stream);
+          (void)hipEventRecord(ctx->ev_h, ctx->comm_stream);
+        }
+      } else {
+        (void)la_halo(ctx, *g, xv);
+      }
+      total += sell_spmv(ctx, A.ell, A.nrows, mode, x, b, dinv, w, y, part, dlo, dhi, aux, z0, c_lo, c_hi);
+      if (overlap) {
+        if (ctx->nccl_comm) (void)hipStreamWaitEvent(ctx->stream, ctx->ev_h, 0);
+        else (void)la_halo(ctx, *g, xv, nullptr, ctx->ev_x);   // callback transport: the host exchanges while the interior rows run
+      }
+      total += sell_spmv(ctx, A.ell, A.nrows, mode, x, b, dinv, w, y, part + total, dlo, dhi, aux, z0, 0, c_lo);
+      total += sell_spmv(ctx, A.ell, A.nrows, mode, x, b, dinv, w, y, part + total, dlo, dhi, aux, z0, c_hi, nchunks);
+      return total;
+    }
+  }
+  if (g && need_halo) {  // ghost planes of x <- owners (slabs only); field-major mixed vectors carry two fields
+    (void)la_halo(ctx, *g, const_cast<double*>(x));
+    if (A.nrows == 2 * g->n) (void)la_halo(ctx, *g, const_cast<double*>(x) + g->n);
+  }
+  return sell_spmv(ctx, A.ell, A.nrows, mode, x, b, dinv, w, y, part, dlo, dhi, aux, z0);
+}
+
 // returns the grid used (number of partial sums written when DOT)
 // jdinv != null (stencil-ELL operators only): y = x + jw * jdinv .* (bvec - A x), one damped-Jacobi sweep out of place
 template <bool DOT>
@@ -195,7 +247,7 @@ static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const doub
                          const double* jdinv = nullptr, const double* jw = nullptr, bool jdot = false, int64_t dlo = 0,
                          int64_t dhi = 0, bool x_ghosts_valid = false) {
   const int variant = DOT ? 1 : 0;
-  if (A.geom && !x_ghosts_valid) {  // ghost planes of x <- owners (slabs only); field-major mixed vectors carry two fields
+  if (A.geom && !x_ghosts_valid && !A.ell.val) {  // ghost planes of x <- owners (slabs only); field-major mixed vectors carry two fields
     (void)la_halo(ctx, *A.geom, const_cast<double*>(x));
     if (A.nrows == 2 * A.geom->n) (void)la_halo(ctx, *A.geom, const_cast<double*>(x) + A.geom->n);
   }
@@ -217,8 +269,8 @@ static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const doub
   double bytes_per_nnz = 12.0;
   if (A.ell.val) {
     // stencil-ELL copy of the operator (pph_sell.hip): 8 B per stored entry, no index arrays
-    grid = sell_spmv(ctx, A.ell, A.nrows, jdinv ? (jdot ? 4 : 3) : (DOT ? 2 : (bvec ? 1 : 0)), x, bvec, jdinv, jw, y,
-                     part ? part : partials(ctx), dlo, dhi);
+    grid = sell_product(ctx, A, jdinv ? (jdot ? 4 : 3) : (DOT ? 2 : (bvec ? 1 : 0)), x, bvec, jdinv, jw, y,
+                        part ? part : partials(ctx), dlo, dhi, nullptr, nullptr, !x_ghosts_valid);
     if (ev) (void)hipEventRecord(ev->e1, ctx->stream);
     // algorithmic bytes: every stored value once, x read once, y written once, plus the epilogue's vectors
     // (b for the residual form; b and 1 / a_ii for the Jacobi update)
@@ -325,7 +377,6 @@ void la_spmv_shift(pph_ctx* ctx, const Csr& A, const double* x, const double* b,
     la_dot(ctx, R + dlo, R + dlo, dhi - dlo, slot);
     return;
   }
-  if (A.geom) (void)la_halo(ctx, *A.geom, const_cast<double*>(x));
   double* part = partials(ctx);
   pph_ctx::EvPair* ev = nullptr;
   if (ctx->time_spmv) {   // (as spmv_dispatch: the instrumented step of bench.py times every product)
@@ -341,7 +392,7 @@ void la_spmv_shift(pph_ctx* ctx, const Csr& A, const double* x, const double* b,
       (void)hipEventRecord(ev->e0, ctx->stream);
     }
   }
-  const int grid = sell_spmv(ctx, A.ell, A.nrows, b ? 5 : 6, x, b, z0 ? dinv0 : nullptr, z0 ? w0 : nullptr, told, part, dlo, dhi, R, z0);
+  const int grid = sell_product(ctx, A, b ? 5 : 6, x, b, z0 ? dinv0 : nullptr, z0 ? w0 : nullptr, told, part, dlo, dhi, R, z0, true);
   if (ev) (void)hipEventRecord(ev->e1, ctx->stream);
   const double bytes = (8.0 * sell_stored(A.ell.kind, A.ell.sym) + 16.0 + (b ? 8.0 : 0.0) + 24.0 + (z0 ? 16.0 : 0.0)) * (double)A.nrows;
   ctx->n_spmv[0]++;

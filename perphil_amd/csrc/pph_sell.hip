@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ va
                                                    const double* __restrict__ dinv, const double* __restrict__ wp,
                                                    double* __restrict__ y, double* __restrict__ aux,
                                                    double* __restrict__ z0, int64_t n, int px, int64_t pxy, int64_t halo,
-                                                   int64_t nchunks,
+                                                   int64_t nchunks, int64_t chunk0,
                                                    int group, int zwalk, int xmap, double* __restrict__ part,
                                                    int64_t dlo, int64_t dhi) {
   constexpr int CH = 256 * RPT;
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ va
       chunk = base + q % group;
       if (chunk >= nchunks) continue;
     }
-    const int64_t c0 = chunk * CH;
+    const int64_t c0 = (chunk0 + chunk) * CH;   // (chunk0: first chunk of a sub-range launch, see sell_spmv)
     const int64_t r0 = c0 + (int64_t)threadIdx.x * RPT;
     // a chunk whose rows and x window lie inside [0, n) needs no index clamps and no row masks (all but the first
     // and last few chunks)
@@ -211,18 +211,18 @@ __global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ va
 
 template <int KIND, int RPT>
 static void sell_launch_mode(pph_ctx* ctx, int mode, int grid, const Sell& E, const double* x, const double* b,
-                             const double* dinv, const double* w, double* y, double* aux, double* z0, int64_t n, int64_t nchunks,
+                             const double* dinv, const double* w, double* y, double* aux, double* z0, int64_t n, int64_t nchunks, int64_t chunk0,
                              int group, double* part, int64_t dlo, int64_t dhi) {
   const int64_t pxy = (int64_t)E.px * E.py;
   const int64_t halo = (E.pz > 1 ? pxy : 0) + E.px + 2;   // reach of the x window of a row (2D: no z lines)
-  const int zwalk = (E.sym && E.pz > 2 && ctx->sell_zwalk > 0 && nchunks >= ctx->sell_zwalk_min_chunks) ? ctx->sell_zwalk : 0;   // (no gain on full storage)
+  const int zwalk = (E.sym && E.pz > 2 && ctx->sell_zwalk > 0 && chunk0 == 0 && nchunks >= ctx->sell_zwalk_min_chunks) ? ctx->sell_zwalk : 0;   // (no gain on full storage)
 #define PPH_SELL_GO(MM)                                                                                              \
   hipLaunchKernelGGL((k_spmv_sell<KIND, MM, RPT>), dim3(grid), dim3(256), 0, ctx->stream, E.val, E.ld, x, b, dinv, w, \
-                     y, aux, z0, n, E.px, pxy, halo, nchunks, group, zwalk, ctx->sell_xmap, part, dlo, dhi)
+                     y, aux, z0, n, E.px, pxy, halo, nchunks, chunk0, group, zwalk, ctx->sell_xmap, part, dlo, dhi)
   if (E.sym) {
 #define PPH_SELL_GOS(MM)                                                                                                   \
   hipLaunchKernelGGL((k_spmv_sell<KIND, MM, RPT, true>), dim3(grid), dim3(256), 0, ctx->stream, E.val, E.ld, x, b, dinv, w, \
-                     y, aux, z0, n, E.px, pxy, halo, nchunks, group, zwalk, ctx->sell_xmap, part, dlo, dhi)
+                     y, aux, z0, n, E.px, pxy, halo, nchunks, chunk0, group, zwalk, ctx->sell_xmap, part, dlo, dhi)
     switch (mode) {
       case 0: PPH_SELL_GOS(0); break;
       case 1: PPH_SELL_GOS(1); break;
@@ -249,14 +249,18 @@ static void sell_launch_mode(pph_ctx* ctx, int mode, int grid, const Sell& E, co
 
 // launches the product; returns the grid (= number of partial sums written in mode 2)
 int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x, const double* b, const double* dinv,
-              const double* w, double* y, double* part, int64_t dlo, int64_t dhi, double* aux, double* z0) {
+              const double* w, double* y, double* part, int64_t dlo, int64_t dhi, double* aux, double* z0, int64_t cbeg, int64_t cend) {
   const int rpt = (ctx->sell_rpt == 1) ? 1 : 2;
-  const int64_t nchunks = ceil_div64(n, 256 * rpt);
+  // [cbeg, cend) (cend < 0: all): the chunks of this launch - a product split into boundary and interior rows
+  const int64_t nchunks_all = ceil_div64(n, 256 * rpt);
+  const int64_t chunk0 = cend < 0 ? 0 : cbeg;
+  const int64_t nchunks = cend < 0 ? nchunks_all : cend - cbeg;
+  if (nchunks <= 0) return 0;
   // grid: persistent, 2048 workgroups; with the z-walk order of symmetric operators ONE workgroup per CU: the value a
   // plane reads a second time must still be in the XCD's 4 MB L2, and every resident workgroup streams 57 KB per plane
   // step (measured on the 256^3 block: 0.58 ms plain order, 0.51 ms z-walk with 4096 workgroups, 0.47 ms with 256;
   // profiles/r02_sell_sym_probe_256.txt, r02_sell_sym_probe2_256.txt)
-  const bool zw = E.sym && E.pz > 2 && ctx->sell_zwalk > 0 && nchunks >= ctx->sell_zwalk_min_chunks;   // (smaller levels: too few chunks per workgroup)
+  const bool zw = E.sym && E.pz > 2 && ctx->sell_zwalk > 0 && chunk0 == 0 && nchunks >= ctx->sell_zwalk_min_chunks;   // (smaller levels: too few chunks per workgroup)
   int cap = (ctx->sell_blocks >= 8 && ctx->sell_blocks <= 8192) ? (ctx->sell_blocks / 8) * 8
                                                                  : (zw ? ((ctx->num_cus + 7) / 8) * 8 : 2048);
   if ((mode == 2 || mode >= 4) && cap > 4096) cap = 4096;   // one partial sum per workgroup (PART_STRIDE of pph_la.hip)
@@ -265,8 +269,8 @@ int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x,
   const int grid = (int)g;
   int group = ctx->sell_group > 0 ? ctx->sell_group : 1;
 #define PPH_SELL_KIND(KK)                                                                                     \
-  if (rpt == 1) sell_launch_mode<KK, 1>(ctx, mode, grid, E, x, b, dinv, w, y, aux, z0, n, nchunks, group, part, dlo, dhi); \
-  else sell_launch_mode<KK, 2>(ctx, mode, grid, E, x, b, dinv, w, y, aux, z0, n, nchunks, group, part, dlo, dhi)
+  if (rpt == 1) sell_launch_mode<KK, 1>(ctx, mode, grid, E, x, b, dinv, w, y, aux, z0, n, nchunks, chunk0, group, part, dlo, dhi); \
+  else sell_launch_mode<KK, 2>(ctx, mode, grid, E, x, b, dinv, w, y, aux, z0, n, nchunks, chunk0, group, part, dlo, dhi)
   switch (E.kind) {
     case PPH_CELL_QUAD: PPH_SELL_KIND(PPH_CELL_QUAD); break;
     case PPH_CELL_TRI: PPH_SELL_KIND(PPH_CELL_TRI); break;

@@ -673,6 +673,7 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
   la_reset_spmv_stats(ctx);
   ctx->n_halo = 0;
   ctx->n_allreduce = 0;
+  ctx->n_split = 0;
   if (ctx->comm_status != PPH_OK) { ctx->err = ctx->comm_error; return ctx->comm_status; }
   PPH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
 

@@ -28,13 +28,18 @@ def _free_port():
                                                          # the device-scalar CG branch of the RCCL transport, over the callbacks
                                                          (2, 32, "hex", "mg", "picard-inexact-devscal"),
                                                          (4, 32, "hex", "mg", "picard-inexact-devscal"),
-                                                         (2, 16, "tet", "jacobi", "picard-devscal")])
+                                                         (2, 16, "tet", "jacobi", "picard-devscal"),
+                                                         # halo exchange overlapped with the interior rows of the products
+                                                         (2, 32, "hex", "mg", "picard-inexact-overlap"),
+                                                         (4, 32, "hex", "mg", "picard-inexact-overlap"),
+                                                         (2, 32, "hex", "mg", "picard-inexact-overlap-devscal"),
+                                                         (3, 24, "tet", "mg", "picard-overlap")])
 def test_slab_runs_match_single_context(world, cells, kind, pc, solver):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tools", "slab_check.py"), "--cells", str(cells), "--backend", "gloo", "--kind", kind,
            "--inner-pc", pc, "--solver", solver.split("-")[0]] + (["--inexact"] if "inexact" in solver else []) + (
-               ["--device-scalars"] if solver.endswith("devscal") else [])
+               ["--device-scalars"] if solver.endswith("devscal") else []) + (["--halo-overlap"] if "overlap" in solver else [])
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=280)
     line = [l for l in r.stdout.splitlines() if l.startswith("world=")]
     assert r.returncode == 0, (line, r.stdout[-2000:], r.stderr[-2000:])

@@ -19,6 +19,9 @@ ap.add_argument("--inexact", action="store_true",
                 help="the benchmark's Picard settings: V(1,1), block solves to a tenfold drop of the unpreconditioned residual")
 ap.add_argument("--device-scalars", action="store_true",
                 help="run the device-scalar CG branch (what the RCCL transport executes) over the callback transport")
+ap.add_argument("--halo-overlap", action="store_true",
+                help="products of large levels are split into interior and boundary rows, the halo exchange overlapping "
+                     "the interior rows: must equal the same split without overlap bit for bit (and the single context as usual)")
 ap.add_argument("--fail-halo-after", type=int, default=-1,
                 help="every rank's halo callback fails from this call on: the solve must return a COMM error, not a result")
 args = ap.parse_args()
@@ -68,6 +71,14 @@ if args.fail_halo_after >= 0:
     dist.barrier()
     dist.destroy_process_group()
     sys.exit(0 if flag.item() == 1.0 else 1)
+serial_split = None
+if args.halo_overlap:
+    # the three-launch split without overlap first, then the overlapped run that the comparison below uses
+    solver.ctx.set_option("halo_overlap_min_rows", 1000)
+    solver.ctx.set_option("halo_overlap", 2)
+    info_s = solver.step()
+    serial_split = (solver.gather_solution().copy(), info_s.iterations, info_s.inner_iterations)
+    solver.ctx.set_option("halo_overlap", 1)
 mono = args.solver != "picard"
 if mono:
     solver.cfg.picard = 0
@@ -78,6 +89,12 @@ if mono:
 info = solver.step()
 full = solver.gather_solution()
 ok = True
+if serial_split is not None:
+    same = np.array_equal(full, serial_split[0]) and (info.iterations, info.inner_iterations) == serial_split[1:]
+    nsplit = solver.ctx.timers()["split_products"]
+    print(f"rank {rank}: overlapped halo run {'==' if same else '!='} serial split (bitwise), sweeps {info.iterations}, inner {info.inner_iterations}, "
+          f"{nsplit} products split", flush=True)
+    ok = ok and same and nsplit > 0
 if rank == 0:
     ctx = _ffi.Context(device)
     ctx.mesh_build(3, kind, args.cells, args.cells, args.cells)
@@ -97,12 +114,12 @@ if rank == 0:
     print(f"world={world} n={args.cells} kind={args.kind} solver={args.solver} pc={args.inner_pc}: sweeps {info.iterations} vs {info1.iterations}, "
           f"inner its {info.inner_iterations} vs {info1.inner_iterations}, residual {info.resnorm:.3e} vs {info1.resnorm:.3e}, "
           f"max rel diff {err:.3e}, halo calls {solver.comm.halo_calls}, allreduce calls {solver.comm.allreduce_calls}", flush=True)
-    ok = (err < (1e-9 if not mono else 1e-7) and abs(info.iterations - info1.iterations) <= (0 if not mono else 2) and abs(info.inner_iterations - info1.inner_iterations) <= max(1, info1.inner_iterations // 50)
+    ok = ok and (err < (1e-9 if not mono else 1e-7) and abs(info.iterations - info1.iterations) <= (0 if not mono else 2) and abs(info.inner_iterations - info1.inner_iterations) <= max(1, info1.inner_iterations // 50)
           and info.converged == 1)
 flag = torch.tensor([1.0 if ok else 0.0])
 if args.backend == "nccl":
     flag = flag.cuda()
-dist.broadcast(flag, 0)
+dist.all_reduce(flag, op=dist.ReduceOp.MIN)
 dist.barrier()
 dist.destroy_process_group()
 sys.exit(0 if flag.item() == 1.0 else 1)
