@@ -192,6 +192,7 @@ struct MgLevel {
   DevBuf<double> dinv[2];
   DevBuf<uint8_t> mask[2];       // per field: non-zero where the dof is constrained
   DevBuf<uint8_t> rownear;       // rows that need the masks (fused level operators); follows the masks
+  DevBuf<uint8_t> rfast[2];      // per field: coarse nodes whose 3^d fine neighbours are all inside, owned and unconstrained (restriction fast path)
   int bc_epoch = -1;             // ctx->bc_epoch the masks / rownear were derived from
   const uint8_t* maskp[2] = {nullptr, nullptr};
   DevBuf<double> x, b, r, d, t, w;  // work vectors of the V-cycle (x, b unused on level 0)

@@ -116,18 +116,63 @@ __global__ void k_restrict(double* __restrict__ bc, const double* __restrict__ r
 // Q1 (quad / hex) restriction with the 3^DIM stencil unrolled and every load unconditional (out-of-range and
 // constrained neighbours get weight 0 and a clamped address): all loads of a coarse node are in flight together,
 // where the generic loop above waits for each conditional load before issuing the next.
+// fast[C] = 1 where the restriction of coarse node C needs neither masks nor range checks: C unconstrained and
+// assigned to this rank, its 3^DIM fine neighbours all inside the local box and unconstrained (every node away from
+// the boundary and from Dirichlet sets).  Depends on the masks only: rebuilt with them.
+template <int DIM>
+__global__ __launch_bounds__(256) void k_restrict_flags(uint8_t* __restrict__ fast, const uint8_t* __restrict__ mc,
+                                                        const uint8_t* __restrict__ mf, TGeom g) {
+  const int64_t nc = (int64_t)g.pxc * g.pyc * g.pzc;
+  NODE_LOOP(id, nc) {
+    const int I = (int)(id % g.pxc);
+    const int64_t t = id / g.pxc;
+    const int J = (int)(t % g.pyc), K = (int)(t / g.pyc) + g.gzc;
+    bool ok = mc[id] == 0 && 2 * K >= g.own_lo_f && 2 * K < g.own_hi_f;
+    constexpr int NZ = (DIM == 3) ? 3 : 1;
+    for (int dz = 0; dz < NZ && ok; ++dz)
+      for (int dy = 0; dy < 3 && ok; ++dy)
+        for (int dx = 0; dx < 3 && ok; ++dx) {
+          const int i = 2 * I + dx - 1, j = 2 * J + dy - 1, k = (DIM == 3) ? 2 * K + dz - 1 - g.gzf : 0;
+          ok = i >= 0 && i < g.pxf && j >= 0 && j < g.pyf && k >= 0 && k < g.pzf;
+          if (ok) ok = (mf[i + (int64_t)g.pxf * (j + (int64_t)g.pyf * k)] & 1) == 0;
+        }
+    fast[id] = ok ? 1 : 0;
+  }
+}
+
 template <int DIM>
 __global__ __launch_bounds__(256) void k_restrict_q1(double* __restrict__ bc, const double* __restrict__ rf,
                                                      const uint8_t* __restrict__ mc, const uint8_t* __restrict__ mf,
                                                      TGeom g, double* __restrict__ xc, const double* __restrict__ dinvc,
-                                                     const double* __restrict__ wcp) {
+                                                     const double* __restrict__ wcp, const uint8_t* __restrict__ fast) {
   const int64_t nc = (int64_t)g.pxc * g.pyc * g.pzc;
   NODE_LOOP(id, nc) {
     const int I = (int)(id % g.pxc);
     const int64_t t = id / g.pxc;
     const int J = (int)(t % g.pyc), K = (int)(t / g.pyc) + g.gzc;
     double s = 0.0;
-    if (mc[id] == 0 && 2 * K >= g.own_lo_f && 2 * K < g.own_hi_f) {
+    if (fast && fast[id]) {
+      // interior: 3^DIM unconditional loads, no masks (same weights, same order of accumulation as below)
+      constexpr int NZ = (DIM == 3) ? 3 : 1;
+      const int64_t f0 = (2 * I - 1) + (int64_t)g.pxf * ((2 * J - 1) + (int64_t)g.pyf * ((DIM == 3) ? 2 * K - 1 - g.gzf : 0));
+      double v[NZ][3][3];
+#pragma unroll
+      for (int dz = 0; dz < NZ; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) v[dz][dy][dx] = rf[f0 + dx + (int64_t)g.pxf * (dy + (int64_t)g.pyf * dz)];
+#pragma unroll
+      for (int dz = 0; dz < NZ; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) {
+            const int nzc = (dx != 1) + (dy != 1) + ((DIM == 3) ? (dz != 1) : 0);
+            const double w = (nzc == 0) ? 1.0 : (nzc == 1) ? 0.5 : (nzc == 2) ? 0.25 : 0.125;
+            s += w * v[dz][dy][dx];
+          }
+    } else if (mc[id] == 0 && 2 * K >= g.own_lo_f && 2 * K < g.own_hi_f) {
       constexpr int NZ = (DIM == 3) ? 3 : 1;
       double v[NZ][3][3];
       uint8_t m[NZ][3][3];
@@ -201,6 +246,46 @@ __global__ __launch_bounds__(256) void k_prolong_to(double* __restrict__ xout, c
       else s = (o == 0) ? xc[c] : 0.5 * (xc[c] + xc[c + o]);
     }
     xout[id] = x0 + s;
+  }
+}
+
+// Q1 interpolation, one thread per PAIR of fine nodes (2m, 2m + 1) of a grid line: the eight coarse values the odd
+// node interpolates contain the four of the even node - 8 loads for two nodes instead of 16; per node the
+// arithmetic of k_prolong_to<0> (an even node's 0.5 (c + c) is c exactly)
+__global__ __launch_bounds__(256) void k_prolong_to_q1(double* __restrict__ xout, const double* __restrict__ xf,
+                                                       const double* __restrict__ xc, const uint8_t* __restrict__ mf,
+                                                       TGeom g) {
+  const int hx = (g.pxf + 1) >> 1;
+  const int64_t npairs = (int64_t)hx * g.pyf * g.pzf;
+  NODE_LOOP(pid, npairs) {
+    const int m = (int)(pid % hx);
+    const int64_t t = pid / hx;
+    const int j = (int)(t % g.pyf), kl = (int)(t / g.pyf), kg = kl + g.gzf;
+    const int64_t id0 = 2 * m + (int64_t)g.pxf * (j + (int64_t)g.pyf * kl);
+    const bool has1 = 2 * m + 1 < g.pxf;
+    const int oy = j & 1, oz = kg & 1;
+    const int64_t sy = g.pxc, sz = (int64_t)g.pxc * g.pyc;
+    const int64_t c = m + sy * (j >> 1) + sz * ((kg >> 1) - g.gzc);
+    const int64_t ex = has1 ? 1 : 0, ey = oy ? sy : 0, ez = oz ? sz : 0;
+    const double x0 = xf[id0], x1 = has1 ? xf[id0 + 1] : 0.0;
+    const uint8_t m0 = mf[id0], m1 = has1 ? mf[id0 + 1] : 1;
+    const double a00 = xc[c], b00 = xc[c + ex], a10 = xc[c + ey], b10 = xc[c + ey + ex];
+    const double a01 = xc[c + ez], b01 = xc[c + ez + ex], a11 = xc[c + ez + ey], b11 = xc[c + ez + ey + ex];
+    double s0, s1;
+    {
+      const double v00 = 0.5 * (a00 + a00), v10 = 0.5 * (a10 + a10), v01 = 0.5 * (a01 + a01), v11 = 0.5 * (a11 + a11);
+      if (oy && oz) s0 = 0.25 * (v00 + v10 + v01 + v11);
+      else if (oy | oz) s0 = 0.5 * (v00 + (oy ? v10 : v01));
+      else s0 = v00;
+    }
+    {
+      const double v00 = 0.5 * (a00 + b00), v10 = 0.5 * (a10 + b10), v01 = 0.5 * (a01 + b01), v11 = 0.5 * (a11 + b11);
+      if (oy && oz) s1 = 0.25 * (v00 + v10 + v01 + v11);
+      else if (oy | oz) s1 = 0.5 * (v00 + (oy ? v10 : v01));
+      else s1 = v00;
+    }
+    xout[id0] = ((m0 & 1) != 0) ? x0 : x0 + s0;
+    if (has1) xout[id0 + 1] = ((m1 & 1) != 0) ? x1 : x1 + s1;
   }
 }
 
@@ -472,6 +557,16 @@ int mg_setup(pph_ctx* ctx) {
           else if (dist && !L.replicated) PPH_TRY(la_halo(ctx, m, mtmp.p));
           hipLaunchKernelGGL(k_mask_from_double, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, L.mask[f].p, mtmp.p, L.n,
                              m.plane(), m.glo, m.ghi);
+          // restriction fast path of the multilinear transfers
+          if (fm.kind == PPH_CELL_HEX || fm.kind == PPH_CELL_QUAD) {
+            PPH_TRY(L.rfast[f].alloc(ctx, (size_t)L.n));
+            if (fm.kind == PPH_CELL_HEX)
+              hipLaunchKernelGGL(k_restrict_flags<3>, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, L.rfast[f].p, L.mask[f].p,
+                                 F.maskp[f], tg);
+            else
+              hipLaunchKernelGGL(k_restrict_flags<2>, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, L.rfast[f].p, L.mask[f].p,
+                                 F.maskp[f], tg);
+          }
         }
       }
       const bool ell_only = use_ell && fuse_lv;   // the fused pass writes the stencil-ELL arrays directly
@@ -1209,10 +1304,10 @@ static void mg_vcycle_fused(pph_ctx* ctx, int which, const double* rin, double* 
     if (sum_c) { xc = nullptr; }
     if (kind == PPH_CELL_HEX)
       hipLaunchKernelGGL(k_restrict_q1<3>, dim3(mg_grid(C.n)), dim3(256), 0, ctx->stream, C.b.p, L.r.p, C.maskp[which],
-                         L.maskp[which], tgeom(L, C), xc, dc, wc);
+                         L.maskp[which], tgeom(L, C), xc, dc, wc, C.rfast[which].p);
     else if (kind == PPH_CELL_QUAD)
       hipLaunchKernelGGL(k_restrict_q1<2>, dim3(mg_grid(C.n)), dim3(256), 0, ctx->stream, C.b.p, L.r.p, C.maskp[which],
-                         L.maskp[which], tgeom(L, C), xc, dc, wc);
+                         L.maskp[which], tgeom(L, C), xc, dc, wc, C.rfast[which].p);
     else
       hipLaunchKernelGGL(k_restrict, dim3(mg_grid(C.n)), dim3(256), 0, ctx->stream, C.b.p, L.r.p, st, C.maskp[which],
                          L.maskp[which], tgeom(L, C), xc, dc, wc);
@@ -1285,7 +1380,7 @@ static void mg_vcycle_fused(pph_ctx* ctx, int which, const double* rin, double* 
     if (dist && !C.replicated) (void)la_halo(ctx, *C.geom, C.x.p);
     const TGeom tg = tgeom(L, C);
     if (kind == PPH_CELL_QUAD || kind == PPH_CELL_HEX)
-      hipLaunchKernelGGL(k_prolong_to<0>, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, L.t.p, x, C.x.p, L.maskp[which], tg);
+      hipLaunchKernelGGL(k_prolong_to_q1, dim3(mg_grid((L.n + 1) / 2 + L.py * L.pz)), dim3(256), 0, ctx->stream, L.t.p, x, C.x.p, L.maskp[which], tg);
     else if (kind == PPH_CELL_TET)
       hipLaunchKernelGGL(k_prolong_to<1>, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, L.t.p, x, C.x.p, L.maskp[which], tg);
     else
@@ -1341,10 +1436,12 @@ void mg_vcycle(pph_ctx* ctx, int which, const double* rin, double* zout, int nsm
     if (dist && !L.replicated) (void)la_halo(ctx, *L.geom, L.r.p);  // restriction reads one fine plane beyond the owned ones
     if (ctx->mesh.kind == PPH_CELL_HEX)
       hipLaunchKernelGGL(k_restrict_q1<3>, dim3(mg_grid(C.n)), dim3(256), 0, ctx->stream, C.b.p, L.r.p, C.maskp[which],
-                         L.maskp[which], tgeom(L, C), (double*)nullptr, (const double*)nullptr, (const double*)nullptr);
+                         L.maskp[which], tgeom(L, C), (double*)nullptr, (const double*)nullptr, (const double*)nullptr,
+                         C.rfast[which].p);
     else if (ctx->mesh.kind == PPH_CELL_QUAD)
       hipLaunchKernelGGL(k_restrict_q1<2>, dim3(mg_grid(C.n)), dim3(256), 0, ctx->stream, C.b.p, L.r.p, C.maskp[which],
-                         L.maskp[which], tgeom(L, C), (double*)nullptr, (const double*)nullptr, (const double*)nullptr);
+                         L.maskp[which], tgeom(L, C), (double*)nullptr, (const double*)nullptr, (const double*)nullptr,
+                         C.rfast[which].p);
     else
       hipLaunchKernelGGL(k_restrict, dim3(mg_grid(C.n)), dim3(256), 0, ctx->stream, C.b.p, L.r.p, st, C.maskp[which],
                          L.maskp[which], tgeom(L, C), (double*)nullptr, (const double*)nullptr, (const double*)nullptr);
