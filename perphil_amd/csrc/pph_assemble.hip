@@ -1574,21 +1574,22 @@ __global__ __launch_bounds__(512, 4) void k_asm_tile(const double* __restrict__ 
   constexpr int NV = VX * VY * VZ;                       // their vertices (240 / 180)
   constexpr int ND = DIM * (DIM + 1) / 2 + 1;            // doubles per (cell, q): packed symmetric D and |det J|
   constexpr int DSTR = NB * ND + 1;                      // cell stride of the factors (+1: off the bank period)
-  constexpr int RSTR = NB + 1;                           // row stride of the element rows
   static_assert(NT * NB == 512, "one lane per (node, corner)");
   // one LDS region, two lives: vertex coordinates + geometry factors (phases A, B), then the element rows K | M
   // (phase C) - 74 KB for hexahedra, so that two workgroups share a CU
   constexpr int NAB = NC * DSTR + NV * DIM;
-  constexpr int NUNI = (NAB > 2 * NT * NB * RSTR) ? NAB : 2 * NT * NB * RSTR;
+  constexpr int NROW = NB * NB * NT;                     // entries of the element rows K (and M): [corner][column][node]
+  constexpr int NUNI = (NAB > 2 * NROW) ? NAB : 2 * NROW;
   __shared__ double sU[NUNI];
   double (*const sXv)[DIM] = reinterpret_cast<double (*)[DIM]>(sU + NC * DSTR);
   __shared__ double sdN[NB][NB][DIM];
   __shared__ double sNq[NB][NB];
-  __shared__ uint8_t sOK[NT][NB];
+  __shared__ uint8_t sOK[NB][NT];
+  __shared__ double sRed[2][NB][NT];                     // per-group partial row sums, combined by the diagonal's group
   __shared__ uint8_t sAff[NC];
   double* const sD = sU;
   double* const sK = sU;
-  double* const sM = sU + NT * NB * RSTR;
+  double* const sM = sU + NROW;
   const int tid = threadIdx.x;
   if (tid < NB * NB) {
     const int q = tid / NB, b = tid % NB;
@@ -1632,8 +1633,12 @@ __global__ __launch_bounds__(512, 4) void k_asm_tile(const double* __restrict__ 
   const int tiles_x = (px + TX - 1) / TX, tiles_y = (py + TY - 1) / TY, tiles_z = (DIM == 3) ? (pz + TZ - 1) / TZ : 1;
   const int64_t ntiles = (int64_t)tiles_x * tiles_y * tiles_z;
   const int64_t pxy = (int64_t)px * py;
-  // this lane's node and corner inside the tile: consecutive lanes = the corners of one node, then the next node in x
-  const int ln = tid / NB, c = tid % NB;
+  // this lane's node and corner inside the tile
+  // lane mapping: corner / slot group c = tid / NT (uniform over a wave), node ln = tid % NT: consecutive lanes are
+  // consecutive nodes in x - the LDS rows [corner][column][node] are read and written without bank conflicts, the
+  // reference gradients of corner c and the candidate list of a slot are wave-uniform (scalar registers), and the
+  // candidate loop of a slot runs exactly as long as that slot needs on every lane of the wave
+  const int c = tid / NT, ln = tid % NT;
   const int lx = ln % TX, ly = (ln / TX) % TY, lz = ln / (TX * TY);
   double best1 = 0.0, best2 = 0.0;
   static_assert(NV <= 512, "one vertex per lane");
@@ -1837,17 +1842,18 @@ __global__ __launch_bounds__(512, 4) void k_asm_tile(const double* __restrict__ 
     __syncthreads();   // every lane has read its factors: the rows may overwrite them
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-      sK[(ln * NB + c) * RSTR + b] = Kr[b];
-      sM[(ln * NB + c) * RSTR + b] = Mr[b];
+      sK[(c * NB + b) * NT + ln] = Kr[b];
+      sM[(c * NB + b) * NT + ln] = Mr[b];
     }
-    sOK[ln][c] = rowok ? 1 : 0;
-    __syncthreads();
+    sOK[c][ln] = rowok ? 1 : 0;
+    // (the barrier also tells every lane whether the tile holds a node next to a Dirichlet dof: lifting sums needed)
+    const int tile_near = __syncthreads_or((innode && pnear != 0) ? 1 : 0);
     if (probe == 2) continue;   // timing probe: phases A and B
-    // ---- C: stencil row of the node, lane c takes slots c, c + NB, ...; fused epilogue
+    // ---- C: stencil row of the node; group c takes the slots c, c + NB, ... of all nodes of the tile; fused epilogue
+    const bool near = innode && pnear != 0;
+    const uint8_t r1 = near ? pr1 : 0, r2 = near ? pr2 : 0;
+    double s11 = 0.0, s22 = 0.0, d11 = 0.0, d22 = 0.0, lK1 = 0.0, lK2 = 0.0, lM = 0.0;
     if (innode) {
-      const bool near = pnear != 0;
-      const uint8_t r1 = near ? pr1 : 0, r2 = near ? pr2 : 0;
-      double s11 = 0.0, s22 = 0.0, d11 = 0.0, d22 = 0.0, lK1 = 0.0, lK2 = 0.0, lM = 0.0;
       int64_t rp = 0;
       if (fa.ld == 0 || fa.keep_km) rp = rowptr[node];
       for (int slot = c; slot < ((probe == 5) ? 0 : NSLOT); slot += NB) {   // (timing probe 5: no slot loop at all)
@@ -1859,9 +1865,9 @@ __global__ __launch_bounds__(512, 4) void k_asm_tile(const double* __restrict__ 
         const int ncand = (probe == 4) ? 0 : (int)(pk >> 48);   // (timing probe 4: no gather)
         for (int q = 0; q < ncand; ++q) {
           const int e = (int)(pk >> (6 * q)) & 63, cc = e & 7, b = e >> 3;
-          if (sOK[ln][cc]) {
-            kv += sK[(ln * NB + cc) * RSTR + b];
-            mv += sM[(ln * NB + cc) * RSTR + b];
+          if (sOK[cc][ln]) {
+            kv += sK[(cc * NB + b) * NT + ln];
+            mv += sM[(cc * NB + b) * NT + ln];
           }
         }
         const int32_t j = (int32_t)(node + sOff[slot]);
@@ -1903,25 +1909,58 @@ __global__ __launch_bounds__(512, 4) void k_asm_tile(const double* __restrict__ 
         s11 += fabs(o11); s22 += fabs(o22);
         if (diag) { d11 = o11; d22 = o22; }
       }
+    }
+    // the groups' partial sums of a node meet in LDS; the group that holds the diagonal slot combines them in the order
+    // of a shuffle tree over the groups (l[i] += l[i + NB/2], ..., l[0] += l[1]) and finishes the row
+    constexpr int GD = (NSLOT / 2) % NB;
+    auto combine = [&](const double (*part)[NT]) -> double {
+      double l[NB];
 #pragma unroll
-      for (int o = NB / 2; o > 0; o >>= 1) {
-        s11 += __shfl_down(s11, o, NB); s22 += __shfl_down(s22, o, NB);
-        d11 += __shfl_down(d11, o, NB); d22 += __shfl_down(d22, o, NB);
-        lK1 += __shfl_down(lK1, o, NB); lK2 += __shfl_down(lK2, o, NB); lM += __shfl_down(lM, o, NB);
-      }
-      if (c == 0) {
-        const double i1 = (d11 != 0.0) ? 1.0 / d11 : 1.0, i2 = (d22 != 0.0) ? 1.0 / d22 : 1.0;
-        fa.dinv1[node] = i1;
-        fa.dinv2[node] = i2;
-        const double q1 = s11 * fabs(i1), q2 = s22 * fabs(i2);
-        best1 = q1 > best1 ? q1 : best1;
-        best2 = q2 > best2 ? q2 : best2;
-        if (fa.rhs) {
-          fa.rhs[node] = (!near || r1 != 0) ? 0.0 : -(fa.a * lK1 + fa.b * lM);
-          fa.rhs[n + node] = (!near || r2 != 0) ? 0.0 : -(fa.c * lK2 - fa.b * lM);
+      for (int g = 0; g < NB; ++g) l[g] = part[g][ln];
+#pragma unroll
+      for (int o = NB / 2; o > 0; o >>= 1)
+#pragma unroll
+        for (int g = 0; g < o; ++g) l[g] += l[g + o];
+      return l[0];
+    };
+    sRed[0][c][ln] = s11;
+    sRed[1][c][ln] = s22;
+    __syncthreads();
+    double i1 = 1.0, i2 = 1.0;
+    if (c == GD && innode) {
+      const double t11 = combine(sRed[0]), t22 = combine(sRed[1]);
+      i1 = (d11 != 0.0) ? 1.0 / d11 : 1.0;
+      i2 = (d22 != 0.0) ? 1.0 / d22 : 1.0;
+      fa.dinv1[node] = i1;
+      fa.dinv2[node] = i2;
+      const double q1 = t11 * fabs(i1), q2 = t22 * fabs(i2);
+      best1 = q1 > best1 ? q1 : best1;
+      best2 = q2 > best2 ? q2 : best2;
+    }
+    if (fa.rhs) {
+      if (tile_near) {
+        // lifting sums of the rows next to Dirichlet dofs: the same meeting point, one quantity pair at a time
+        __syncthreads();
+        sRed[0][c][ln] = lK1;
+        sRed[1][c][ln] = lK2;
+        __syncthreads();
+        double tK1 = 0.0, tK2 = 0.0;
+        if (c == GD && innode) { tK1 = combine(sRed[0]); tK2 = combine(sRed[1]); }
+        __syncthreads();
+        sRed[0][c][ln] = lM;
+        __syncthreads();
+        if (c == GD && innode) {
+          const double tM = combine(sRed[0]);
+          fa.rhs[node] = (!near || r1 != 0) ? 0.0 : -(fa.a * tK1 + fa.b * tM);
+          fa.rhs[n + node] = (!near || r2 != 0) ? 0.0 : -(fa.c * tK2 - fa.b * tM);
           fa.u0[node] = near ? fa.g1[node] : 0.0;
           fa.u0[n + node] = near ? fa.g2[node] : 0.0;
         }
+      } else if (c == GD && innode) {
+        fa.rhs[node] = 0.0;
+        fa.rhs[n + node] = 0.0;
+        fa.u0[node] = 0.0;
+        fa.u0[n + node] = 0.0;
       }
     }
   }
