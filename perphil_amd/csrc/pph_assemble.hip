@@ -1515,6 +1515,37 @@ __host__ __device__ constexpr double tile_dN(int q, int b, int e) {
   return v;
 }
 
+// Reference-element integrals for cells with a constant geometry factor D (equal parallel edges):
+//   K_e[a][b] = sum_{e <= f} D[ef] G[a][b][ef],  G[a][b][ef] = sum_q dN_q[a][e] dN_q[b][f] (+ the transposed term, e != f)
+//   M_e[a][b] = |det J| M[a][b],                 M[a][b]     = sum_q N_q[a] N_q[b]
+// (ef in the packed order of tile_factor: 00 01 02 11 12 22 / 00 01 11)
+template <int DIM>
+struct TileRef {
+  double G[1 << DIM][1 << DIM][DIM * (DIM + 1) / 2];
+  double M[1 << DIM][1 << DIM];
+  constexpr TileRef() : G(), M() {
+    for (int a = 0; a < (1 << DIM); ++a)
+      for (int b = 0; b < (1 << DIM); ++b) {
+        int k = 0;
+        for (int e = 0; e < DIM; ++e)
+          for (int f = e; f < DIM; ++f) {
+            double s = 0.0;
+            for (int q = 0; q < (1 << DIM); ++q)
+              s += tile_dN<DIM>(q, a, e) * tile_dN<DIM>(q, b, f) + ((e != f) ? tile_dN<DIM>(q, a, f) * tile_dN<DIM>(q, b, e) : 0.0);
+            G[a][b][k++] = s;
+          }
+        double m = 0.0;
+        for (int q = 0; q < (1 << DIM); ++q) m += tile_N<DIM>(q, a) * tile_N<DIM>(q, b);
+        M[a][b] = m;
+      }
+  }
+};
+__device__ constexpr TileRef<2> kTileRef2 = TileRef<2>();
+__device__ constexpr TileRef<3> kTileRef3 = TileRef<3>();
+template <int DIM> __device__ __forceinline__ const TileRef<DIM>& tile_ref();
+template <> __device__ __forceinline__ const TileRef<2>& tile_ref<2>() { return kTileRef2; }
+template <> __device__ __forceinline__ const TileRef<3>& tile_ref<3>() { return kTileRef3; }
+
 // geometry factor of one Gauss point from the Jacobian J[e][d] = sum_b dN[b][e] x_b[d]: packed symmetric
 // D = |det J| J^-1 J^-T and the weight |det J| (the arithmetic of the general pass of k_asm_tile)
 template <int DIM>
@@ -1638,7 +1669,7 @@ __global__ __launch_bounds__(512, 4) void k_asm_tile(const double* __restrict__ 
   // consecutive nodes in x - the LDS rows [corner][column][node] are read and written without bank conflicts, the
   // reference gradients of corner c and the candidate list of a slot are wave-uniform (scalar registers), and the
   // candidate loop of a slot runs exactly as long as that slot needs on every lane of the wave
-  const int c = tid / NT, ln = tid % NT;
+  const int c = __builtin_amdgcn_readfirstlane(tid / NT), ln = tid % NT;   // (NT is a multiple of the wave size: uniform, kept in a scalar register)
   const int lx = ln % TX, ly = (ln / TX) % TY, lz = ln / (TX * TY);
   double best1 = 0.0, best2 = 0.0;
   static_assert(NV <= 512, "one vertex per lane");
@@ -1812,10 +1843,24 @@ __global__ __launch_bounds__(512, 4) void k_asm_tile(const double* __restrict__ 
       if (rowok) {
         const int cl = (ci - (i0 - 1)) + CX * ((cj - (j0 - 1)) + CY * ((DIM == 3) ? ck - (k0 - 1) : 0));
         const double* dc = sD + cl * DSTR;
-        const int qstr = sAff[cl] ? 0 : ND;   // constant factor of a cell with equal parallel edges: one slot
+        if (sAff[cl]) {
+          // constant factor: the sum over the Gauss points is a table of the reference element (row c: wave-uniform)
+          const TileRef<DIM>& R = tile_ref<DIM>();
+          double D[ND];
+#pragma unroll
+          for (int f = 0; f < ND; ++f) D[f] = dc[f];
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            double kb = 0.0;
+#pragma unroll
+            for (int f = 0; f < ND - 1; ++f) kb += D[f] * R.G[c][b][f];
+            Kr[b] = kb;
+            Mr[b] = D[ND - 1] * R.M[c][b];
+          }
+        } else
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
-          const double* dq = dc + q * qstr;
+          const double* dq = dc + q * ND;
           double t[DIM];
           if constexpr (DIM == 2) {
             const double g0 = sdN[q][c][0], g1 = sdN[q][c][1];

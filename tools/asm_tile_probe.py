@@ -7,7 +7,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 ctx = _ffi.Context(0); ctx.mesh_build(3, _ffi.CELL_HEX, N, N, N)
 b, g1, g2 = bench.mms_boundary(N, 1.0, 1e-2, 1.0, 1.0)
 ctx.set_dirichlet(0, b, g1); ctx.set_dirichlet(1, b, g2)
-for probe in (0, 2, 3, 4, 5, 0):
+for probe in (0, 1, 2, 3, 4, 5, 6, 0):
     ctx.set_option("asm_tile_probe", probe)
     for _ in range(3):
         ctx.set_option("invalidate_KM", 1)
