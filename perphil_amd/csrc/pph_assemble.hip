@@ -13,6 +13,7 @@
 // (segments found from the cell->dof map itself, so the merge is also correct on any other numbering).
 #include "pph_internal.h"
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 __device__ inline int64_t find_slot(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                     int32_t row, int32_t c) {
@@ -1615,7 +1616,6 @@ __global__ __launch_bounds__(512, 4) void k_asm_tile(const double* __restrict__ 
   double (*const sXv)[DIM] = reinterpret_cast<double (*)[DIM]>(sU + NC * DSTR);
   __shared__ double sdN[NB][NB][DIM];
   __shared__ double sNq[NB][NB];
-  __shared__ uint8_t sOK[NB][NT];
   __shared__ double sRed[2][NB][NT];                     // per-group partial row sums, combined by the diagonal's group
   __shared__ uint8_t sAff[NC];
   double* const sD = sU;
@@ -1662,7 +1662,7 @@ __global__ __launch_bounds__(512, 4) void k_asm_tile(const double* __restrict__ 
     sOff[tid] = (long long)dd[0] + (long long)dd[1] * px + (long long)dd[2] * (long long)px * py;
   }
   const int tiles_x = (px + TX - 1) / TX, tiles_y = (py + TY - 1) / TY, tiles_z = (DIM == 3) ? (pz + TZ - 1) / TZ : 1;
-  const int64_t ntiles = (int64_t)tiles_x * tiles_y * tiles_z;
+  const int ntiles = tiles_x * tiles_y * tiles_z;   // (launcher: fewer than 2^31 tiles; 32-bit, wave-uniform index arithmetic)
   const int64_t pxy = (int64_t)px * py;
   // this lane's node and corner inside the tile
   // lane mapping: corner / slot group c = tid / NT (uniform over a wave), node ln = tid % NT: consecutive lanes are
@@ -1677,10 +1677,10 @@ __global__ __launch_bounds__(512, 4) void k_asm_tile(const double* __restrict__ 
   // coordinates of the NEXT tile are requested while the current one is computed (register double buffer): the
   // load latency sat exposed in front of phase A with only two workgroups per CU to hide it
   double pv[3] = {0.0, 0.0, 0.0};
-  auto fetch_vertex = [&](int64_t tile) {
+  auto fetch_vertex = [&](int tile) {
     if (tile >= ntiles || tid >= NV) return;
-    const int tx = (int)(tile % tiles_x);
-    const int64_t tt = tile / tiles_x;
+    const int tx = tile % tiles_x;
+    const int tt = tile / tiles_x;
     const int ty = (int)(tt % tiles_y), tz = (int)(tt / tiles_y);
     const int vx = tid % VX, vy = (tid / VX) % VY, vz = tid / (VX * VY);
     int gi = tx * TX - 1 + vx, gj = ty * TY - 1 + vy, gk = (DIM == 3) ? tz * TZ - 1 + vz : 0;
@@ -1693,9 +1693,9 @@ __global__ __launch_bounds__(512, 4) void k_asm_tile(const double* __restrict__ 
     if constexpr (DIM == 3) pv[2] = cz[g];
   };
   fetch_vertex(blockIdx.x);
-  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const int tx = (int)(tile % tiles_x);
-    const int64_t tt = tile / tiles_x;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int tx = tile % tiles_x;
+    const int tt = tile / tiles_x;
     const int ty = (int)(tt % tiles_y), tz = (int)(tt / tiles_y);
     const int i0 = tx * TX, j0 = ty * TY, k0 = tz * TZ;
     __syncthreads();   // previous tile's rows are consumed
@@ -1704,7 +1704,7 @@ __global__ __launch_bounds__(512, 4) void k_asm_tile(const double* __restrict__ 
       sXv[tid][1] = pv[1];
       if constexpr (DIM == 3) sXv[tid][2] = pv[2];
     }
-    fetch_vertex(tile + gridDim.x);
+    fetch_vertex(tile + (int)gridDim.x);
     // operands of phase C that depend on the node only: requested now, used after three barriers
     uint8_t pnear = 0, pr1 = 0, pr2 = 0;
     {
@@ -1890,7 +1890,6 @@ __global__ __launch_bounds__(512, 4) void k_asm_tile(const double* __restrict__ 
       sK[(c * NB + b) * NT + ln] = Kr[b];
       sM[(c * NB + b) * NT + ln] = Mr[b];
     }
-    sOK[c][ln] = rowok ? 1 : 0;
     // (the barrier also tells every lane whether the tile holds a node next to a Dirichlet dof: lifting sums needed)
     const int tile_near = __syncthreads_or((innode && pnear != 0) ? 1 : 0);
     if (probe == 2) continue;   // timing probe: phases A and B
@@ -1908,12 +1907,27 @@ __global__ __launch_bounds__(512, 4) void k_asm_tile(const double* __restrict__ 
         double kv = 0.0, mv = 0.0;
         const unsigned long long pk = sCand[slot];
         const int ncand = (probe == 4) ? 0 : (int)(pk >> 48);   // (timing probe 4: no gather)
-        for (int q = 0; q < ncand; ++q) {
-          const int e = (int)(pk >> (6 * q)) & 63, cc = e & 7, b = e >> 3;
-          if (sOK[cc][ln]) {
-            kv += sK[(cc * NB + b) * NT + ln];
-            mv += sM[(cc * NB + b) * NT + ln];
+        // rows of cells that do not exist are zero rows (phase B stores them as such): no validity test; the candidate
+        // count is uniform over the wave and one of 1 / 2 / 4 / 8 - straight-line loads, all in flight together, summed
+        // in ascending candidate order
+        auto gather = [&](auto NC_) {
+          constexpr int NCAND = decltype(NC_)::value;
+          double kk[NCAND], mm[NCAND];
+#pragma unroll
+          for (int q = 0; q < NCAND; ++q) {
+            const int e = (int)(pk >> (6 * q)) & 63, cc = e & 7, b = e >> 3;
+            kk[q] = sK[(cc * NB + b) * NT + ln];
+            mm[q] = sM[(cc * NB + b) * NT + ln];
           }
+#pragma unroll
+          for (int q = 0; q < NCAND; ++q) { kv += kk[q]; mv += mm[q]; }
+        };
+        switch (ncand) {
+          case 1: gather(std::integral_constant<int, 1>()); break;
+          case 2: gather(std::integral_constant<int, 2>()); break;
+          case 4: gather(std::integral_constant<int, 4>()); break;
+          case 8: gather(std::integral_constant<int, 8>()); break;
+          default: break;
         }
         const int32_t j = (int32_t)(node + sOff[slot]);
         // position of the entry in the CSR row = number of existing neighbours in the slots before this one
@@ -2052,6 +2066,7 @@ int pph_launch_fused_kernels(pph_ctx* ctx, MeshData& mesh, const FuseArgs& fa, d
     // single pass, no element-row buffer (k_asm_tile)
     const int tx = (mesh.dim == 3) ? 8 : 16, ty = (mesh.dim == 3) ? 4 : 8, tz = (mesh.dim == 3) ? 2 : 1;
     const int64_t ntiles = ceil_div64(mesh.px, tx) * ceil_div64(mesh.py, ty) * ceil_div64(mesh.pzl, tz);
+    PPH_REQUIRE(ctx, ntiles < (int64_t)1 << 31, "tile assembly: too many tiles for 32-bit tile indices");
     const int grid = (int)(ntiles < 256 * 16 ? ntiles : 256 * 16);
     if (mesh.kind == PPH_CELL_QUAD)
       hipLaunchKernelGGL(k_asm_tile<2>, dim3(grid), dim3(512), 0, ctx->stream, mesh.cx.p, mesh.cy.p, mesh.cz.p, mesh.rowptr.p,
