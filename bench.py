@@ -312,7 +312,7 @@ def main():
     sell = not any(kv.split("=")[0] == "op_format" and float(kv.split("=")[1]) == 0 for kv in args.set)
     tr, launches, ms, byts = instrumented_step()
     achieved = (byts / 1e9) / (ms / 1e3) if ms > 0 else 0.0
-    sym = world == 1 and not any(kv.split("=")[0] == "sell_sym" and float(kv.split("=")[1]) == 0 for kv in args.set)
+    sym = bool(ctx.timers().get("symmetric_storage", False))   # what the last assembly actually stored
     S = 14 if sym else 27        # stored slots per row: diagonal + upper half of the 27-point stencil, or all of it
     sell_bytes = 8.0 * S * ctx.n + 16.0 * ctx.n
     csr_bytes = 12.0 * ctx.nnzb + 20.0 * ctx.n

@@ -229,14 +229,17 @@ int pph_comm_stats(pph_ctx* ctx, int64_t* halo_exchanges, int64_t* allreduces, i
  * out[6+3v] algorithmic bytes (12 nnz + 20 nrows per launch); out[10] halo exchanges of the last solve;
  * out[11..13] the same three figures (ms, launches, bytes; both variants together) for the launches on
  * fine-level operators only (rows >= nodes of the mesh), i.e. without the coarser multigrid levels;
- * out[14] products of the last solve launched as interior + boundary rows (option "halo_overlap", slabs only). */
+ * out[14] products of the last solve launched as interior + boundary rows (option "halo_overlap", slabs only);
+ * out[15] 1 when the stencil-ELL blocks of the last assembly use symmetric storage. */
 int pph_get_timers(pph_ctx* ctx, double* out, int n);
 /* tuning / profiling switches (no reference counterpart; defaults in brackets):
  *   "op_format" [1]      operator format of the scalar blocks inside block solves / Picard sweeps: 1 stencil-ELL
  *                        (values only, val[slot][row]; written directly by the fused assembly), 0 CSR.  pph_get_csr /
  *                        pph_spmv export CSR either way (converted on demand).
  *   "sell_rpt" [2], "sell_blocks" [2048], "sell_group" [1]   stencil-ELL SpMV: rows per thread, grid cap, XCD chunk group
- *   "sell_sym" [1]       symmetric blocks store the diagonal and the upper stencil slots only (single context)
+ *   "sell_sym" [1]       symmetric blocks store the diagonal and the upper stencil slots only; "sell_sym_slabs" [1]: also
+ *                        on slabs, where ghost rows then keep their entries towards owned columns (the mirrors of the
+ *                        owned rows' lower entries; operators converted from CSR values stay in full storage there)
  *   "sell_zwalk" [4], "sell_zwalk_min_chunks" [8192], "sell_xmap" [1]   symmetric product on large 3D levels: a workgroup
  *                        walks this many node planes at one in-plane position (>= 1000: a balanced share of a whole z
  *                        column); the in-plane positions of one XCD's workgroups are consecutive

@@ -373,7 +373,7 @@ static int attach_sell(pph_ctx* ctx, int which, Csr* A) {
     return PPH_OK;
   }
   // K, M and the blocks of the two-step path: symmetric as well (K, M before elimination; A12 only with one Dirichlet set)
-  const int sym = pph_sell_sym(ctx) && (which != 5 && which != 6 ? 1 : (ctx->a21_alias ? 1 : 0));
+  const int sym = pph_sell_sym_from_csr(ctx) && (which != 5 && which != 6 ? 1 : (ctx->a21_alias ? 1 : 0));
   return sell_from_csr(ctx, ctx->mesh, A->val, ctx->sell_tmp, &A->ell, sym);
 }
 
@@ -549,6 +549,11 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
     release_system(ctx);
     return PPH_OK;
   }
+  if (!strcmp(name, "sell_sym_slabs")) {   // takes effect at the next assembly
+    ctx->sell_sym_slabs = value != 0.0 ? 1 : 0;
+    release_system(ctx);
+    return PPH_OK;
+  }
   if (!strcmp(name, "sell_zwalk_min_chunks")) { ctx->sell_zwalk_min_chunks = (int64_t)value; return PPH_OK; }
   if (!strcmp(name, "halo_overlap")) { ctx->halo_overlap = (value == 2.0) ? 2 : (value != 0.0 ? 1 : 0); la_release_graphs(ctx); return PPH_OK; }
   if (!strcmp(name, "halo_overlap_min_rows")) { ctx->halo_overlap_min_rows = (int64_t)value; la_release_graphs(ctx); return PPH_OK; }
@@ -603,11 +608,12 @@ int pph_comm_set_callbacks(pph_ctx* ctx, int rank, int world, pph_halo_fn halo, 
 int pph_get_timers(pph_ctx* ctx, double* out, int n) {
   if (!ctx || !out) return PPH_ERR_INVALID;
   la_harvest_spmv_times(ctx);
-  const double v[15] = {ctx->t_mesh, ctx->t_asm, ctx->t_bc, ctx->t_solve,
+  const double v[16] = {ctx->t_mesh, ctx->t_asm, ctx->t_bc, ctx->t_solve,
                         ctx->t_spmv[0], (double)ctx->n_spmv[0], ctx->spmv_bytes[0],
                         ctx->t_spmv[1], (double)ctx->n_spmv[1], ctx->spmv_bytes[1], (double)ctx->n_halo,
-                        ctx->t_spmv_fine, (double)ctx->n_spmv_fine, ctx->spmv_bytes_fine, (double)ctx->n_split};
-  for (int i = 0; i < n && i < 15; ++i) out[i] = v[i];
+                        ctx->t_spmv_fine, (double)ctx->n_spmv_fine, ctx->spmv_bytes_fine, (double)ctx->n_split,
+                        (ctx->ell_ok && ctx->S11.sym) ? 1.0 : 0.0};
+  for (int i = 0; i < n && i < 16; ++i) out[i] = v[i];
   return PPH_OK;
 }
 

@@ -666,10 +666,25 @@ struct FuseArgs {
   // With symmetric storage (Sell::sym) only the diagonal and the upper slots are stored: slot_of is then the STORED
   // slot (s - S/2) or -1 for a lower slot, whose entry is not written.  The diagonal blocks (slot_of) and the coupling
   // blocks (slot_of_c: symmetric only when both fields carry the same Dirichlet set) have their own tables.
+  int symg;                        // symmetric storage on a slab: ghost rows keep their entries towards owned columns
   int64_t ld;
   int8_t slot_of[27];
   int8_t slot_of_c[27];
 };
+
+// Eliminated entries of the fused epilogues.  rm / cm: mask bytes of the row and of the column dof (bit 0 constrained,
+// bit 1 ghost plane of a slab).  Ghost rows belong to the neighbouring slab and are empty here - except, with
+// symmetric storage on slabs (`symg`), their entries towards OWNED columns: an owned row reads its lower entry
+// (r, g) as the upper entry stored with row g, which the local cells between the two planes determine completely.
+__device__ __forceinline__ double fuse_elim_diag(double v, uint8_t rm, uint8_t cm, bool diag, int symg) {
+  if (rm & 2) return (symg && !(cm & 2) && !(rm & 1) && !(cm & 1)) ? v : 0.0;
+  if (rm & 1) return diag ? 1.0 : 0.0;
+  return (cm & 1) ? 0.0 : v;
+}
+__device__ __forceinline__ double fuse_elim_coupling(double v, uint8_t rm, uint8_t cm_other, int symg) {
+  if (rm & 2) return (symg && !(cm_other & 2) && !(rm & 1) && !(cm_other & 1)) ? v : 0.0;
+  return ((rm & 1) || (cm_other & 1)) ? 0.0 : v;
+}
 
 static void fuse_set_format(FuseArgs& fa, int kind, int64_t ld, int sym = 0, int sym_c = 0) {
   fa.ld = ld;
@@ -840,15 +855,15 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__
           double o11 = fa.a * kv + fa.b * mv, o22 = fa.c * kv + fa.b * mv, o12 = -fa.b * mv, o21 = o12;
           if (near) {
             // same arithmetic as k_lift_rhs / k_blocks: ghost rows empty, Dirichlet rows identity, constrained columns zero
-            const bool c1 = (fa.m1[j] & 1) != 0, c2 = fa.same ? c1 : (fa.m2[j] & 1) != 0;
+            const uint8_t cm1 = fa.m1[j], cm2 = fa.same ? cm1 : fa.m2[j];
             if (fa.rhs) {
               const double v1 = fa.g1[j], v2 = fa.g2[j];
               lK1 += kv * v1; lK2 += kv * v2; lM += mv * (v1 - v2);
             }
-            o11 = (r1 & 2) ? 0.0 : (r1 & 1) ? (diag ? 1.0 : 0.0) : (c1 ? 0.0 : o11);
-            o22 = (r2 & 2) ? 0.0 : (r2 & 1) ? (diag ? 1.0 : 0.0) : (c2 ? 0.0 : o22);
-            o12 = (r1 != 0 || c2) ? 0.0 : -fa.b * mv;
-            o21 = (r2 != 0 || c1) ? 0.0 : -fa.b * mv;
+            o11 = fuse_elim_diag(o11, r1, cm1, diag, fa.symg);
+            o22 = fuse_elim_diag(o22, r2, cm2, diag, fa.symg);
+            o12 = fuse_elim_coupling(-fa.b * mv, r1, cm2, fa.symg);
+            o21 = fuse_elim_coupling(-fa.b * mv, r2, cm1, fa.symg);
           }
           const int64_t ko = fuse_out_index(fa, k, node, j, px, py), kc = fuse_out_index(fa, k, node, j, px, py, true);
           if (ko >= 0) { fa.A11[ko] = o11; fa.A22[ko] = o22; }
@@ -873,8 +888,8 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__
           fa.dinv1[node] = i1;
           fa.dinv2[node] = i2;
           const double q1 = s11 * fabs(i1), q2 = s22 * fabs(i2);
-          best1 = q1 > best1 ? q1 : best1;
-          best2 = q2 > best2 ? q2 : best2;
+          if (!(r1 & 2)) best1 = q1 > best1 ? q1 : best1;   // (ghost rows: not rows of this rank's operator)
+          if (!(r2 & 2)) best2 = q2 > best2 ? q2 : best2;
           if (fa.rhs) {
             fa.rhs[node] = (!near || r1 != 0) ? 0.0 : -(fa.a * lK1 + fa.b * lM);
             fa.rhs[n + node] = (!near || r2 != 0) ? 0.0 : -(fa.c * lK2 - fa.b * lM);
@@ -1031,15 +1046,15 @@ __global__ __launch_bounds__(256) void k_asm_simplex_gather(const int32_t* __res
           const bool diag = (jc == (int32_t)node);
           double o11 = fa.a * kv + fa.b * mv, o22 = fa.c * kv + fa.b * mv, o12 = -fa.b * mv, o21 = o12;
           if (near) {
-            const bool c1 = (fa.m1[jc] & 1) != 0, c2 = fa.same ? c1 : (fa.m2[jc] & 1) != 0;
+            const uint8_t cm1 = fa.m1[jc], cm2 = fa.same ? cm1 : fa.m2[jc];
             if (fa.rhs) {
               const double v1 = fa.g1[jc], v2 = fa.g2[jc];
               lK1 += kv * v1; lK2 += kv * v2; lM += mv * (v1 - v2);
             }
-            o11 = (r1 & 2) ? 0.0 : (r1 & 1) ? (diag ? 1.0 : 0.0) : (c1 ? 0.0 : o11);
-            o22 = (r2 & 2) ? 0.0 : (r2 & 1) ? (diag ? 1.0 : 0.0) : (c2 ? 0.0 : o22);
-            o12 = (r1 != 0 || c2) ? 0.0 : -fa.b * mv;
-            o21 = (r2 != 0 || c1) ? 0.0 : -fa.b * mv;
+            o11 = fuse_elim_diag(o11, r1, cm1, diag, fa.symg);
+            o22 = fuse_elim_diag(o22, r2, cm2, diag, fa.symg);
+            o12 = fuse_elim_coupling(-fa.b * mv, r1, cm2, fa.symg);
+            o21 = fuse_elim_coupling(-fa.b * mv, r2, cm1, fa.symg);
           }
           const int64_t ko = fuse_out_index(fa, s + q, node, jc, px, py), kc = fuse_out_index(fa, s + q, node, jc, px, py, true);
           if (ko >= 0) { fa.A11[ko] = o11; fa.A22[ko] = o22; }
@@ -1054,8 +1069,8 @@ __global__ __launch_bounds__(256) void k_asm_simplex_gather(const int32_t* __res
       fa.dinv1[node] = i1;
       fa.dinv2[node] = i2;
       const double q1 = s11 * fabs(i1), q2 = s22 * fabs(i2);
-      best1 = q1 > best1 ? q1 : best1;
-      best2 = q2 > best2 ? q2 : best2;
+      if (!(r1 & 2)) best1 = q1 > best1 ? q1 : best1;   // (ghost rows: not rows of this rank's operator)
+      if (!(r2 & 2)) best2 = q2 > best2 ? q2 : best2;
       if (fa.rhs) {
         fa.rhs[node] = (!near || r1 != 0) ? 0.0 : -(fa.a * lK1 + fa.b * lM);
         fa.rhs[n + node] = (!near || r2 != 0) ? 0.0 : -(fa.c * lK2 - fa.b * lM);
@@ -1467,8 +1482,8 @@ int pph_launch_blocks(pph_ctx* ctx, int monolithic) {
   ctx->csr_ok = true;
   ctx->ell_ok = false;
   if (ctx->op_format == 1) {
-    // the block solves run on stencil-ELL copies
-    const int sym = pph_sell_sym(ctx), sym_c = (sym && ctx->a21_alias) ? 1 : 0;
+    // the block solves run on stencil-ELL copies (CSR rows of ghost nodes are empty: symmetric storage only without slabs)
+    const int sym = pph_sell_sym_from_csr(ctx), sym_c = (sym && ctx->a21_alias) ? 1 : 0;
     PPH_TRY(sell_from_csr(ctx, ctx->mesh, ctx->A11.p, ctx->E11, &ctx->S11, sym));
     PPH_TRY(sell_from_csr(ctx, ctx->mesh, ctx->A22.p, ctx->E22, &ctx->S22, sym));
     PPH_TRY(sell_from_csr(ctx, ctx->mesh, ctx->A12.p, ctx->E12, &ctx->S12, sym_c));
@@ -1944,15 +1959,15 @@ __global__ __launch_bounds__(512, 4) void k_asm_tile(const double* __restrict__ 
         const bool diag = (slot == NSLOT / 2);
         double o11 = fa.a * kv + fa.b * mv, o22 = fa.c * kv + fa.b * mv, o12 = -fa.b * mv, o21 = o12;
         if (near) {
-          const bool c1 = (fa.m1[j] & 1) != 0, c2 = fa.same ? c1 : (fa.m2[j] & 1) != 0;
+          const uint8_t cm1 = fa.m1[j], cm2 = fa.same ? cm1 : fa.m2[j];
           if (fa.rhs) {
             const double v1 = fa.g1[j], v2 = fa.g2[j];
             lK1 += kv * v1; lK2 += kv * v2; lM += mv * (v1 - v2);
           }
-          o11 = (r1 & 2) ? 0.0 : (r1 & 1) ? (diag ? 1.0 : 0.0) : (c1 ? 0.0 : o11);
-          o22 = (r2 & 2) ? 0.0 : (r2 & 1) ? (diag ? 1.0 : 0.0) : (c2 ? 0.0 : o22);
-          o12 = (r1 != 0 || c2) ? 0.0 : -fa.b * mv;
-          o21 = (r2 != 0 || c1) ? 0.0 : -fa.b * mv;
+          o11 = fuse_elim_diag(o11, r1, cm1, diag, fa.symg);
+          o22 = fuse_elim_diag(o22, r2, cm2, diag, fa.symg);
+          o12 = fuse_elim_coupling(-fa.b * mv, r1, cm2, fa.symg);
+          o21 = fuse_elim_coupling(-fa.b * mv, r2, cm1, fa.symg);
         }
         const int sq = (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1);
         const int so = fa.slot_of[sq], sc = fa.slot_of_c[sq];     // stored slots (-1: lower half of a symmetric operator)
@@ -1993,8 +2008,8 @@ __global__ __launch_bounds__(512, 4) void k_asm_tile(const double* __restrict__ 
       fa.dinv1[node] = i1;
       fa.dinv2[node] = i2;
       const double q1 = t11 * fabs(i1), q2 = t22 * fabs(i2);
-      best1 = q1 > best1 ? q1 : best1;
-      best2 = q2 > best2 ? q2 : best2;
+      if (!(r1 & 2)) best1 = q1 > best1 ? q1 : best1;   // (ghost rows: not rows of this rank's operator)
+      if (!(r2 & 2)) best2 = q2 > best2 ? q2 : best2;
     }
     if (fa.rhs) {
       if (tile_near) {
@@ -2136,6 +2151,7 @@ int pph_launch_level_operators(pph_ctx* ctx, MeshData& mesh, const uint8_t* m1, 
                                double* dinv1, double* dinv2, unsigned long long* lam, int64_t ell_ld, int ell_sym) {
   FuseArgs fa;
   fuse_set_format(fa, mesh.kind, ell_ld, ell_sym, ell_sym);
+  fa.symg = (ell_sym && ctx->world > 1) ? 1 : 0;
   fa.m1 = m1; fa.m2 = m2; fa.near = near;
   fa.g1 = nullptr; fa.g2 = nullptr;
   fa.a = coefK1; fa.b = coefM; fa.c = coefK2;
@@ -2178,6 +2194,7 @@ int pph_launch_assemble_fused(pph_ctx* ctx, int monolithic) {
     fa.A11 = ctx->A11.p; fa.A22 = ctx->A22.p; fa.A12 = ctx->A12.p; fa.A21 = ctx->a21_alias ? nullptr : ctx->A21.p;
   }
   fuse_set_format(fa, mesh.kind, ell ? ctx->S11.ld : 0, ell ? ctx->S11.sym : 0, ell ? ctx->S12.sym : 0);
+  fa.symg = (ell && ctx->S11.sym && ctx->world > 1) ? 1 : 0;
   fa.rhs = ctx->rhs.p; fa.u0 = ctx->u0.p;
   fa.dinv1 = ctx->dinv0[0].p; fa.dinv2 = ctx->dinv0[1].p;
   fa.lam = ctx->lam0.p;

@@ -355,6 +355,7 @@ struct pph_ctx {
   int spmv_kernel = 3;                  // 3: aligned-wide CSR-vector (default); 0,1,2,4..8,10: variants kept for A/B runs
   // operator format of the scalar blocks inside the block solves / Picard sweeps: 1 stencil-ELL (pph_sell.hip), 0 CSR
   int op_format = 1;
+  int sell_sym_slabs = 1;               // ... also on slabs (0: full storage there)
   int sell_sym = 1;                     // stencil-ELL operators store the diagonal and the upper slots only (symmetric blocks)
   int64_t sell_zwalk_min_chunks = 8192; // levels with fewer 512-row chunks keep the plain chunk order
   int sell_zwalk = 4;                   // > 0 (symmetric operators, 3D): a workgroup walks this many consecutive node planes at one in-plane position
@@ -468,6 +469,7 @@ int sell_from_csr(pph_ctx* ctx, const MeshData& mesh, const double* csr_val, Dev
 // symmetric storage is used for operators that are symmetric on the local box: single context (a slab's ghost rows
 // are empty, which breaks the symmetry of the local matrix) and option sell_sym on
 static inline int pph_sell_sym(const pph_ctx* ctx);
+static inline int pph_sell_sym_from_csr(const pph_ctx* ctx);
 int sell_to_csr(pph_ctx* ctx, const MeshData& mesh, const Sell& E, double* csr_val);
 
 // block values + Dirichlet elimination on any level: out = (row constrained) ? I : coefK*K + coefM*M with
@@ -486,7 +488,11 @@ bool mg_pre_smoother(pph_ctx* ctx, int which, int nsmooth, const double** dinv, 
                      bool* launch_only);
 
 static inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
-static inline int pph_sell_sym(const pph_ctx* ctx) { return (ctx->sell_sym && ctx->world == 1) ? 1 : 0; }
+// symmetric storage (diagonal + upper slots); on slabs (sell_sym_slabs) the ghost rows keep their entries towards owned
+// columns so that owned rows find their lower entries (fuse_elim_diag, pph_assemble.hip)
+static inline int pph_sell_sym(const pph_ctx* ctx) { return (ctx->sell_sym && (ctx->world == 1 || ctx->sell_sym_slabs)) ? 1 : 0; }
+// ... for operators converted from CSR values, whose ghost rows are empty: single context only
+static inline int pph_sell_sym_from_csr(const pph_ctx* ctx) { return (ctx->sell_sym && ctx->world == 1) ? 1 : 0; }
 
 // owned index set of a vector of `nrows` entries living on slab geometry g (null: everything)
 static inline Seg pph_owned_seg(const MeshData* g, int64_t nrows) {

@@ -403,7 +403,11 @@ void la_spmv_shift(pph_ctx* ctx, const Csr& A, const double* x, const double* b,
 
 void la_spmv_dot(pph_ctx* ctx, const Csr& A, const double* x, double* y, int slot, int copy_src, int copy_dst) {
   double* part = partials(ctx);
-  const int grid = spmv_dispatch<true>(ctx, A, x, nullptr, y, part);
+  // the sum runs over the owned rows (slabs: ghost rows are empty in CSR / full stencil-ELL storage, but not in symmetric storage)
+  const Seg sg = pph_owned_seg(A.geom, A.nrows);
+  const bool two = sg.len2 > 0;   // field-major mixed vector: two owned segments - only operators with empty ghost rows get here
+  const int grid = spmv_dispatch<true>(ctx, A, x, nullptr, y, part, nullptr, nullptr, false, two ? 0 : sg.off1,
+                                       two ? A.nrows : sg.off1 + sg.len1);
   hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, ctx->stream, part, grid, ctx->scal.p + slot,
                      copy_src >= 0 ? (const double*)(ctx->scal.p + copy_src) : (const double*)nullptr,
                      copy_src >= 0 ? ctx->scal.p + copy_dst : (double*)nullptr);

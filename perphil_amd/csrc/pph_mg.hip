@@ -595,7 +595,7 @@ int mg_setup(pph_ctx* ctx) {
       } else {
         for (int f = 0; f < 2; ++f) {
           pph_launch_scalar_block(ctx, m, L.maskp[f], coefK[f], ctx->b, L.own_val[f].p);
-          if (use_ell) PPH_TRY(sell_from_csr(ctx, m, L.own_val[f].p, L.own_ell[f], &L.ell[f], pph_sell_sym(ctx)));
+          if (use_ell) PPH_TRY(sell_from_csr(ctx, m, L.own_val[f].p, L.own_ell[f], &L.ell[f], pph_sell_sym_from_csr(ctx)));
         }
       }
       L.bc_epoch = ctx->bc_epoch;

@@ -18,7 +18,7 @@ __device__ inline double sell_wave_sum(double v) {
   return v;
 }
 
-// MODE 0: y = A x      1: y = b - A x      2: y = A x and per-workgroup partial sums of x.y
+// MODE 0: y = A x      1: y = b - A x      2: y = A x and per-workgroup partial sums of x.y over the rows [dlo, dhi)
 // MODE 3: y = x + w * dinv .* (b - A x)   (one damped-Jacobi / one-step Chebyshev sweep, out of place)
 // MODE 4: MODE 3 and the dot product b . y over the rows [dlo, dhi) (CG: r . z from the last kernel of the V-cycle)
 // MODE 5: t = b - A x ;  aux += t - y ;  y = t      MODE 6: t = A x ;  aux -= t - y ;  y = t      (the residual
@@ -122,7 +122,7 @@ __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_
     const int64_t r = r0 + i;
     if (MODE == 0) y[r] = acc[i];
     else if (MODE == 1) y[r] = bv[i] - acc[i];
-    else if (MODE == 2) { y[r] = acc[i]; dotacc += acc[i] * xr[i]; }
+    else if (MODE == 2) { y[r] = acc[i]; if (r >= dlo && r < dhi) dotacc += acc[i] * xr[i]; }   // (owned rows: ghost rows of a symmetric slab operator hold no row of this rank)
     else if (MODE >= 5) {
       const double tn = (MODE == 5) ? bv[i] - acc[i] : acc[i];
       const double rn = av[i] + ((MODE == 5) ? 1.0 : -1.0) * (tn - tv[i]);   // k_shift
@@ -287,7 +287,7 @@ int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x,
 template <bool TO_SELL>
 __global__ __launch_bounds__(256) void k_sell_convert(const int64_t* __restrict__ rowptr, double* __restrict__ csr,
                                                       double* __restrict__ ell, int64_t ld, Stencil st, int px, int py,
-                                                      int pz, int64_t n, int sym) {
+                                                      int pz, int64_t n, int sym, int glo, int ghi) {
   const int c0 = st.count / 2;
   for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < n; row += (int64_t)gridDim.x * blockDim.x) {
     const int i = (int)(row % px);
@@ -297,7 +297,12 @@ __global__ __launch_bounds__(256) void k_sell_convert(const int64_t* __restrict_
     for (int s = 0; s < st.count; ++s) {
       const int ii = i + st.d[s][0], jj = j + st.d[s][1], kk = k + st.d[s][2];
       const bool in = ii >= 0 && ii < px && jj >= 0 && jj < py && kk >= 0 && kk < pz;
-      if (!sym) {
+      // CSR export of a symmetric slab operator: ghost rows are empty in CSR (their stored entries are the mirrors of
+      // owned rows' entries, pph_assemble.hip: fuse_elim_diag)
+      const bool ghost_row = !TO_SELL && sym && ((glo && k == 0) || (ghi && k == pz - 1));
+      if (ghost_row) {
+        if (in) csr[o] = 0.0;
+      } else if (!sym) {
         if (TO_SELL) ell[(int64_t)s * ld + row] = in ? csr[o] : 0.0;
         else if (in) csr[o] = ell[(int64_t)s * ld + row];
       } else if (s >= c0) {
@@ -336,14 +341,15 @@ int sell_from_csr(pph_ctx* ctx, const MeshData& mesh, const double* csr_val, Dev
   PPH_TRY(sell_alloc(ctx, mesh, buf, out, sym));
   hipLaunchKernelGGL(k_sell_convert<true>, dim3(sell_grid(mesh.n)), dim3(256), 0, ctx->stream, mesh.rowptr.p,
                      const_cast<double*>(csr_val), buf.p, out->ld, make_stencil(mesh.kind), mesh.px, mesh.py, mesh.pzl,
-                     mesh.n, sym);
+                     mesh.n, sym, 0, 0);
   PPH_HIP(ctx, hipGetLastError());
   return PPH_OK;
 }
 
 int sell_to_csr(pph_ctx* ctx, const MeshData& mesh, const Sell& E, double* csr_val) {
   hipLaunchKernelGGL(k_sell_convert<false>, dim3(sell_grid(mesh.n)), dim3(256), 0, ctx->stream, mesh.rowptr.p, csr_val,
-                     const_cast<double*>(E.val), E.ld, make_stencil(mesh.kind), mesh.px, mesh.py, mesh.pzl, mesh.n, E.sym);
+                     const_cast<double*>(E.val), E.ld, make_stencil(mesh.kind), mesh.px, mesh.py, mesh.pzl, mesh.n, E.sym,
+                     mesh.glo ? 1 : 0, mesh.ghi ? 1 : 0);
   PPH_HIP(ctx, hipGetLastError());
   return PPH_OK;
 }

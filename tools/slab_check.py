@@ -89,6 +89,10 @@ if mono:
 info = solver.step()
 full = solver.gather_solution()
 ok = True
+sym = solver.ctx.timers()["symmetric_storage"]
+if not mono and not sym:
+    print(f"rank {rank}: the slab operators are not in symmetric stencil-ELL storage", flush=True)
+    ok = False
 if serial_split is not None:
     same = np.array_equal(full, serial_split[0]) and (info.iterations, info.inner_iterations) == serial_split[1:]
     nsplit = solver.ctx.timers()["split_products"]
@@ -113,7 +117,8 @@ if rank == 0:
     err = np.abs(full - x1).max() / np.abs(x1).max()
     print(f"world={world} n={args.cells} kind={args.kind} solver={args.solver} pc={args.inner_pc}: sweeps {info.iterations} vs {info1.iterations}, "
           f"inner its {info.inner_iterations} vs {info1.inner_iterations}, residual {info.resnorm:.3e} vs {info1.resnorm:.3e}, "
-          f"max rel diff {err:.3e}, halo calls {solver.comm.halo_calls}, allreduce calls {solver.comm.allreduce_calls}", flush=True)
+          f"max rel diff {err:.3e}, halo calls {solver.comm.halo_calls}, allreduce calls {solver.comm.allreduce_calls}, "
+          f"symmetric storage {sym}", flush=True)
     ok = ok and (err < (1e-9 if not mono else 1e-7) and abs(info.iterations - info1.iterations) <= (0 if not mono else 2) and abs(info.inner_iterations - info1.inner_iterations) <= max(1, info1.inner_iterations // 50)
           and info.converged == 1)
 flag = torch.tensor([1.0 if ok else 0.0])
