@@ -50,6 +50,22 @@ template struct DevBuf<int64_t>;
 template struct DevBuf<uint8_t>;
 template struct DevBuf<unsigned long long>;
 
+// Dirichlet data of one field: the ghost-plane flag (bit 1) of the mask survives, the constrained flag (bit 0) and the
+// boundary values are rebuilt from the (node, value) list (byte stores of different lanes never share a byte)
+__global__ __launch_bounds__(256) void k_dirichlet_clear(uint8_t* __restrict__ mask, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    mask[i] &= (uint8_t)2;
+}
+__global__ __launch_bounds__(256) void k_dirichlet_set(uint8_t* __restrict__ mask, double* __restrict__ g,
+                                                       const int64_t* __restrict__ nodes, const double* __restrict__ vals,
+                                                       int64_t count) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t nd = nodes[i];
+    mask[nd] |= (uint8_t)1;
+    g[nd] = vals[i];
+  }
+}
+
 extern "C" {
 
 const char* pph_last_error(const pph_ctx* ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
@@ -272,22 +288,28 @@ int pph_set_dirichlet(pph_ctx* ctx, int field, const int64_t* nodes, const doubl
     PPH_REQUIRE(ctx, nodes[i] >= 0 && nodes[i] < n, "Dirichlet node %lld outside [0,%lld)", (long long)nodes[i],
                 (long long)n);
   release_system(ctx);  // any assembled system is stale now
-  // mask bytes are written from the host side to avoid byte-granular races between threads
-  std::vector<uint8_t> hmask((size_t)n);
-  std::vector<double> hg((size_t)n, 0.0);
-  PPH_HIP(ctx, hipMemcpyAsync(hmask.data(), ctx->bcmask[field].p, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
-  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  for (int64_t i = 0; i < n; ++i) hmask[(size_t)i] &= (uint8_t)2;
-  for (int64_t i = 0; i < count; ++i) {
-    hmask[(size_t)nodes[i]] |= (uint8_t)1;
-    hg[(size_t)nodes[i]] = vals[i];
+  // only the (node, value) list travels to the device; mask and boundary-value vector are rebuilt there (a node listed
+  // more than once must carry the same value in all its entries)
+  DevBuf<int64_t> dn;
+  DevBuf<double> dv;
+  if (count > 0) {
+    PPH_TRY(dn.alloc(ctx, (size_t)count));
+    PPH_TRY(dv.alloc(ctx, (size_t)count));
+    PPH_HIP(ctx, hipMemcpyAsync(dn.p, nodes, sizeof(int64_t) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
+    PPH_HIP(ctx, hipMemcpyAsync(dv.p, vals, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
   }
-  PPH_HIP(ctx, hipMemcpyAsync(ctx->bcmask[field].p, hmask.data(), (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+  PPH_HIP(ctx, hipMemsetAsync(ctx->g[field].p, 0, sizeof(double) * (size_t)n, ctx->stream));
+  const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  hipLaunchKernelGGL(k_dirichlet_clear, dim3(grid < 1 ? 1 : grid), dim3(256), 0, ctx->stream, ctx->bcmask[field].p, n);
+  if (count > 0) {
+    const int g2 = (int)((count + 255) / 256 < 4096 ? (count + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_dirichlet_set, dim3(g2), dim3(256), 0, ctx->stream, ctx->bcmask[field].p, ctx->g[field].p, dn.p,
+                       dv.p, count);
+  }
   ctx->bc_dirty = true;
   ctx->bc_epoch++;
-  PPH_HIP(ctx, hipMemcpyAsync(ctx->g[field].p, hg.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice,
-                              ctx->stream));
-  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (the caller's arrays and the staging buffers are free again)
+  PPH_HIP(ctx, hipGetLastError());
   return PPH_OK;
 }
 
