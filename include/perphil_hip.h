@@ -248,7 +248,7 @@ int pph_get_timers(pph_ctx* ctx, double* out, int n);
  *   "time_spmv" [0]      1: bracket every SpMV launch of a solve with a HIP event pair on the context stream
  *   "asm_kernel" [2]     multilinear assembly: 0 cell-centred scatter-add (atomics), 1 node-centred gather, 2 fused kernels
  *   "asm_tile" [1]       fused multilinear assembly: 1 single-pass tile kernel on levels of at least
- *                        "asm_tile_min_nodes" [500000] nodes (2: on every level), 0 two-pass (element rows + gather)
+ *                        "asm_tile_min_nodes" [30000] nodes (2: on every level), 0 two-pass (element rows + gather)
  *   "asm_affine" [1]     tile kernel: a cell whose parallel edges are equal vectors gets its constant geometry factor once
  *                        per cell; 0: Jacobian at every Gauss point of every cell (the general pass)
  *   "asm_fused" [1]      the node-centred pass writes the eliminated blocks, lifted right-hand side and smoother

@@ -686,6 +686,26 @@ __device__ __forceinline__ double fuse_elim_coupling(double v, uint8_t rm, uint8
   return ((rm & 1) || (cm_other & 1)) ? 0.0 : v;
 }
 
+// max over the workgroup of the two spectral-bound candidates, then ONE atomic pair per workgroup (and none for zeros):
+// atomics to one word are served one after the other (~50 ns each) - with a pair per WAVE, the 65 k atomics of a 4096 x 512
+// launch cost 0.6 ms at the end of a small level's assembly
+__device__ __forceinline__ void fuse_lam_max(double best1, double best2, unsigned long long* lam) {
+  __shared__ double slam[2][16];
+  for (int o = 32; o > 0; o >>= 1) {
+    const double t1 = __shfl_down(best1, o, 64), t2 = __shfl_down(best2, o, 64);
+    best1 = t1 > best1 ? t1 : best1;
+    best2 = t2 > best2 ? t2 : best2;
+  }
+  if ((threadIdx.x & 63) == 0) { slam[0][threadIdx.x >> 6] = best1; slam[1][threadIdx.x >> 6] = best2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m1 = 0.0, m2 = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { m1 = slam[0][w] > m1 ? slam[0][w] : m1; m2 = slam[1][w] > m2 ? slam[1][w] : m2; }
+    if (m1 > 0.0) atomicMax(lam, (unsigned long long)__double_as_longlong(m1));
+    if (m2 > 0.0) atomicMax(lam + 1, (unsigned long long)__double_as_longlong(m2));
+  }
+}
+
 static void fuse_set_format(FuseArgs& fa, int kind, int64_t ld, int sym = 0, int sym_c = 0) {
   fa.ld = ld;
   for (int q = 0; q < 27; ++q) { fa.slot_of[q] = -1; fa.slot_of_c[q] = -1; }
@@ -901,15 +921,7 @@ __global__ __launch_bounds__(256) void k_gather_rows(const int32_t* __restrict__
     }
   }
   if constexpr (FUSED) {
-    for (int o = 32; o > 0; o >>= 1) {
-      const double t1 = __shfl_down(best1, o, 64), t2 = __shfl_down(best2, o, 64);
-      best1 = t1 > best1 ? t1 : best1;
-      best2 = t2 > best2 ? t2 : best2;
-    }
-    if ((threadIdx.x & 63) == 0) {
-      atomicMax(fa.lam, (unsigned long long)__double_as_longlong(best1));
-      atomicMax(fa.lam + 1, (unsigned long long)__double_as_longlong(best2));
-    }
+    fuse_lam_max(best1, best2, fa.lam);
   }
 }
 
@@ -1080,15 +1092,7 @@ __global__ __launch_bounds__(256) void k_asm_simplex_gather(const int32_t* __res
     }
   }
   if constexpr (FUSED) {
-    for (int o = 32; o > 0; o >>= 1) {
-      const double t1 = __shfl_down(best1, o, 64), t2 = __shfl_down(best2, o, 64);
-      best1 = t1 > best1 ? t1 : best1;
-      best2 = t2 > best2 ? t2 : best2;
-    }
-    if ((threadIdx.x & 63) == 0) {
-      atomicMax(fa.lam, (unsigned long long)__double_as_longlong(best1));
-      atomicMax(fa.lam + 1, (unsigned long long)__double_as_longlong(best2));
-    }
+    fuse_lam_max(best1, best2, fa.lam);
   }
 }
 
@@ -2038,15 +2042,7 @@ __global__ __launch_bounds__(512, 4) void k_asm_tile(const double* __restrict__ 
       }
     }
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    const double t1 = __shfl_down(best1, o, 64), t2 = __shfl_down(best2, o, 64);
-    best1 = t1 > best1 ? t1 : best1;
-    best2 = t2 > best2 ? t2 : best2;
-  }
-  if ((threadIdx.x & 63) == 0) {
-    atomicMax(fa.lam, (unsigned long long)__double_as_longlong(best1));
-    atomicMax(fa.lam + 1, (unsigned long long)__double_as_longlong(best2));
-  }
+  fuse_lam_max(best1, best2, fa.lam);
 }
 
 // Fused assembly of the fine level for multilinear cells (two-pass kernels): element rows, then ONE node-centred

@@ -257,7 +257,7 @@ struct pph_ctx {
   int asm_fused = 1;                    // multilinear two-pass assembly writes the blocks directly (see pph_launch_assemble_fused)
   int asm_affine = 1;                   // tile kernel: cells with equal parallel edges get their (constant) geometry factor once per cell
   int asm_tile_probe = 0;               // timing probe of the tile kernel: 1 stop after phase A, 2 after phase B (wrong results)
-  int64_t asm_tile_min_nodes = 500000;  // levels with fewer nodes use the two-pass kernels (asm_tile 2: tile kernel always)
+  int64_t asm_tile_min_nodes = 30000;   // levels with fewer nodes use the two-pass kernels (asm_tile 2: tile kernel always)
   int asm_tile = 1;                     // multilinear fused assembly: 1 single-pass tile kernel (no element-row buffer), 0 two-pass
   int asm_ring = 0;                     // > 0 (experiment, slower): fused 3D assembly alternates element and node passes over a ring of cell layers, about asm_ring cells per launch
   int asm_keep_km = 0;                  // 1: the fused pass also stores K and M (two more 8 B/nnz streams); 0: they are integrated on demand (pph_get_csr K/M, Darcy projection)
