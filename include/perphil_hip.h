@@ -261,9 +261,6 @@ int pph_get_timers(pph_ctx* ctx, double* out, int n);
  *   "mg_fp32" [0], "mg_replicate_below" [40000 nodes], "coarse_on_device" [1]   multigrid: fp32 copies of the V-cycle
  *                        operators (CSR only), replication threshold of coarse levels on slabs, coarsest solve on the device
  *   "fetch_spin" [1]     reduction results reach the host through a mapped mirror the host polls; 0: D2H copy + sync
- *   "early_publish_max_rows" [5000000]  CG block solves on stencil-ELL operators up to this size (single context): the
- *                        product also sums r.Ap and Ap.Ap and the host tests the NEXT residual norm, formed by one step
- *                        of the recurrence from the true r.r of the previous update, while the update kernel runs; 0: off
  *   "use_graphs" [1]     Krylov iteration bodies / ILU sweeps replayed from captured hipGraphs on small systems (2: always)
  *   "device_scalars" [0] 1: the device-scalar CG branch also over the callback transport (tests)
  *   "halo_overlap" [0]   slabs: products on levels of at least "halo_overlap_min_rows" [200000] rows are launched as

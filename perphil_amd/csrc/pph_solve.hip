@@ -129,14 +129,6 @@ static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double*
     // alpha and beta live in ctx->scal: the host sees p.Ap (breakdown test) and r.r (convergence test) once per
     // iteration, in one copy
     const int sPQ = slot, sRR = slot + 1, sRZn = slot + 2, sRZc = slot + 3;   // p.Ap, r.r, r.z (new), r.z (current)
-    // Early publication (single context, stencil-ELL operator, systems up to early_publish_max_rows): the product also
-    // sums r.Ap and Ap.Ap, and { r.r of the previous update, r.z, p.Ap, r.Ap, Ap.Ap } travel to the host BEFORE the
-    // update kernel runs.  The host forms the next r.r = r.r - 2 alpha r.Ap + alpha^2 Ap.Ap (relative to the true
-    // r.r of the previous update: one step of the recurrence, no accumulation) and decides while the update executes -
-    // the stream does not drain while the host thinks.  sE .. sE + 2 = p.Ap, r.Ap, Ap.Ap.
-    const int sE = slot + 4;
-    const bool early = ctx->world == 1 && A.ell.val != nullptr && n <= ctx->early_publish_max_rows && ctx->fetch_spin &&
-                       !ctx->time_spmv;
     // z = M^-1 r and r.z -> scal[slot_rz]; a fused multigrid cycle delivers the dot product from its last kernel
     auto pc_and_rz = [&](double* zz, int slot_rz, bool x0_ready) {
       if (pre.on) { ctx->mg_dot_slot = slot_rz; ctx->mg_dot_seg = sg; ctx->mg_x0_ready = x0_ready; }
@@ -149,12 +141,6 @@ static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double*
     // the two halves of an iteration around the host's convergence test.  `rotate`: r.z (current) := r.z (new) rides
     // on the final reduction of p.Ap - after the direction update read both, before the CG update reads the current one
     auto half_product = [&](bool rotate) -> int {
-      if (early) {
-        la_spmv_dot3(ctx, A, p, r, q, sE, rotate ? sRZn : -1, sRZc);
-        la_publish(ctx, sRR, 6);   // r.r (previous update), r.z (new, current), p.Ap, r.Ap, Ap.Ap
-        la_cg_update_dev(ctx, x, r, p, q, sRZc, sE, n, sRR, sg, pre.on ? z : nullptr, pre.dinv, pre.w);
-        return PPH_OK;
-      }
       la_spmv_dot(ctx, A, p, q, sPQ, rotate ? sRZn : -1, sRZc);
       PPH_TRY(la_reduce_device(ctx, sPQ, 1));
       // x += alpha p ; r -= alpha q ; r.r (and the next cycle's pre-smoothed first guess into z)
@@ -181,34 +167,24 @@ static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double*
     if (graphable) {
       gk.p[0] = A.ell.val ? (const void*)A.ell.val : (const void*)A.val; gk.p[1] = x; gk.p[2] = r; gk.p[3] = z; gk.p[4] = p;
       gk.p[5] = q; gk.p[6] = pre.dinv; gk.p[7] = pre.w;
-      gk.n = n; gk.slot = slot; gk.epoch = ctx->mg_epoch; gk.tag = pre.tag + (early ? 100000 : 0);
+      gk.n = n; gk.slot = slot; gk.epoch = ctx->mg_epoch; gk.tag = pre.tag;
     }
     int its = 0;
-    double rr_prev = res * res;   // (early publication) r.r the recurrence starts from: host-known before the first update
     while (its < max_it) {
       if (its == 0) {
         PPH_TRY(half_product(false));
-        if (early) PPH_TRY(la_wait_published(ctx));
-        else PPH_TRY(la_fetch_raw(ctx, sPQ, 2));
+        PPH_TRY(la_fetch_raw(ctx, sPQ, 2));
       } else {
         auto body = [&]() -> int {
           PPH_TRY(half_direction());
           PPH_TRY(half_product(true));
-          if (!early) la_publish(ctx, sPQ, 2);
+          la_publish(ctx, sPQ, 2);
           return PPH_OK;
         };
         if (graphable) PPH_TRY(la_run_graph(ctx, gk, body));
         else PPH_TRY(body());
         PPH_TRY(la_wait_published(ctx));
         if (ctx->comm_status != PPH_OK) { ctx->err = ctx->comm_error; return ctx->comm_status; }
-      }
-      if (early) {
-        if (its > 0) rr_prev = ctx->h_scal[sRR];   // the true r.r of the previous update, published with this product
-        const double pqe = ctx->h_scal[sE], rq = ctx->h_scal[sE + 1], qq = ctx->h_scal[sE + 2];
-        const double alpha = ctx->h_scal[sRZc] / pqe;
-        const double rr = rr_prev - 2.0 * alpha * rq + alpha * alpha * qq;
-        ctx->h_scal[sPQ] = pqe;
-        ctx->h_scal[sRR] = (rr > 0.0 || rr != rr) ? rr : 0.0;   // (a NaN stays one: breakdown below)
       }
       const double pq = ctx->h_scal[sPQ];
       res = std::sqrt(ctx->h_scal[sRR]);
