@@ -51,7 +51,7 @@ def test_G4_conditioning_2d(goldens, row):
     assert o.condition_number(s.A[n:, n:]) == pytest.approx(g["cond_micro"], rel=1e-10)
 
 
-@pytest.mark.parametrize("row", [0, 1])
+@pytest.mark.parametrize("row", [0, 1, 2, 3, 4])   # N = 4 .. 12 of the reference's 7 rows (N = 14, 16: minutes of dense SVD)
 def test_G5_conditioning_3d_hex(goldens, row):
     g = goldens["G5_conditioning_3d_hex"][row]
     N = int(g["N"])
