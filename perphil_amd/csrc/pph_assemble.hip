@@ -1502,17 +1502,20 @@ int pph_launch_blocks(pph_ctx* ctx, int monolithic) {
 // Single-pass fused assembly for multilinear cells ("tile" kernel, default): no element-row buffer at all.
 //
 // A workgroup owns a tile of TX x TY x TZ nodes (8 x 4 x 2 hexahedral, 16 x 8 quadrilateral nodes).
-//   A. lane (cell, q) over the (TX+1)(TY+1)(TZ+1) cells touching the tile: Jacobian at Gauss point q from the cell's
-//      vertex coordinates (staged in LDS), its inverse, and the GEOMETRY FACTOR D_q = |det J| J^-1 J^-T (symmetric
-//      DIM x DIM) + the weight |det J| -> LDS (7 doubles per (cell, q) instead of the 8 x 8 x 3 physical gradients);
-//   B. lane (node, corner c) forms row c of K_e and M_e of the node's incident cell c from the factors:
+//   A. geometry factors of the (TX+1)(TY+1)(TZ+1) cells touching the tile, from vertex coordinates staged in LDS:
+//      D = |det J| J^-1 J^-T (symmetric DIM x DIM) + the weight |det J| (7 doubles instead of the 8 x 8 x 3 physical
+//      gradients).  A cell whose parallel edges are equal vectors has a constant Jacobian: one lane per CELL stores
+//      its factor once; any other cell takes the general pass, lane (cell, Gauss point q);
+//   B. lane = node, wave = corner c (kept in a scalar register): row c of K_e and M_e of the node's incident cell c,
 //      K_e[a][b] = sum_q dN_q[a]^T D_q dN_q[b],  M_e[a][b] = sum_q |det J_q| N_q[a] N_q[b]
-//      with the reference gradients of the column vertices as compile-time constants (the row vertex's from a table);
-//      rows -> LDS (over the factors, which are dead by then);
-//   C. the 2^d lanes of a node sum, slot by slot of the node's stencil row and in a fixed order, the entries of the
-//      incident cells' rows that belong to the slot's column, and apply the fused epilogue of k_gather_rows
-//      (Dirichlet elimination, DPP blocks, lifting, 1 / a_ii, spectral bound) before the only global stores.
-// Every element row is formed exactly once (by the lane that consumes it); the Jacobian work is repeated for the
+//      - for a constant factor through the reference-element tables TileRef (6 + 1 multiply-adds per entry) -
+//      rows -> LDS as [corner][column][node] (over the factors, which are dead by then; conflict-free);
+//   C. lane = node, wave = slot group g: the slots g, g + 2^d, ... of the node's stencil row; per slot the entries of
+//      the incident cells' rows that belong to its column are summed in a fixed order (the candidate list of a slot
+//      is wave-uniform) and the fused epilogue of k_gather_rows applied (Dirichlet elimination, DPP blocks, lifting,
+//      1 / a_ii, spectral bound) before the only global stores; the groups' row sums meet in LDS and the group that
+//      holds the diagonal slot finishes the row.
+// Every element row is formed exactly once; the Jacobian work is repeated for the
 // cells on tile faces (2.1 evaluations per cell on average instead of 1), which is what removing the 17 GB
 // element-row round trip of the two-pass kernels costs.  Deterministic, no atomics.  Vertices are addressed in
 // closed form (vertex v of cell (ci,cj,ck) = node (ci + v&1, cj + (v>>1)&1, ck + (v>>2)&1), the cell->dof map of
