@@ -261,6 +261,9 @@ int pph_get_timers(pph_ctx* ctx, double* out, int n);
  *   "mg_fp32" [0], "mg_replicate_below" [40000 nodes], "coarse_on_device" [1]   multigrid: fp32 copies of the V-cycle
  *                        operators (CSR only), replication threshold of coarse levels on slabs, coarsest solve on the device
  *   "fetch_spin" [1]     reduction results reach the host through a mapped mirror the host polls; 0: D2H copy + sync
+ *   "merge_allreduce" [1] slabs, CG block solves on stencil-ELL operators: the product also sums r.Ap and Ap.Ap, and
+ *                        { p.Ap, r.Ap, Ap.Ap, r.r of the previous update } travel in ONE all-reduce; the host forms the next
+ *                        r.r by one step of the recurrence (two scalar all-reduces per iteration instead of three)
  *   "use_graphs" [1]     Krylov iteration bodies / ILU sweeps replayed from captured hipGraphs on small systems (2: always)
  *   "device_scalars" [0] 1: the device-scalar CG branch also over the callback transport (tests)
  *   "halo_overlap" [0]   slabs: products on levels of at least "halo_overlap_min_rows" [200000] rows are launched as

@@ -308,6 +308,7 @@ struct pph_ctx {
   unsigned long long pub_seq = 0;       // fetches published so far
   DevBuf<unsigned long long> pub_ctr;   // device-side count of publications (k_publish), so that a publication can be
                                         // replayed from a graph: the sequence number is not a kernel argument
+  int merge_allreduce = 1;              // slabs: p.Ap, r.Ap, Ap.Ap and the previous r.r in ONE all-reduce per CG iteration (the host forms the next r.r)
   int use_graphs = 1;                   // Krylov iteration bodies are captured into hipGraphs where possible
   std::vector<GraphEntry> graphs;
   uint64_t graph_clock = 0;
@@ -406,6 +407,8 @@ void la_spmv_jacobi(pph_ctx* ctx, const Csr& A, const double* x, const double* b
 // y = A x and partial sums of dot(x, y) -> scal slot
 // (copy_src >= 0: scal[copy_dst] = scal[copy_src] is done by the final reduction's single workgroup)
 void la_spmv_dot(pph_ctx* ctx, const Csr& A, const double* x, double* y, int slot, int copy_src = -1, int copy_dst = -1);
+void la_spmv_dot3(pph_ctx* ctx, const Csr& A, const double* x, const double* r, double* y, int slot, int copy_src = -1,
+                  int copy_dst = -1);   // + r.y and y.y in slot + 1, slot + 2 (stencil-ELL operators)
 // publication of scal[slot .. slot + count) to the host mirror (enqueue) / wait for the last publication
 void la_publish(pph_ctx* ctx, int slot, int count);
 int la_wait_published(pph_ctx* ctx);
@@ -504,3 +507,4 @@ static inline Seg pph_owned_seg(const MeshData* g, int64_t nrows) {
 }
 
 #define PPH_MAX_SCAL 4096  // reduction slots in ctx->scal
+#define PPH_PART_STRIDE 4096  // partial sums per reduction slot behind them (>= the largest grid that writes partial sums)

@@ -10,7 +10,7 @@
 #define RED_BLOCKS 1024        // grid of the BLAS-1 reduction kernels
 #define SPMV_MAX_BLOCKS 2048   // upper limit of the persistent SpMV grid (multiple of 8 XCDs)
 #define SPMV_DEF_BLOCKS 1024   // default grid: 4 workgroups per CU measured fastest (tools/spmv_probe.py)
-#define PART_STRIDE 4096       // partial sums per reduction slot (>= the largest grid that writes partial sums)
+#define PART_STRIDE PPH_PART_STRIDE   // partial sums per reduction slot (pph_internal.h)
 #define PART_SLOTS 32          // concurrent reduction slots (GMRES restart 30 + 2)
 
 static inline double* partials(pph_ctx* ctx) { return ctx->scal.p + PPH_MAX_SCAL; }
@@ -269,7 +269,7 @@ static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const doub
   double bytes_per_nnz = 12.0;
   if (A.ell.val) {
     // stencil-ELL copy of the operator (pph_sell.hip): 8 B per stored entry, no index arrays
-    grid = sell_product(ctx, A, jdinv ? (jdot ? 4 : 3) : (DOT ? 2 : (bvec ? 1 : 0)), x, bvec, jdinv, jw, y,
+    grid = sell_product(ctx, A, jdinv ? (jdot ? 4 : 3) : (DOT ? (bvec ? 7 : 2) : (bvec ? 1 : 0)), x, bvec, jdinv, jw, y,
                         part ? part : partials(ctx), dlo, dhi, nullptr, nullptr, !x_ghosts_valid);
     if (ev) (void)hipEventRecord(ev->e1, ctx->stream);
     // algorithmic bytes: every stored value once, x read once, y written once, plus the epilogue's vectors
@@ -399,6 +399,18 @@ void la_spmv_shift(pph_ctx* ctx, const Csr& A, const double* x, const double* b,
   ctx->spmv_bytes[0] += bytes;
   if (A.nrows >= ctx->mesh.n) { ctx->n_spmv_fine++; ctx->spmv_bytes_fine += bytes; }
   hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, ctx->stream, part, grid, ctx->scal.p + slot);
+}
+
+// y = A x with x.y, r.y and y.y -> scal[slot .. slot + 2] (stencil-ELL operators only): what the host needs to form
+// the NEXT residual norm of a CG iteration, r.r - 2 alpha r.Ap + alpha^2 Ap.Ap, while the update kernel still runs
+void la_spmv_dot3(pph_ctx* ctx, const Csr& A, const double* x, const double* r, double* y, int slot, int copy_src,
+                  int copy_dst) {
+  double* part = partials(ctx);
+  const Seg sg = pph_owned_seg(A.geom, A.nrows);
+  const int grid = spmv_dispatch<true>(ctx, A, x, r, y, part, nullptr, nullptr, false, sg.off1, sg.off1 + sg.len1);
+  hipLaunchKernelGGL(k_reduce_final, dim3(3), dim3(256), 0, ctx->stream, part, grid, ctx->scal.p + slot,
+                     copy_src >= 0 ? (const double*)(ctx->scal.p + copy_src) : (const double*)nullptr,
+                     copy_src >= 0 ? ctx->scal.p + copy_dst : (double*)nullptr);
 }
 
 void la_spmv_dot(pph_ctx* ctx, const Csr& A, const double* x, double* y, int slot, int copy_src, int copy_dst) {

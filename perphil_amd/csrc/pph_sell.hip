@@ -24,7 +24,9 @@ __device__ inline double sell_wave_sum(double v) {
 // MODE 5: t = b - A x ;  aux += t - y ;  y = t      MODE 6: t = A x ;  aux -= t - y ;  y = t      (the residual
 //         bookkeeping of the Picard sweeps, k_shift, in the epilogue of the coupling product) and the sum of
 //         aux^2 over the rows [dlo, dhi); z0 != null: also z0 = dinv .* aux * w (pre-smoothing of the new residual)
-// MODE 2 / 4 / 5 / 6 write one partial sum per workgroup to part[blockIdx.x]; the caller finishes the sum.
+// MODE 7: MODE 2 and, for the same rows, the sums b.y and y.y to part[pstride + blockIdx.x], part[2 pstride + blockIdx.x]
+//         (CG: with b = r the host can form r.r of the NEXT residual from p.Ap, r.Ap, Ap.Ap before the update has run)
+// MODE 2 / 4 / 5 / 6 / 7 write one partial sum per workgroup to part[blockIdx.x]; the caller finishes the sum.
 // One thread owns RPT consecutive rows; a workgroup a chunk of 256 RPT rows.  Chunks are dealt to the XCDs in groups
 // of `group` consecutive chunks (group 1 = plain grid-stride order); workgroups with equal blockIdx % 8 share an XCD.
 template <int KIND, int MODE, int RPT, bool CLAMP, bool SYM = false>
@@ -32,7 +34,7 @@ __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_
                                           const double* __restrict__ b, const double* __restrict__ dinv, double w,
                                           double* __restrict__ y, double* __restrict__ aux, double* __restrict__ z0,
                                           int64_t n, int px, int64_t pxy, int64_t r0, double& dotacc, int64_t dlo,
-                                          int64_t dhi) {
+                                          int64_t dhi, double* dotx = nullptr) {
   using ST = SellSt<KIND>;
   double acc[RPT];
   double bv[RPT], xr[RPT], dv[RPT], tv[RPT], av[RPT];
@@ -43,10 +45,10 @@ __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_
     act[i] = !CLAMP || (r0 + i < n);
     // operands of the epilogue are requested before the matrix stream, not after the sums
     if (act[i]) {
-      if (MODE == 1 || (MODE >= 3 && MODE <= 5)) bv[i] = b[r0 + i];
-      if (MODE >= 2 && MODE <= 4) xr[i] = x[r0 + i];
+      if (MODE == 1 || (MODE >= 3 && MODE <= 5) || MODE == 7) bv[i] = b[r0 + i];
+      if ((MODE >= 2 && MODE <= 4) || MODE == 7) xr[i] = x[r0 + i];
       if (MODE == 3 || MODE == 4) dv[i] = dinv[r0 + i];
-      if (MODE >= 5) { tv[i] = y[r0 + i]; av[i] = aux[r0 + i]; if (z0) dv[i] = dinv[r0 + i]; }
+      if (MODE == 5 || MODE == 6) { tv[i] = y[r0 + i]; av[i] = aux[r0 + i]; if (z0) dv[i] = dinv[r0 + i]; }
     }
   }
   int slot = 0;
@@ -123,7 +125,10 @@ __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_
     if (MODE == 0) y[r] = acc[i];
     else if (MODE == 1) y[r] = bv[i] - acc[i];
     else if (MODE == 2) { y[r] = acc[i]; if (r >= dlo && r < dhi) dotacc += acc[i] * xr[i]; }   // (owned rows: ghost rows of a symmetric slab operator hold no row of this rank)
-    else if (MODE >= 5) {
+    else if (MODE == 7) {
+      y[r] = acc[i];
+      if (r >= dlo && r < dhi) { dotacc += acc[i] * xr[i]; dotx[0] += acc[i] * bv[i]; dotx[1] += acc[i] * acc[i]; }
+    } else if (MODE >= 5) {
       const double tn = (MODE == 5) ? bv[i] - acc[i] : acc[i];
       const double rn = av[i] + ((MODE == 5) ? 1.0 : -1.0) * (tn - tv[i]);   // k_shift
       aux[r] = rn;
@@ -150,8 +155,9 @@ __global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ va
   constexpr int CH = 256 * RPT;
   const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, bpx = gridDim.x >> 3;   // launcher keeps gridDim.x a multiple of 8
   // the smoother weight lives in device memory (refreshed per assembly) so that captured graphs survive a re-assembly
-  const double w = (MODE == 3 || MODE == 4 || (MODE >= 5 && z0)) ? *wp : 0.0;
+  const double w = (MODE == 3 || MODE == 4 || ((MODE == 5 || MODE == 6) && z0)) ? *wp : 0.0;
   double dotacc = 0.0;
+  double dotx[2] = {0.0, 0.0};
   // Chunk order.  zwalk = Z > 0 (3D): a workgroup takes Z work items in a row that sit at the same in-plane position
   // of Z consecutive node planes (chunk, chunk + P, ..., P = chunks per plane rounded: the rows shift by pxy - P CH,
   // one row at 256^3).  The x lines and - with symmetric storage - the operator values a plane reads at offset
@@ -196,9 +202,9 @@ __global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ va
     // a chunk whose rows and x window lie inside [0, n) needs no index clamps and no row masks (all but the first
     // and last few chunks)
     if (c0 >= halo && c0 + CH + halo <= n)
-      sell_rows<KIND, MODE, RPT, false, SYM>(val, ld, x, b, dinv, w, y, aux, z0, n, px, pxy, r0, dotacc, dlo, dhi);
+      sell_rows<KIND, MODE, RPT, false, SYM>(val, ld, x, b, dinv, w, y, aux, z0, n, px, pxy, r0, dotacc, dlo, dhi, dotx);
     else
-      sell_rows<KIND, MODE, RPT, true, SYM>(val, ld, x, b, dinv, w, y, aux, z0, n, px, pxy, r0, dotacc, dlo, dhi);
+      sell_rows<KIND, MODE, RPT, true, SYM>(val, ld, x, b, dinv, w, y, aux, z0, n, px, pxy, r0, dotacc, dlo, dhi, dotx);
   }
   if (MODE == 2 || MODE >= 4) {
     __shared__ double lds[4];
@@ -206,6 +212,16 @@ __global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ va
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = dotacc;
     __syncthreads();
     if (threadIdx.x == 0) part[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+    if (MODE == 7) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        __syncthreads();
+        const double t = sell_wave_sum(dotx[k]);
+        if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) part[(int64_t)(k + 1) * PPH_PART_STRIDE + blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+      }
+    }
   }
 }
 
@@ -230,7 +246,8 @@ static void sell_launch_mode(pph_ctx* ctx, int mode, int grid, const Sell& E, co
       case 3: PPH_SELL_GOS(3); break;
       case 4: PPH_SELL_GOS(4); break;
       case 5: PPH_SELL_GOS(5); break;
-      default: PPH_SELL_GOS(6); break;
+      case 6: PPH_SELL_GOS(6); break;
+      default: PPH_SELL_GOS(7); break;
     }
 #undef PPH_SELL_GOS
     return;
@@ -242,7 +259,8 @@ static void sell_launch_mode(pph_ctx* ctx, int mode, int grid, const Sell& E, co
     case 3: PPH_SELL_GO(3); break;
     case 4: PPH_SELL_GO(4); break;
     case 5: PPH_SELL_GO(5); break;
-    default: PPH_SELL_GO(6); break;
+    case 6: PPH_SELL_GO(6); break;
+    default: PPH_SELL_GO(7); break;
   }
 #undef PPH_SELL_GO
 }

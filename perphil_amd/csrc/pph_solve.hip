@@ -129,6 +129,13 @@ static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double*
     // alpha and beta live in ctx->scal: the host sees p.Ap (breakdown test) and r.r (convergence test) once per
     // iteration, in one copy
     const int sPQ = slot, sRR = slot + 1, sRZn = slot + 2, sRZc = slot + 3;   // p.Ap, r.r, r.z (new), r.z (current)
+    // Slabs: ONE all-reduce behind the product instead of one for p.Ap and one for r.r (`merge_allreduce`, stencil-ELL
+    // operators).  The product also sums r.Ap and Ap.Ap (mode 7); { p.Ap, r.Ap, Ap.Ap, local r.r of the PREVIOUS update }
+    // sit in four consecutive slots and are summed over the ranks together; the host forms the new
+    // r.r = r.r_prev - 2 alpha r.Ap + alpha^2 Ap.Ap - one step of the recurrence from a true value, no accumulation of
+    // rounding - so an iteration costs two scalar all-reduces (r.z; this one) instead of three.
+    const int sE = slot + 4;   // sE .. sE + 2 = p.Ap, r.Ap, Ap.Ap ; sE + 3 = r.r of the previous update
+    const bool merged = ctx->merge_allreduce && ctx->world > 1 && !ctx->comm_suspended && A.ell.val != nullptr;
     // z = M^-1 r and r.z -> scal[slot_rz]; a fused multigrid cycle delivers the dot product from its last kernel
     auto pc_and_rz = [&](double* zz, int slot_rz, bool x0_ready) {
       if (pre.on) { ctx->mg_dot_slot = slot_rz; ctx->mg_dot_seg = sg; ctx->mg_x0_ready = x0_ready; }
@@ -141,6 +148,12 @@ static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double*
     // the two halves of an iteration around the host's convergence test.  `rotate`: r.z (current) := r.z (new) rides
     // on the final reduction of p.Ap - after the direction update read both, before the CG update reads the current one
     auto half_product = [&](bool rotate) -> int {
+      if (merged) {
+        la_spmv_dot3(ctx, A, p, r, q, sE, rotate ? sRZn : -1, sRZc);
+        PPH_TRY(la_reduce_device(ctx, sE, 4));
+        la_cg_update_dev(ctx, x, r, p, q, sRZc, sE, n, sE + 3, sg, pre.on ? z : nullptr, pre.dinv, pre.w);   // (its r.r: local, summed with the next product's)
+        return PPH_OK;
+      }
       la_spmv_dot(ctx, A, p, q, sPQ, rotate ? sRZn : -1, sRZc);
       PPH_TRY(la_reduce_device(ctx, sPQ, 1));
       // x += alpha p ; r -= alpha q ; r.r (and the next cycle's pre-smoothed first guess into z)
@@ -170,21 +183,32 @@ static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double*
       gk.n = n; gk.slot = slot; gk.epoch = ctx->mg_epoch; gk.tag = pre.tag;
     }
     int its = 0;
+    double rr_prev = res * res;   // (merged all-reduce) r.r the recurrence starts from: host-known before the first update
     while (its < max_it) {
       if (its == 0) {
         PPH_TRY(half_product(false));
-        PPH_TRY(la_fetch_raw(ctx, sPQ, 2));
+        if (merged) PPH_TRY(la_fetch_raw(ctx, sRZc, 5));   // r.z (current), p.Ap, r.Ap, Ap.Ap, r.r of the previous update
+        else PPH_TRY(la_fetch_raw(ctx, sPQ, 2));
       } else {
         auto body = [&]() -> int {
           PPH_TRY(half_direction());
           PPH_TRY(half_product(true));
-          la_publish(ctx, sPQ, 2);
+          if (merged) la_publish(ctx, sRZc, 5);
+          else la_publish(ctx, sPQ, 2);
           return PPH_OK;
         };
         if (graphable) PPH_TRY(la_run_graph(ctx, gk, body));
         else PPH_TRY(body());
         PPH_TRY(la_wait_published(ctx));
         if (ctx->comm_status != PPH_OK) { ctx->err = ctx->comm_error; return ctx->comm_status; }
+      }
+      if (merged) {
+        if (its > 0) rr_prev = ctx->h_scal[sE + 3];   // the true r.r of the previous update, summed with this product's sums
+        const double pqe = ctx->h_scal[sE], rq = ctx->h_scal[sE + 1], qq = ctx->h_scal[sE + 2];
+        const double alpha = ctx->h_scal[sRZc] / pqe;
+        const double rr = rr_prev - 2.0 * alpha * rq + alpha * alpha * qq;
+        ctx->h_scal[sPQ] = pqe;
+        ctx->h_scal[sRR] = (rr > 0.0 || rr != rr) ? rr : 0.0;   // (a NaN stays one: breakdown below)
       }
       const double pq = ctx->h_scal[sPQ];
       res = std::sqrt(ctx->h_scal[sRR]);

@@ -22,6 +22,7 @@ ap.add_argument("--device-scalars", action="store_true",
 ap.add_argument("--halo-overlap", action="store_true",
                 help="products of large levels are split into interior and boundary rows, the halo exchange overlapping "
                      "the interior rows: must equal the same split without overlap bit for bit (and the single context as usual)")
+ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE", help="extra pph_set_option settings on the slab contexts")
 ap.add_argument("--fail-halo-after", type=int, default=-1,
                 help="every rank's halo callback fails from this call on: the solve must return a COMM error, not a result")
 args = ap.parse_args()
@@ -48,6 +49,8 @@ else:
     solver = SlabSolver(args.cells, world, rank, device, k1, k2, beta, mu, kind=kind, inner_pc=pc)
 if args.device_scalars:
     solver.ctx.set_option("device_scalars", 1)
+for kv in args.set:
+    solver.ctx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
 if args.fail_halo_after >= 0:
     solver.comm.fail_halo_after = args.fail_halo_after
     try:
