@@ -264,7 +264,8 @@ int pph_get_timers(pph_ctx* ctx, double* out, int n);
  *   "merge_allreduce" [1] slabs, CG block solves on stencil-ELL operators: the product also sums r.Ap and Ap.Ap, and
  *                        { p.Ap, r.Ap, Ap.Ap, r.r of the previous update } travel in ONE all-reduce; the host forms the next
  *                        r.r by one step of the recurrence (two scalar all-reduces per iteration instead of three)
- *   "use_graphs" [1]     Krylov iteration bodies / ILU sweeps replayed from captured hipGraphs on small systems (2: always)
+ *   "use_graphs" [1]     launch sequences replayed from captured hipGraphs: ILU(0) sweeps, the launch-only Picard sweeps of
+ *                        inner_norm 2, and CG iteration bodies on systems of up to "graph_cg_max_rows" [0] rows (2: always)
  *   "device_scalars" [0] 1: the device-scalar CG branch also over the callback transport (tests)
  *   "halo_overlap" [0]   slabs: products on levels of at least "halo_overlap_min_rows" [200000] rows are launched as
  *                        interior rows + boundary rows; 1: the exchange of the operand's ghost planes runs on a second

@@ -577,6 +577,7 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
     return PPH_OK;
   }
   if (!strcmp(name, "sell_zwalk_min_chunks")) { ctx->sell_zwalk_min_chunks = (int64_t)value; return PPH_OK; }
+  if (!strcmp(name, "graph_cg_max_rows")) { ctx->graph_cg_max_rows = (int64_t)value; la_release_graphs(ctx); return PPH_OK; }
   if (!strcmp(name, "merge_allreduce")) { ctx->merge_allreduce = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "halo_overlap")) { ctx->halo_overlap = (value == 2.0) ? 2 : (value != 0.0 ? 1 : 0); la_release_graphs(ctx); return PPH_OK; }
   if (!strcmp(name, "halo_overlap_min_rows")) { ctx->halo_overlap_min_rows = (int64_t)value; la_release_graphs(ctx); return PPH_OK; }

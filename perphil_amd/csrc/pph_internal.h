@@ -309,6 +309,7 @@ struct pph_ctx {
   DevBuf<unsigned long long> pub_ctr;   // device-side count of publications (k_publish), so that a publication can be
                                         // replayed from a graph: the sequence number is not a kernel argument
   int merge_allreduce = 1;              // slabs: p.Ap, r.Ap, Ap.Ap and the previous r.r in ONE all-reduce per CG iteration (the host forms the next r.r)
+  int64_t graph_cg_max_rows = 0;        // CG iteration bodies are replayed from graphs on systems up to this size (0: never - eager is as fast or faster)
   int use_graphs = 1;                   // Krylov iteration bodies are captured into hipGraphs where possible
   std::vector<GraphEntry> graphs;
   uint64_t graph_clock = 0;

@@ -174,8 +174,10 @@ static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double*
     // is host-bound; the captured body replays in one call.  Single context, fused multigrid cycle only.
     GraphKey gk;
     // (measured: a replay starts 38 us after the host's decision, an eager launch 17 us - the replay pays off only
-    // where the iteration's kernels are shorter than the host's launch rate, i.e. on small systems; use_graphs 2: always)
-    const bool graphable = ctx->use_graphs && (ctx->use_graphs == 2 || n <= 600000) && pre.on && pre.launch_only &&
+    // where the iteration's kernels are shorter than the host's launch rate.  With the fused cycle and its on-chip tail
+    // that is no longer the case at any size measured: 32^3 equal, 64^3 3.45 ms replayed vs 3.15 ms eager, 96^3 equal -
+    // graph_cg_max_rows defaults to 0 (off); use_graphs 2: always)
+    const bool graphable = ctx->use_graphs && (ctx->use_graphs == 2 || n <= ctx->graph_cg_max_rows) && pre.on && pre.launch_only &&
                            ctx->world == 1 && !ctx->time_spmv && ctx->fetch_spin;
     if (graphable) {
       gk.p[0] = A.ell.val ? (const void*)A.ell.val : (const void*)A.val; gk.p[1] = x; gk.p[2] = r; gk.p[3] = z; gk.p[4] = p;
@@ -786,7 +788,7 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
           return PPH_OK;
         };
         const int its_before = bs.total_its;
-        if (ctx->use_graphs) {
+        if (ctx->use_graphs == 2) {   // (measured after the kernel work of round 2: the eager sweep is faster, 64^3 2.65 vs 2.80 ms - the host runs ahead of a launch-only sequence anyway; a replay only adds its start-up latency)
           GraphKey gk;
           gk.p[0] = du; gk.p[1] = R0; gk.p[2] = R1; gk.p[3] = t12; gk.p[4] = tn; gk.p[5] = rhs1; gk.p[6] = pb;
           gk.p[7] = bs.A[0].ell.val ? (const void*)bs.A[0].ell.val : (const void*)bs.A[0].val;
