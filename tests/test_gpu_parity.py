@@ -997,6 +997,23 @@ def test_option_paths_agree(gpu_ctx_factory):
 
 
 @pytest.mark.gpu
+def test_launch_only_sweeps_eager_equals_graph_replay(gpu_ctx_factory):
+    """Block solves without a convergence test (inner_norm 2): the warm sweeps are a pure launch sequence, run eagerly by
+    default and replayed from a captured graph with use_graphs 2 - same sweeps, iterations and solution bit for bit."""
+    f = _ffi()
+    out = []
+    for graphs in (1, 2):
+        ctx, om, osys = _setup(gpu_ctx_factory, 3, o.CELL_HEX, 16, 16, 16)
+        ctx.set_option("use_graphs", graphs)
+        xs, info, _ = ctx.solve(_cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_MG, inner_norm=2, inner_max_it=1,
+                                     mg_smooth=1, picard_rtol=1e-9))
+        assert info.converged
+        out.append((xs, info.iterations, info.inner_iterations))
+    assert out[0][1:] == out[1][1:]
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dim,kind,ns", [(2, o.CELL_TRI, (8, 16)), (3, o.CELL_TET, (6, 12))])
 def test_error_norms_on_simplices(gpu_ctx_factory, dim, kind, ns):
     """l2_error / h1_seminorm_error on P1 triangles and Kuhn tetrahedra: device quadrature against the oracle's
