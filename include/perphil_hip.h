@@ -236,11 +236,11 @@ int pph_get_timers(pph_ctx* ctx, double* out, int n);
  *   "op_format" [1]      operator format of the scalar blocks inside block solves / Picard sweeps: 1 stencil-ELL
  *                        (values only, val[slot][row]; written directly by the fused assembly), 0 CSR.  pph_get_csr /
  *                        pph_spmv export CSR either way (converted on demand).
- *   "sell_rpt" [2], "sell_blocks" [2048], "sell_group" [1]   stencil-ELL SpMV: rows per thread, grid cap, XCD chunk group
+ *   "sell_rpt" [2], "sell_blocks" [4096; z-walk: one per CU], "sell_group" [1]   stencil-ELL SpMV: rows per thread, grid cap, XCD chunk group
  *   "sell_sym" [1]       symmetric blocks store the diagonal and the upper stencil slots only; "sell_sym_slabs" [1]: also
  *                        on slabs, where ghost rows then keep their entries towards owned columns (the mirrors of the
  *                        owned rows' lower entries; operators converted from CSR values stay in full storage there)
- *   "sell_zwalk" [4], "sell_zwalk_min_chunks" [8192], "sell_xmap" [1]   symmetric product on large 3D levels: a workgroup
+ *   "sell_zwalk" [4], "sell_zwalk_min_chunks" [5500], "sell_xmap" [1]   symmetric product on large 3D levels: a workgroup
  *                        walks this many node planes at one in-plane position (>= 1000: a balanced share of a whole z
  *                        column); the in-plane positions of one XCD's workgroups are consecutive
  *   "spmv_kernel" [3]    CSR SpMV variant; values other than 3 need a library built with EXPERIMENTS=1

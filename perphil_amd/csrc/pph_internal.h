@@ -359,7 +359,7 @@ struct pph_ctx {
   int op_format = 1;
   int sell_sym_slabs = 1;               // ... also on slabs (0: full storage there)
   int sell_sym = 1;                     // stencil-ELL operators store the diagonal and the upper slots only (symmetric blocks)
-  int64_t sell_zwalk_min_chunks = 8192; // levels with fewer 512-row chunks keep the plain chunk order
+  int64_t sell_zwalk_min_chunks = 5500; // levels with fewer 512-row chunks keep the plain chunk order (measured: 128^3 = 4200 chunks loses 4 % with the z-walk, 144^3 = 5950 equal, 160^3 gains 8 %, 192^3 4 %, 256^3 20 %)
   int sell_zwalk = 4;                   // > 0 (symmetric operators, 3D): a workgroup walks this many consecutive node planes at one in-plane position
   int sell_xmap = 1;                    // z-walk: consecutive in-plane positions on one XCD
   int sell_rpt = 2, sell_blocks = 0, sell_group = 0;   // SELL SpMV tuning: rows per thread, grid cap, XCD chunk group

@@ -274,13 +274,13 @@ int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x,
   const int64_t chunk0 = cend < 0 ? 0 : cbeg;
   const int64_t nchunks = cend < 0 ? nchunks_all : cend - cbeg;
   if (nchunks <= 0) return 0;
-  // grid: persistent, 2048 workgroups; with the z-walk order of symmetric operators ONE workgroup per CU: the value a
+  // grid: persistent, up to 4096 workgroups (128^3: 9.38 ms per step against 9.60 with 2048); with the z-walk order of symmetric operators ONE workgroup per CU: the value a
   // plane reads a second time must still be in the XCD's 4 MB L2, and every resident workgroup streams 57 KB per plane
   // step (measured on the 256^3 block: 0.58 ms plain order, 0.51 ms z-walk with 4096 workgroups, 0.47 ms with 256;
   // profiles/r02_sell_sym_probe_256.txt, r02_sell_sym_probe2_256.txt)
   const bool zw = E.sym && E.pz > 2 && ctx->sell_zwalk > 0 && chunk0 == 0 && nchunks >= ctx->sell_zwalk_min_chunks;   // (smaller levels: too few chunks per workgroup)
   int cap = (ctx->sell_blocks >= 8 && ctx->sell_blocks <= 8192) ? (ctx->sell_blocks / 8) * 8
-                                                                 : (zw ? ((ctx->num_cus + 7) / 8) * 8 : 2048);
+                                                                 : (zw ? ((ctx->num_cus + 7) / 8) * 8 : 4096);
   if ((mode == 2 || mode >= 4) && cap > 4096) cap = 4096;   // one partial sum per workgroup (PART_STRIDE of pph_la.hip)
   int64_t g = nchunks < cap ? nchunks : cap;
   g = ((g + 7) / 8) * 8;
