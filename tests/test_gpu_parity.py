@@ -724,8 +724,11 @@ def test_config5_256cubed_tets_gmres_fieldsplit(gpu_ctx_factory, goldens):
 @pytest.mark.gpu
 @pytest.mark.parametrize("hexa,N,norm,red", [(True, 96, 0, 1e-2), (False, 48, 0, 1e-2), (True, 96, 1, 1e-1), (False, 48, 1, 1e-1),
                                              (True, 40, 1, 3e-2),
+                                             # BASELINE config 3's size with the bench's algorithm (tile assembly on every
+                                             # level down to 33^3, 2.1 M rows per block: 57 M entries compared per block)
+                                             (True, 128, 1, 1e-1),
                                              # no inner convergence test (ksp_norm_type none): exactly `red` CG iterations
-                                             # per block solve, sweeps replayed from a graph
+                                             # per block solve (launch-only sweeps)
                                              (True, 96, 2, 1), (False, 48, 2, 1), (True, 40, 2, 2), (True, 64, 2, 3)])
 def test_hip_matches_cpu_port_mid_size(gpu_ctx_factory, hexa, N, norm, red):
     """HIP path vs the C/OpenMP restatement (oracle/dpp_cpu.c) at sizes the NumPy oracle cannot reach in seconds:
