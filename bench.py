@@ -72,7 +72,7 @@ def _mms_boundary_np(N, k1, k2, beta, mu):
     return idx[on], g1, g2
 
 
-def _cpu_port_run(N, threads, k1, k2, beta, mu, smooth, reduction, inner_rtol, inner_norm):
+def _cpu_port_run(N, threads, k1, k2, beta, mu, smooth, reduction, inner_rtol, inner_norm, keep=None):
     """One step (assemble + multigrid setup + inexact Picard) of the C/OpenMP restatement; seconds, sweeps, its."""
     from oracle import dpp_cpu as cpu
 
@@ -86,9 +86,11 @@ def _cpu_port_run(N, threads, k1, k2, beta, mu, smooth, reduction, inner_rtol, i
         t0 = time.perf_counter()
         S.assemble(k1, k2, beta, mu)
         S.mg_setup()
-        _, sweeps, inner, _ = S.picard(pc=cpu.PC_MG, inner_rtol=inner_rtol, reduction=reduction, smooth=smooth, rtol=1e-8,
-                                       atol=1e-12, max_it=100, inner_norm=inner_norm)
+        x, sweeps, inner, res = S.picard(pc=cpu.PC_MG, inner_rtol=inner_rtol, reduction=reduction, smooth=smooth, rtol=1e-8,
+                                         atol=1e-12, max_it=100, inner_norm=inner_norm)
         t = time.perf_counter() - t0
+    if keep is not None:      # what main() compares the GPU step with (parity_vs_port)
+        keep.update({"cells": N, "sweeps": int(sweeps), "inner": int(inner), "final_residual": float(res), "x": x})
     spmv_gbs = (12.0 * S.nnz + 20.0 * S.n) / S.spmv_seconds(cpu.MAT_A11, 10) / 1e9
     dofs = 2 * S.n
     scipy_gbs = None
@@ -124,14 +126,14 @@ def host_cores(cap=16):
     return max(1, min(n, cap))
 
 
-def cpu_baseline(sample_n, k1, k2, beta, mu, smooth=1, reduction=1e-1, inner_rtol=1e-10, threads=0, inner_norm=1):
+def cpu_baseline(sample_n, k1, k2, beta, mu, smooth=1, reduction=1e-1, inner_rtol=1e-10, threads=0, inner_norm=1, keep=None):
     """The CPU port (oracle/dpp_cpu.c: C99 + OpenMP restatement of the same algorithm - assembly, multigrid
     setup, inexact Picard with multigrid-CG block solves) timed on the host: all available cores on a
     `sample_n`^3 cube (bounded sample of the 256^3 workload) and one core on 64^3; returns DoF/s."""
     cores = threads if threads > 0 else host_cores()
     small = min(64, sample_n)
     t1, sw1, in1, dofs1, gbs1, scipy_gbs = _cpu_port_run(small, 1, k1, k2, beta, mu, smooth, reduction, inner_rtol, inner_norm)
-    t, sw, inner, dofs, gbs, _ = _cpu_port_run(small, cores, k1, k2, beta, mu, smooth, reduction, inner_rtol, inner_norm)
+    t, sw, inner, dofs, gbs, _ = _cpu_port_run(small, cores, k1, k2, beta, mu, smooth, reduction, inner_rtol, inner_norm, keep)
     # largest cube up to sample_n whose predicted time stays within a minute and whose ~2.3 KB per node fit in memory
     try:
         import psutil
@@ -146,7 +148,7 @@ def cpu_baseline(sample_n, k1, k2, beta, mu, smooth=1, reduction=1e-1, inner_rto
             break
         cand //= 2
     if pick > small:
-        t, sw, inner, dofs, gbs, _ = _cpu_port_run(pick, cores, k1, k2, beta, mu, smooth, reduction, inner_rtol, inner_norm)
+        t, sw, inner, dofs, gbs, _ = _cpu_port_run(pick, cores, k1, k2, beta, mu, smooth, reduction, inner_rtol, inner_norm, keep)
     sample_n = pick
     return {"value": dofs / t, "unit": "DoF/s", "cores": cores, "kind": "port",
             "single_core_value": dofs1 / t1, "spmv_gbs": round(gbs, 1), "single_core_spmv_gbs": round(gbs1, 1),
@@ -156,6 +158,51 @@ def cpu_baseline(sample_n, k1, k2, beta, mu, smooth=1, reduction=1e-1, inner_rto
                       f"{'unpreconditioned' if inner_norm else 'preconditioned'} residual) in "
                       f"C/OpenMP on {cores} threads, {t:.1f} s (second step, buffers warm); single_core_value: {small}^3 on 1 thread, "
                       f"{t1:.1f} s"}
+
+
+def self_launch(nproc):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N bench.py <same arguments>` as a child process (one rank per GPU, rendezvous on 127.0.0.1 at a
+    free port), pass its output through and return its exit code."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def parity_vs_port(ctx_solution, info, keep):
+    """GPU step against the C/OpenMP port on the same problem (reference
+    src/perphil/experiments/petsc_profiling_3d.py:147-150 reads iterations / residual off one more solve the same
+    way): sweeps and inner iterations equal, final residual to 1e-3 relative, the solution to 1e-9 of its largest
+    entry over ALL entries, its 2-norm to 1e-9, and 8 probe nodes per field listed for the record."""
+    xg, xp = ctx_solution, keep["x"]
+    n = xp.size // 2
+    px = round(n ** (1.0 / 3.0))
+    q = [px // 4, (3 * px) // 4]
+    probes = [i + px * (j + px * k) for k in q for j in q for i in q]
+    idx = np.array(probes + [n + v for v in probes])
+    scale = float(np.abs(xp).max())
+    dmax = float(np.abs(xg - xp).max()) / scale
+    ng, npn = float(np.linalg.norm(xg)), float(np.linalg.norm(xp))
+    res_rel = abs(info.resnorm - keep["final_residual"]) / max(abs(keep["final_residual"]), 1e-300)
+    ok = (int(info.iterations) == keep["sweeps"] and int(info.inner_iterations) == keep["inner"] and res_rel <= 1e-3
+          and dmax <= 1e-9 and abs(ng - npn) <= 1e-9 * npn)
+    return {"ok": bool(ok), "cells": int(keep["cells"]),
+            "sweeps": [int(info.iterations), keep["sweeps"]], "inner_cg_iterations": [int(info.inner_iterations), keep["inner"]],
+            "final_residual": [float(info.resnorm), keep["final_residual"]], "final_residual_rel_diff": res_rel,
+            "solution_norm2": [ng, npn], "solution_max_abs_diff_over_max_abs": dmax,
+            "probe_nodes": [int(v) for v in idx], "probe_gpu": [float(v) for v in xg[idx]],
+            "probe_port": [float(v) for v in xp[idx]],
+            "tolerances": "sweeps / iterations equal, residual 1e-3 rel, solution 1e-9 of max |x| (all entries), norm 1e-9 rel; "
+                          "each pair is [gpu, port]"}
 
 
 def main():
@@ -187,6 +234,11 @@ def main():
                     help="N > 1: continue on the torch.distributed callback transport when the RCCL transport fails its "
                          "self-test (default: exit non-zero - no silent downgrade of a scaling run)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started like the 1-GPU run (`python bench.py --gpus N`): launch the ranks as a CHILD process - nothing in this
+        # process has imported torch or touched a GPU yet - and relay rank 0's JSON line and the exit code
+        raise SystemExit(self_launch(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -278,6 +330,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     tm = ctx.timers()
+    # the timed steps' solution, for the parity check against the port below (272 MB at 256^3; outside the timed region)
+    x_gpu = ctx.solution() if (world == 1 and not args.no_cpu_baseline) else None
+    info_timed = info
 
     # ---- roofline of the dominant kernel: one more (untimed) step with an event pair around every
     # SpMV launch on the solver's stream; bytes are algorithmic (stencil-ELL: 8 S nrows + 16 nrows per
@@ -414,17 +469,37 @@ def main():
         },
         "roofline": roofline,
     }
+    parity_failed = False
     if rank == 0 and not args.no_cpu_baseline and world == 1:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, k1, k2, beta, mu, args.smooth, args.inner_reduction,
-                                           args.inner_rtol, args.cpu_threads, args.inner_norm)
+        keep = {}
+        out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_n, N), k1, k2, beta, mu, args.smooth, args.inner_reduction,
+                                           args.inner_rtol, args.cpu_threads, args.inner_norm, keep)
+        if args.inner_norm == 2:
+            out["parity_vs_port"] = None      # (the port's leg runs the reduction-based sweeps)
+        else:
+            if keep["cells"] != N:
+                # the port's bounded sample is a smaller cube than the timed one: one GPU step at the port's size
+                ctx.mesh_build(3, _ffi.CELL_HEX, keep["cells"], keep["cells"], keep["cells"])
+                b, g1, g2 = mms_boundary(keep["cells"], k1, k2, beta, mu)
+                ctx.set_dirichlet(0, b, g1)
+                ctx.set_dirichlet(1, b, g2)
+                info_timed = step()
+                x_gpu = ctx.solution()
+            pv = parity_vs_port(x_gpu, info_timed, keep)
+            out["parity_vs_port"] = pv["ok"]
+            out["parity"] = pv
+            parity_failed = not pv["ok"]
     elif rank == 0:
         out["cpu_baseline"] = None
+        out["parity_vs_port"] = None
     if dist is not None:
         dist.barrier()
         ctx.close()  # destroys the library's RCCL communicator before the process group goes away
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+    if parity_failed:
+        raise SystemExit("bench.py: the GPU step and the CPU port disagree (see \"parity\" in the line above)")
 
 
 if __name__ == "__main__":

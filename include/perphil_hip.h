@@ -226,11 +226,14 @@ int pph_comm_stats(pph_ctx* ctx, int64_t* halo_exchanges, int64_t* allreduces, i
  * the two-step path (0 when fused), [3] last solve ms;
  * SpMV accounting of the last solve per kernel variant v (0: plain, 1: fused with the p.Ap dot):
  * out[4+3v] sum of per-launch durations in ms (0 unless option "time_spmv" is on), out[5+3v] launches,
- * out[6+3v] algorithmic bytes (12 nnz + 20 nrows per launch); out[10] halo exchanges of the last solve;
+ * out[6+3v] algorithmic bytes (CSR launches: 12 nnz + 20 nrows; stencil-ELL launches: (8 S + 16 + e) nrows with S the
+ * STORED slots per row - 14 of 27 for hexahedra in symmetric storage - and e = 8 / 16 / 32..48 for the residual,
+ * Jacobi-update and Picard-bookkeeping epilogues' extra vectors); out[10] halo exchanges of the last solve;
  * out[11..13] the same three figures (ms, launches, bytes; both variants together) for the launches on
  * fine-level operators only (rows >= nodes of the mesh), i.e. without the coarser multigrid levels;
  * out[14] products of the last solve launched as interior + boundary rows (option "halo_overlap", slabs only);
- * out[15] 1 when the stencil-ELL blocks of the last assembly use symmetric storage. */
+ * out[15] 1 when the stencil-ELL blocks of the last assembly use symmetric storage;
+ * out[16] the most partial sums a split product has written into one reduction slot so far (<= option "part_cap"). */
 int pph_get_timers(pph_ctx* ctx, double* out, int n);
 /* tuning / profiling switches (no reference counterpart; defaults in brackets):
  *   "op_format" [1]      operator format of the scalar blocks inside block solves / Picard sweeps: 1 stencil-ELL
@@ -270,7 +273,9 @@ int pph_get_timers(pph_ctx* ctx, double* out, int n);
  *   "halo_overlap" [0]   slabs: products on levels of at least "halo_overlap_min_rows" [200000] rows are launched as
  *                        interior rows + boundary rows; 1: the exchange of the operand's ghost planes runs on a second
  *                        stream while the interior rows are computed, 2: the same launches, exchange first (the two
- *                        give bit-identical results) */
+ *                        give bit-identical results).  The three launches share one reduction slot's partial-sum area:
+ *                        their grids are capped so that together they write at most "part_cap" [4096, the area's size;
+ *                        tests lower it] partial sums */
 int pph_set_option(pph_ctx* ctx, const char* name, double value);
 
 #ifdef __cplusplus

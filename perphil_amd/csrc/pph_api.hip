@@ -585,8 +585,14 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
   if (!strcmp(name, "sell_zwalk")) { ctx->sell_zwalk = value > 0 ? (int)value : 0; return PPH_OK; }
   if (!strcmp(name, "sell_rpt")) { ctx->sell_rpt = (int)value; return PPH_OK; }
   if (!strcmp(name, "sell_blocks")) { ctx->sell_blocks = (int)value; return PPH_OK; }
+  if (!strcmp(name, "part_cap")) {   // tests: partial sums one (split) product may write in total
+    PPH_REQUIRE(ctx, value >= 32 && value <= PPH_PART_STRIDE && ((int)value % 32) == 0, "part_cap must be a multiple of 32 in [32, %d]", PPH_PART_STRIDE);
+    ctx->part_cap = (int)value; la_release_graphs(ctx); return PPH_OK;
+  }
+  if (!strcmp(name, "sell_flags")) { ctx->sell_flags = (int)value; la_release_graphs(ctx); return PPH_OK; }
   if (!strcmp(name, "sell_group")) { ctx->sell_group = (int)value; return PPH_OK; }
   if (!strcmp(name, "asm_tile")) { ctx->asm_tile = (value == 2.0) ? 2 : (value != 0.0 ? 1 : 0); return PPH_OK; }
+  if (!strcmp(name, "asm_tile_xmap")) { ctx->asm_tile_xmap = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "asm_affine")) { ctx->asm_affine = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "asm_tile_probe")) { ctx->asm_tile_probe = (int)value; return PPH_OK; }
   if (!strcmp(name, "asm_tile_min_nodes")) { ctx->asm_tile_min_nodes = (int64_t)value; return PPH_OK; }
@@ -632,12 +638,12 @@ int pph_comm_set_callbacks(pph_ctx* ctx, int rank, int world, pph_halo_fn halo, 
 int pph_get_timers(pph_ctx* ctx, double* out, int n) {
   if (!ctx || !out) return PPH_ERR_INVALID;
   la_harvest_spmv_times(ctx);
-  const double v[16] = {ctx->t_mesh, ctx->t_asm, ctx->t_bc, ctx->t_solve,
+  const double v[17] = {ctx->t_mesh, ctx->t_asm, ctx->t_bc, ctx->t_solve,
                         ctx->t_spmv[0], (double)ctx->n_spmv[0], ctx->spmv_bytes[0],
                         ctx->t_spmv[1], (double)ctx->n_spmv[1], ctx->spmv_bytes[1], (double)ctx->n_halo,
                         ctx->t_spmv_fine, (double)ctx->n_spmv_fine, ctx->spmv_bytes_fine, (double)ctx->n_split,
-                        (ctx->ell_ok && ctx->S11.sym) ? 1.0 : 0.0};
-  for (int i = 0; i < n && i < 16; ++i) out[i] = v[i];
+                        (ctx->ell_ok && ctx->S11.sym) ? 1.0 : 0.0, (double)ctx->max_split_partials};
+  for (int i = 0; i < n && i < 17; ++i) out[i] = v[i];
   return PPH_OK;
 }
 

@@ -1617,7 +1617,7 @@ template <int DIM>
 __global__ __launch_bounds__(512, 4) void k_asm_tile(const double* __restrict__ cx, const double* __restrict__ cy,
                                                   const double* __restrict__ cz, const int64_t* __restrict__ rowptr,
                                                   double* __restrict__ K, double* __restrict__ M, int nx, int ny, int nzl,
-                                                  int px, int py, int pz, int64_t n, FuseArgs fa, int probe) {
+                                                  int px, int py, int pz, int64_t n, FuseArgs fa, int probe, int xmap) {
   using TG = TileGeo<DIM>;
   constexpr int NB = 1 << DIM;
   constexpr int TX = TG::TX, TY = TG::TY, TZ = TG::TZ;
@@ -1714,8 +1714,19 @@ __global__ __launch_bounds__(512, 4) void k_asm_tile(const double* __restrict__ 
     pv[1] = cy[g];
     if constexpr (DIM == 3) pv[2] = cz[g];
   };
-  fetch_vertex(blockIdx.x);
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+  // Tile order.  A slot store of a tile is 8 runs of TX doubles (64 B, never aligned: px is odd on the usual 2^k cell
+  // meshes): the two halves of a 128-B line belong to x-adjacent tiles.  Dealt round-robin (tile = blockIdx + k grid)
+  // those tiles sit on different XCDs, whose L2s each write back a partial line - the memory side then reads the line
+  // to merge it (PMC, 256^3: 4.4 GB fetched by a kernel with 0.5 GB of inputs, 1.5 x its stores written).  xmap: every
+  // XCD (blockIdx % 8) takes one contiguous eighth of the tile sequence and its workgroups consecutive tiles of it, so
+  // both halves of a line meet in ONE L2 within a few microseconds.
+  const int xcd = blockIdx.x & 7, bxx = blockIdx.x >> 3, bpx = gridDim.x >> 3;
+  const int tpx = (ntiles + 7) >> 3;                                // tiles per XCD
+  const int t_first = xmap ? xcd * tpx + bxx : (int)blockIdx.x;
+  const int t_step = xmap ? bpx : (int)gridDim.x;
+  const int t_end = xmap ? ((xcd + 1) * tpx < ntiles ? (xcd + 1) * tpx : ntiles) : ntiles;
+  fetch_vertex(t_first < t_end ? t_first : ntiles);
+  for (int tile = t_first; tile < t_end; tile += t_step) {
     const int tx = tile % tiles_x;
     const int tt = tile / tiles_x;
     const int ty = (int)(tt % tiles_y), tz = (int)(tt / tiles_y);
@@ -1726,7 +1737,7 @@ __global__ __launch_bounds__(512, 4) void k_asm_tile(const double* __restrict__ 
       sXv[tid][1] = pv[1];
       if constexpr (DIM == 3) sXv[tid][2] = pv[2];
     }
-    fetch_vertex(tile + (int)gridDim.x);
+    fetch_vertex(tile + t_step < t_end ? tile + t_step : ntiles);
     // operands of phase C that depend on the node only: requested now, used after three barriers
     uint8_t pnear = 0, pr1 = 0, pr2 = 0;
     {
@@ -2081,13 +2092,15 @@ int pph_launch_fused_kernels(pph_ctx* ctx, MeshData& mesh, const FuseArgs& fa, d
     const int tx = (mesh.dim == 3) ? 8 : 16, ty = (mesh.dim == 3) ? 4 : 8, tz = (mesh.dim == 3) ? 2 : 1;
     const int64_t ntiles = ceil_div64(mesh.px, tx) * ceil_div64(mesh.py, ty) * ceil_div64(mesh.pzl, tz);
     PPH_REQUIRE(ctx, ntiles < (int64_t)1 << 31, "tile assembly: too many tiles for 32-bit tile indices");
-    const int grid = (int)(ntiles < 256 * 16 ? ntiles : 256 * 16);
+    int grid = (int)(ntiles < 256 * 16 ? ntiles : 256 * 16);
+    const int xmap = (ctx->asm_tile_xmap && grid >= 64) ? 1 : 0;
+    if (xmap) grid &= ~7;   // (the XCD-contiguous tile order wants a multiple of 8 workgroups)
     if (mesh.kind == PPH_CELL_QUAD)
       hipLaunchKernelGGL(k_asm_tile<2>, dim3(grid), dim3(512), 0, ctx->stream, mesh.cx.p, mesh.cy.p, mesh.cz.p, mesh.rowptr.p,
-                         Kp, Mp, mesh.nx, mesh.ny, 0, mesh.px, mesh.py, 1, mesh.n, fa, ctx->asm_tile_probe ? ctx->asm_tile_probe : (ctx->asm_affine ? 0 : 6));
+                         Kp, Mp, mesh.nx, mesh.ny, 0, mesh.px, mesh.py, 1, mesh.n, fa, ctx->asm_tile_probe ? ctx->asm_tile_probe : (ctx->asm_affine ? 0 : 6), xmap);
     else
       hipLaunchKernelGGL(k_asm_tile<3>, dim3(grid), dim3(512), 0, ctx->stream, mesh.cx.p, mesh.cy.p, mesh.cz.p, mesh.rowptr.p,
-                         Kp, Mp, mesh.nx, mesh.ny, mesh.nzl, mesh.px, mesh.py, mesh.pzl, mesh.n, fa, ctx->asm_tile_probe ? ctx->asm_tile_probe : (ctx->asm_affine ? 0 : 6));
+                         Kp, Mp, mesh.nx, mesh.ny, mesh.nzl, mesh.px, mesh.py, mesh.pzl, mesh.n, fa, ctx->asm_tile_probe ? ctx->asm_tile_probe : (ctx->asm_affine ? 0 : 6), xmap);
     PPH_HIP(ctx, hipGetLastError());
     return PPH_OK;
   }

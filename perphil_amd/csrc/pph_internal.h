@@ -243,6 +243,8 @@ struct pph_ctx {
   int halo_overlap = 0;
   int64_t halo_overlap_min_rows = 200000;
   int64_t n_split = 0;                  // products launched split (statistics)
+  int max_split_partials = 0;           // largest total a split product wrote so far (statistics)
+  int part_cap = 4096;                  // partial sums the launches of ONE product may write in total (= PPH_PART_STRIDE; tests lower it)
   std::string err;
 
   // mesh (local box)
@@ -258,6 +260,7 @@ struct pph_ctx {
   int asm_affine = 1;                   // tile kernel: cells with equal parallel edges get their (constant) geometry factor once per cell
   int asm_tile_probe = 0;               // timing probe of the tile kernel: 1 stop after phase A, 2 after phase B (wrong results)
   int64_t asm_tile_min_nodes = 30000;   // levels with fewer nodes use the two-pass kernels (asm_tile 2: tile kernel always)
+  int asm_tile_xmap = 1;                // tile kernel: x-adjacent tiles on ONE XCD (both halves of a 128-B line of a slot array meet in one L2)
   int asm_tile = 1;                     // multilinear fused assembly: 1 single-pass tile kernel (no element-row buffer), 0 two-pass
   int asm_ring = 0;                     // > 0 (experiment, slower): fused 3D assembly alternates element and node passes over a ring of cell layers, about asm_ring cells per launch
   int asm_keep_km = 0;                  // 1: the fused pass also stores K and M (two more 8 B/nnz streams); 0: they are integrated on demand (pph_get_csr K/M, Darcy projection)
@@ -362,6 +365,7 @@ struct pph_ctx {
   int64_t sell_zwalk_min_chunks = 5500; // levels with fewer 512-row chunks keep the plain chunk order (measured: 128^3 = 4200 chunks loses 4 % with the z-walk, 144^3 = 5950 equal, 160^3 gains 8 %, 192^3 4 %, 256^3 20 %)
   int sell_zwalk = 4;                   // > 0 (symmetric operators, 3D): a workgroup walks this many consecutive node planes at one in-plane position
   int sell_xmap = 1;                    // z-walk: consecutive in-plane positions on one XCD
+  int sell_flags = 0;                   // experiments: 1 non-temporal y stores (mode 0), 2 non-temporal loads of the diagonal slot
   int sell_rpt = 2, sell_blocks = 0, sell_group = 0;   // SELL SpMV tuning: rows per thread, grid cap, XCD chunk group
   DevBuf<double> sell_tmp;              // SELL copy of the matrix last selected by pph_spmv / pph_spmv_bench
 };
@@ -467,7 +471,7 @@ void la_reset_spmv_stats(pph_ctx* ctx);
 // stencil-ELL operator format (pph_sell.hip)
 int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x, const double* b, const double* dinv,
               const double* w /* device */, double* y, double* part, int64_t dlo = 0, int64_t dhi = 0, double* aux = nullptr, double* z0 = nullptr,
-              int64_t cbeg = 0, int64_t cend = -1);
+              int64_t cbeg = 0, int64_t cend = -1, int grid_cap = 0);
 int sell_alloc(pph_ctx* ctx, const MeshData& mesh, DevBuf<double>& buf, Sell* out, int sym);
 int sell_from_csr(pph_ctx* ctx, const MeshData& mesh, const double* csr_val, DevBuf<double>& buf, Sell* out, int sym);
 // symmetric storage is used for operators that are symmetric on the local box: single context (a slab's ghost rows

@@ -223,13 +223,30 @@ static int sell_product(pph_ctx* ctx, const Csr& A, int mode, const double* x, c
       } else {
         (void)la_halo(ctx, *g, xv);
       }
-      total += sell_spmv(ctx, A.ell, A.nrows, mode, x, b, dinv, w, y, part, dlo, dhi, aux, z0, c_lo, c_hi);
+      // The partial sums of the dot-product modes are laid out launch after launch in ONE slot area of PPH_PART_STRIDE
+      // entries (mode 7 keeps two more areas at that stride): the three grids together must stay within it, or the
+      // tail of one sum would alias the next slot.  The boundary launches get up to a quarter each, the interior the rest.
+      int cap_i = 0, cap_lo = 0, cap_hi = 0;
+      if (mode == 2 || mode >= 4) {
+        const int pc = ctx->part_cap;
+        const int64_t q = (pc / 4) & ~7;
+        auto grid8 = [](int64_t chunks, int64_t cap) { const int64_t g = chunks < cap ? chunks : cap; return (int)(((g + 7) / 8) * 8); };
+        cap_lo = (int)q; cap_hi = (int)q;
+        cap_i = pc - (c_lo > 0 ? grid8(c_lo, q) : 0) - (nchunks - c_hi > 0 ? grid8(nchunks - c_hi, q) : 0);
+      }
+      total += sell_spmv(ctx, A.ell, A.nrows, mode, x, b, dinv, w, y, part, dlo, dhi, aux, z0, c_lo, c_hi, cap_i);
       if (overlap) {
         if (ctx->nccl_comm) (void)hipStreamWaitEvent(ctx->stream, ctx->ev_h, 0);
         else (void)la_halo(ctx, *g, xv, nullptr, ctx->ev_x);   // callback transport: the host exchanges while the interior rows run
       }
-      total += sell_spmv(ctx, A.ell, A.nrows, mode, x, b, dinv, w, y, part + total, dlo, dhi, aux, z0, 0, c_lo);
-      total += sell_spmv(ctx, A.ell, A.nrows, mode, x, b, dinv, w, y, part + total, dlo, dhi, aux, z0, c_hi, nchunks);
+      total += sell_spmv(ctx, A.ell, A.nrows, mode, x, b, dinv, w, y, part + total, dlo, dhi, aux, z0, 0, c_lo, cap_lo);
+      total += sell_spmv(ctx, A.ell, A.nrows, mode, x, b, dinv, w, y, part + total, dlo, dhi, aux, z0, c_hi, nchunks, cap_hi);
+      if ((mode == 2 || mode >= 4) && total > ctx->part_cap && ctx->comm_status == PPH_OK) {
+        // cannot happen with the caps above; if it ever does the sums are wrong: refuse the solve instead of computing on
+        ctx->comm_status = PPH_ERR_INVALID;
+        ctx->comm_error = "split product wrote more partial sums than one reduction slot holds";
+      }
+      ctx->max_split_partials = total > ctx->max_split_partials ? total : ctx->max_split_partials;
       return total;
     }
   }

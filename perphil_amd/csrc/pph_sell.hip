@@ -34,7 +34,7 @@ __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_
                                           const double* __restrict__ b, const double* __restrict__ dinv, double w,
                                           double* __restrict__ y, double* __restrict__ aux, double* __restrict__ z0,
                                           int64_t n, int px, int64_t pxy, int64_t r0, double& dotacc, int64_t dlo,
-                                          int64_t dhi, double* dotx = nullptr) {
+                                          int64_t dhi, double* dotx = nullptr, int flags = 0) {
   using ST = SellSt<KIND>;
   double acc[RPT];
   double bv[RPT], xr[RPT], dv[RPT], tv[RPT], av[RPT];
@@ -109,7 +109,13 @@ __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_
 #pragma unroll
         for (int i = 0; i < RPT; i += 2) {
           double2 t = make_double2(0.0, 0.0);
-          if (act[i]) t = *reinterpret_cast<const double2*>(vp + i);
+          if (act[i]) {
+            if (SYM && slot == C0 && (flags & 2)) {   // experiment: the diagonal is the one stored slot no other row reads
+              typedef double v2d __attribute__((ext_vector_type(2)));
+              const v2d q = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(vp + i));
+              t = make_double2(q.x, q.y);
+            } else t = *reinterpret_cast<const double2*>(vp + i);
+          }
           v[i] = t.x; v[i + 1] = t.y;
         }
       }
@@ -122,7 +128,7 @@ __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_
   for (int i = 0; i < RPT; ++i) {
     if (!act[i]) continue;
     const int64_t r = r0 + i;
-    if (MODE == 0) y[r] = acc[i];
+    if (MODE == 0) { if (flags & 1) __builtin_nontemporal_store(acc[i], y + r); else y[r] = acc[i]; }
     else if (MODE == 1) y[r] = bv[i] - acc[i];
     else if (MODE == 2) { y[r] = acc[i]; if (r >= dlo && r < dhi) dotacc += acc[i] * xr[i]; }   // (owned rows: ghost rows of a symmetric slab operator hold no row of this rank)
     else if (MODE == 7) {
@@ -151,7 +157,7 @@ __global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ va
                                                    double* __restrict__ z0, int64_t n, int px, int64_t pxy, int64_t halo,
                                                    int64_t nchunks, int64_t chunk0,
                                                    int group, int zwalk, int xmap, double* __restrict__ part,
-                                                   int64_t dlo, int64_t dhi) {
+                                                   int64_t dlo, int64_t dhi, int flags) {
   constexpr int CH = 256 * RPT;
   const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, bpx = gridDim.x >> 3;   // launcher keeps gridDim.x a multiple of 8
   // the smoother weight lives in device memory (refreshed per assembly) so that captured graphs survive a re-assembly
@@ -202,9 +208,9 @@ __global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ va
     // a chunk whose rows and x window lie inside [0, n) needs no index clamps and no row masks (all but the first
     // and last few chunks)
     if (c0 >= halo && c0 + CH + halo <= n)
-      sell_rows<KIND, MODE, RPT, false, SYM>(val, ld, x, b, dinv, w, y, aux, z0, n, px, pxy, r0, dotacc, dlo, dhi, dotx);
+      sell_rows<KIND, MODE, RPT, false, SYM>(val, ld, x, b, dinv, w, y, aux, z0, n, px, pxy, r0, dotacc, dlo, dhi, dotx, flags);
     else
-      sell_rows<KIND, MODE, RPT, true, SYM>(val, ld, x, b, dinv, w, y, aux, z0, n, px, pxy, r0, dotacc, dlo, dhi, dotx);
+      sell_rows<KIND, MODE, RPT, true, SYM>(val, ld, x, b, dinv, w, y, aux, z0, n, px, pxy, r0, dotacc, dlo, dhi, dotx, flags);
   }
   if (MODE == 2 || MODE >= 4) {
     __shared__ double lds[4];
@@ -234,11 +240,11 @@ static void sell_launch_mode(pph_ctx* ctx, int mode, int grid, const Sell& E, co
   const int zwalk = (E.sym && E.pz > 2 && ctx->sell_zwalk > 0 && chunk0 == 0 && nchunks >= ctx->sell_zwalk_min_chunks) ? ctx->sell_zwalk : 0;   // (no gain on full storage)
 #define PPH_SELL_GO(MM)                                                                                              \
   hipLaunchKernelGGL((k_spmv_sell<KIND, MM, RPT>), dim3(grid), dim3(256), 0, ctx->stream, E.val, E.ld, x, b, dinv, w, \
-                     y, aux, z0, n, E.px, pxy, halo, nchunks, chunk0, group, zwalk, ctx->sell_xmap, part, dlo, dhi)
+                     y, aux, z0, n, E.px, pxy, halo, nchunks, chunk0, group, zwalk, ctx->sell_xmap, part, dlo, dhi, ctx->sell_flags)
   if (E.sym) {
 #define PPH_SELL_GOS(MM)                                                                                                   \
   hipLaunchKernelGGL((k_spmv_sell<KIND, MM, RPT, true>), dim3(grid), dim3(256), 0, ctx->stream, E.val, E.ld, x, b, dinv, w, \
-                     y, aux, z0, n, E.px, pxy, halo, nchunks, chunk0, group, zwalk, ctx->sell_xmap, part, dlo, dhi)
+                     y, aux, z0, n, E.px, pxy, halo, nchunks, chunk0, group, zwalk, ctx->sell_xmap, part, dlo, dhi, ctx->sell_flags)
     switch (mode) {
       case 0: PPH_SELL_GOS(0); break;
       case 1: PPH_SELL_GOS(1); break;
@@ -267,7 +273,8 @@ static void sell_launch_mode(pph_ctx* ctx, int mode, int grid, const Sell& E, co
 
 // launches the product; returns the grid (= number of partial sums written in mode 2)
 int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x, const double* b, const double* dinv,
-              const double* w, double* y, double* part, int64_t dlo, int64_t dhi, double* aux, double* z0, int64_t cbeg, int64_t cend) {
+              const double* w, double* y, double* part, int64_t dlo, int64_t dhi, double* aux, double* z0, int64_t cbeg, int64_t cend,
+              int grid_cap) {
   const int rpt = (ctx->sell_rpt == 1) ? 1 : 2;
   // [cbeg, cend) (cend < 0: all): the chunks of this launch - a product split into boundary and interior rows
   const int64_t nchunks_all = ceil_div64(n, 256 * rpt);
@@ -281,7 +288,9 @@ int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x,
   const bool zw = E.sym && E.pz > 2 && ctx->sell_zwalk > 0 && chunk0 == 0 && nchunks >= ctx->sell_zwalk_min_chunks;   // (smaller levels: too few chunks per workgroup)
   int cap = (ctx->sell_blocks >= 8 && ctx->sell_blocks <= 8192) ? (ctx->sell_blocks / 8) * 8
                                                                  : (zw ? ((ctx->num_cus + 7) / 8) * 8 : 4096);
-  if ((mode == 2 || mode >= 4) && cap > 4096) cap = 4096;   // one partial sum per workgroup (PART_STRIDE of pph_la.hip)
+  if ((mode == 2 || mode >= 4) && cap > PPH_PART_STRIDE) cap = PPH_PART_STRIDE;   // one partial sum per workgroup
+  // (a product launched as several row ranges shares the PPH_PART_STRIDE partial sums of a slot: sell_product)
+  if (grid_cap >= 8 && cap > grid_cap) cap = (grid_cap / 8) * 8;
   int64_t g = nchunks < cap ? nchunks : cap;
   g = ((g + 7) / 8) * 8;
   const int grid = (int)g;

@@ -54,8 +54,9 @@ def init_rccl(ctx: _ffi.Context, group=None) -> int:
     1. every rank checks that librccl loads (``pph_rccl_available``) and the ranks agree on that (torch-level MIN)
        BEFORE anyone enters ``ncclCommInitRank``;
     2. rank 0 draws the unique id; a failed draw travels as an all-zero id in the same broadcast;
-    3. every rank joins the communicator, then runs the straight-line self-test (all three phases are always
-       issued, failures are reported afterwards), and the ranks agree on the verdict.
+    3. every rank joins the communicator and the ranks agree that all of them did; only then they run the
+       straight-line self-test (all three phases are always issued, failures are reported afterwards) and agree on
+       its verdict.
 
     Raises RuntimeError on every rank when any rank failed."""
     import torch
@@ -81,9 +82,13 @@ def init_rccl(ctx: _ffi.Context, group=None) -> int:
     if not ident.any():   # identical on every rank: all of them leave here together
         raise RuntimeError("rank 0 could not draw an RCCL unique id")
     st = _ffi.lib.pph_comm_init_rccl(ctx._h, rank, world, ident.ctypes.data_as(C.c_void_p), path)
+    # the self-test talks to the neighbours: nobody enters it unless EVERY rank joined the communicator (a rank that
+    # skipped it alone would leave its peers waiting inside ncclSend/ncclRecv for ever)
+    if not _agree(st == _ffi.PPH_OK, group):
+        msg = (_ffi.lib.pph_last_error(ctx._h) or b"").decode() if st != _ffi.PPH_OK else "ok"
+        raise RuntimeError(f"ncclCommInitRank failed on at least one rank (rank {rank}: {msg})")
     seen = C.c_int(0)
-    if st == _ffi.PPH_OK:
-        st = _ffi.lib.pph_comm_selftest2(ctx._h, C.byref(seen))
+    st = _ffi.lib.pph_comm_selftest2(ctx._h, C.byref(seen))
     msg = (_ffi.lib.pph_last_error(ctx._h) or b"").decode() if st != _ffi.PPH_OK else ""
     if not _agree(st == _ffi.PPH_OK and seen.value == world, group):
         raise RuntimeError(f"RCCL transport failed its self-test on at least one rank (rank {rank}: {msg or 'ok'})")

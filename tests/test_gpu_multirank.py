@@ -69,3 +69,20 @@ def test_rccl_plumbing_single_rank():
     ) % (ROOT, _free_port())
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=200)
     assert r.returncode == 0 and "rccl selftest ok" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
+
+
+def test_bench_gpus_2_starts_its_own_ranks():
+    """`python bench.py --gpus 2` exactly as the driver starts the 1-GPU run (no launcher): bench.py spawns
+    torch.distributed.run itself; gloo rehearsal, both ranks on the one GPU."""
+    import json
+
+    env = dict(os.environ, PERPHIL_DIST_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cells", "16", "--steps", "1",
+                        "--warmup", "1", "--no-cpu-baseline", "--skip-fine-bench", "--skip-csr"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["transport"] == "torch-gloo" and out["config"]["ranks_seen"] == 2
+    assert out["config"]["halo_exchanges_per_step"] > 0 and out["value"] > 0

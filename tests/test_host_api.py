@@ -158,3 +158,33 @@ def test_function_views_and_split():
     p2.vector()[0] = -1.0  # views
     assert w.vector()[9] == -1.0
     assert w.sub(0).at((0.5, 0.5)) == 4.0
+
+
+def test_bench_gpus_n_launches_itself(monkeypatch):
+    # `python bench.py --gpus N` without a launcher starts torch.distributed.run as a child (one rank per GPU,
+    # rendezvous on 127.0.0.1) with the same arguments and returns its exit code; nothing touches a GPU before that
+    import subprocess
+    import sys
+
+    import bench
+
+    seen = {}
+
+    class _Done:
+        returncode = 7
+
+    def fake_run(cmd, env=None, **kw):
+        seen["cmd"], seen["env"] = cmd, env
+        return _Done()
+
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "2", "--warmup", "1"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7
+    cmd = seen["cmd"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
