@@ -592,6 +592,7 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
   if (!strcmp(name, "sell_flags")) { ctx->sell_flags = (int)value; la_release_graphs(ctx); return PPH_OK; }
   if (!strcmp(name, "sell_group")) { ctx->sell_group = (int)value; return PPH_OK; }
   if (!strcmp(name, "asm_tile")) { ctx->asm_tile = (value == 2.0) ? 2 : (value != 0.0 ? 1 : 0); return PPH_OK; }
+  if (!strcmp(name, "asm_node")) { ctx->asm_node = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "asm_tile_xmap")) { ctx->asm_tile_xmap = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "asm_affine")) { ctx->asm_affine = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "asm_tile_probe")) { ctx->asm_tile_probe = (int)value; return PPH_OK; }

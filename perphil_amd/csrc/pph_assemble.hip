@@ -2059,6 +2059,221 @@ __global__ __launch_bounds__(512, 4) void k_asm_tile(const double* __restrict__ 
   fuse_lam_max(best1, best2, fa.lam);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Node kernel (round 3; default on box meshes, whose cells all have equal parallel edges): ONE THREAD PER NODE,
+// registers only - no LDS, no barriers, no element rows.
+//
+// The tile kernel's phases B and C exist because a general cell needs its 8 x 8 element matrix once; for a cell with a
+// constant Jacobian the element row of corner a is 8 x (6 + 1) multiply-adds on the cell's geometry factor D against
+// the compile-time reference tables (TileRef), so every node can form the rows of its 2^d incident cells ITSELF from
+// the 3^d vertex coordinates around it (served by L1: neighbours overlap) and sum them slot by slot in registers:
+//     a_(node, node + o) = sum over incident cells c that also hold node + o of  K_e^c[a_c][b_c(o)],   a_c = corner of node in c.
+// The factor of a cell is recomputed by each of its 2^d nodes (8 x ~60 flops: cheap next to one pass over LDS), the
+// formula per entry and the order of every sum are the tile kernel's (constant-factor branch): the two kernels agree
+// to the last bit or two (the compiler contracts the multiply-adds of the two bodies differently; test: 1e-15 of the
+// largest entry, same sweeps / iterations).
+// What it buys: consecutive lanes are consecutive nodes of the linear numbering, so every slot store of a wave is
+// 512 contiguous, aligned bytes (tile kernel: 8 runs of 64 B each, none aligned: PMC showed 1.5 x the stored bytes
+// written and 4.4 GB fetched by a kernel with 0.5 GB of inputs - partial-line write-throughs), and there is nothing
+// left to synchronise.  Stencil-ELL output only; meshes with a cell that fails the exact equal-edges test
+// (MeshData::all_affine, established once at mesh build) take the tile kernel and its general pass.
+// ------------------------------------------------------------------------------------------------
+template <int DIM, int WPS>
+__global__ __launch_bounds__(256, WPS) void k_asm_node(const double* __restrict__ cx, const double* __restrict__ cy,
+                                                  const double* __restrict__ cz, int nx, int ny, int nzl, int px, int py,
+                                                  int pz, int64_t n, FuseArgs fa) {
+  constexpr int NB = 1 << DIM;
+  constexpr int NSLOT = (DIM == 3) ? 27 : 9;
+  constexpr int NV = NSLOT;                                // vertices around a node
+  constexpr int ND = DIM * (DIM + 1) / 2 + 1;
+  const TileRef<DIM>& R = tile_ref<DIM>();
+  const int64_t pxy = (int64_t)px * py;
+  double best1 = 0.0, best2 = 0.0;
+  // Blocks of 256 consecutive nodes; every XCD (blockIdx % 8) takes one contiguous eighth of them, its workgroups
+  // consecutive blocks of it: a node's 3^d vertex neighbourhood is shared with its neighbours in x, y AND z, and dealt
+  // round-robin every one of the eight non-coherent L2s ended up fetching every coordinate plane (PMC, 256^3: 4.1 GB
+  // read by a kernel with 0.5 GB of inputs)
+  const int64_t nblk = (n + 255) / 256;
+  const int64_t bpx = (int64_t)(gridDim.x >> 3), cpx = (nblk + 7) >> 3;   // (launcher: gridDim.x is a multiple of 8)
+  const int64_t blk0 = (int64_t)(blockIdx.x & 7) * cpx;
+  for (int64_t c = blockIdx.x >> 3; c < cpx; c += bpx) {
+    const int64_t node = (blk0 + c) * 256 + threadIdx.x;
+    if (node >= n) continue;
+    const int gi = (int)(node % px);
+    const int64_t tq = node / px;
+    const int gj = (int)(tq % py), gk = (int)(tq / py);
+    const uint8_t pnear = fa.near[node];
+    const bool near = pnear != 0;
+    const uint8_t r1 = near ? fa.m1[node] : 0, r2 = near ? fa.m2[node] : 0;
+    // vertex coordinates around the node, indices clamped into the box (cells outside it are skipped below)
+    double V[NV][DIM];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+      const int dx = q % 3 - 1, dy = (q / 3) % 3 - 1, dz = (DIM == 3) ? q / 9 - 1 : 0;
+      int vi = gi + dx, vj = gj + dy, vk = gk + dz;
+      vi = vi < 0 ? 0 : (vi > px - 1 ? px - 1 : vi);
+      vj = vj < 0 ? 0 : (vj > py - 1 ? py - 1 : vj);
+      vk = vk < 0 ? 0 : (vk > pz - 1 ? pz - 1 : vk);
+      const int64_t g = vi + (int64_t)px * vj + pxy * vk;
+      V[q][0] = cx[g];
+      V[q][1] = cy[g];
+      if constexpr (DIM == 3) V[q][2] = cz[g];
+    }
+    double kv[NSLOT], mv[NSLOT];
+#pragma unroll
+    for (int q = 0; q < NSLOT; ++q) { kv[q] = 0.0; mv[q] = 0.0; }
+    // incident cells in ascending corner index a of the node (the tile kernel's candidate order)
+#pragma unroll
+    for (int a = 0; a < NB; ++a) {
+      const int ax = a & 1, ay = (a >> 1) & 1, az = (DIM == 3) ? (a >> 2) & 1 : 0;
+      const int ci = gi - ax, cj = gj - ay, ck = (DIM == 3) ? gk - az : 0;
+      const bool incell = ci >= 0 && ci < nx && cj >= 0 && cj < ny && (DIM == 2 || (ck >= 0 && ck < nzl));
+      if (!incell) continue;
+      // vertex b of the cell = neighbourhood entry (b - a) + centre; J[e][d] = (x_{2^e} - x_0)[d] / 2
+      const int v0 = (1 - ax) + 3 * (1 - ay) + ((DIM == 3) ? 9 * (1 - az) : 0);
+      double J[DIM][DIM];
+#pragma unroll
+      for (int e = 0; e < DIM; ++e) {
+        const int ve = v0 + ((e == 0) ? 1 : (e == 1) ? 3 : 9);
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) J[e][d] = 0.5 * (V[ve][d] - V[v0][d]);
+      }
+      double D[ND];
+      tile_factor<DIM>(J, D);
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
+        const int bx = b & 1, by = (b >> 1) & 1, bz = (DIM == 3) ? (b >> 2) & 1 : 0;
+        const int slot = (bx - ax + 1) + 3 * (by - ay + 1) + ((DIM == 3) ? 9 * (bz - az + 1) : 0);
+        double kb = 0.0;
+#pragma unroll
+        for (int f = 0; f < ND - 1; ++f) kb += D[f] * R.G[a][b][f];
+        kv[slot] += kb;
+        mv[slot] += D[ND - 1] * R.M[a][b];
+      }
+    }
+    // stencil row: fused epilogue of the tile kernel's phase C; partial sums per slot group (slot % 2^d), combined in
+    // the order of its shuffle tree
+    double g11[NB], g22[NB], gK1[NB], gK2[NB], gM[NB];
+#pragma unroll
+    for (int g = 0; g < NB; ++g) { g11[g] = 0.0; g22[g] = 0.0; gK1[g] = 0.0; gK2[g] = 0.0; gM[g] = 0.0; }
+    double d11 = 0.0, d22 = 0.0;
+#pragma unroll
+    for (int slot = 0; slot < NSLOT; ++slot) {
+      const int dx = slot % 3 - 1, dy = (slot / 3) % 3 - 1, dz = (DIM == 3) ? slot / 9 - 1 : 0;
+      const int ni = gi + dx, nj = gj + dy, nk = gk + dz;
+      if (ni < 0 || ni >= px || nj < 0 || nj >= py || nk < 0 || nk >= pz) continue;   // no such neighbour: pad / absent
+      const double kvs = kv[slot], mvs = mv[slot];
+      const int64_t j = node + dx + (int64_t)dy * px + (int64_t)dz * pxy;
+      const bool diag = (slot == NSLOT / 2);
+      double o11 = fa.a * kvs + fa.b * mvs, o22 = fa.c * kvs + fa.b * mvs, o12 = -fa.b * mvs, o21 = o12;
+      if (near) {
+        const uint8_t cm1 = fa.m1[j], cm2 = fa.same ? cm1 : fa.m2[j];
+        if (fa.rhs) {
+          const double v1 = fa.g1[j], v2 = fa.g2[j];
+          gK1[slot % NB] += kvs * v1; gK2[slot % NB] += kvs * v2; gM[slot % NB] += mvs * (v1 - v2);
+        }
+        o11 = fuse_elim_diag(o11, r1, cm1, diag, fa.symg);
+        o22 = fuse_elim_diag(o22, r2, cm2, diag, fa.symg);
+        o12 = fuse_elim_coupling(-fa.b * mvs, r1, cm2, fa.symg);
+        o21 = fuse_elim_coupling(-fa.b * mvs, r2, cm1, fa.symg);
+      }
+      const int sq = (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1);
+      const int so = fa.slot_of[sq], sc = fa.slot_of_c[sq];     // stored slots (-1: lower half of a symmetric operator)
+      if (so >= 0) { fa.A11[(int64_t)so * fa.ld + node] = o11; fa.A22[(int64_t)so * fa.ld + node] = o22; }
+      if (sc >= 0) {
+        if (fa.A12) fa.A12[(int64_t)sc * fa.ld + node] = o12;
+        if (fa.A21) fa.A21[(int64_t)sc * fa.ld + node] = o21;
+      }
+      g11[slot % NB] += fabs(o11); g22[slot % NB] += fabs(o22);
+      if (diag) { d11 = o11; d22 = o22; }
+    }
+    auto combine = [&](double (&l)[NB]) -> double {
+#pragma unroll
+      for (int o = NB / 2; o > 0; o >>= 1)
+#pragma unroll
+        for (int g = 0; g < o; ++g) l[g] += l[g + o];
+      return l[0];
+    };
+    const double t11 = combine(g11), t22 = combine(g22);
+    const double i1 = (d11 != 0.0) ? 1.0 / d11 : 1.0, i2 = (d22 != 0.0) ? 1.0 / d22 : 1.0;
+    fa.dinv1[node] = i1;
+    fa.dinv2[node] = i2;
+    const double q1 = t11 * fabs(i1), q2 = t22 * fabs(i2);
+    if (!(r1 & 2)) best1 = q1 > best1 ? q1 : best1;   // (ghost rows: not rows of this rank's operator)
+    if (!(r2 & 2)) best2 = q2 > best2 ? q2 : best2;
+    if (fa.rhs) {
+      double o1 = 0.0, o2 = 0.0, u1 = 0.0, u2 = 0.0;
+      if (near) {
+        const double tK1 = combine(gK1), tK2 = combine(gK2), tM = combine(gM);
+        o1 = (r1 != 0) ? 0.0 : -(fa.a * tK1 + fa.b * tM);
+        o2 = (r2 != 0) ? 0.0 : -(fa.c * tK2 - fa.b * tM);
+        u1 = fa.g1[node];
+        u2 = fa.g2[node];
+      }
+      fa.rhs[node] = o1;
+      fa.rhs[n + node] = o2;
+      fa.u0[node] = u1;
+      fa.u0[n + node] = u2;
+    }
+  }
+  fuse_lam_max(best1, best2, fa.lam);
+}
+
+// every cell of a multilinear mesh has equal parallel edges (exact test of the tile kernel's phase A): out[0] != 0 otherwise
+template <int DIM>
+__global__ __launch_bounds__(256) void k_affine_check(const double* __restrict__ cx, const double* __restrict__ cy,
+                                                      const double* __restrict__ cz, int nx, int ny, int nzl, int px, int py,
+                                                      int* __restrict__ out) {
+  constexpr int NB = 1 << DIM;
+  const int64_t ncell = (int64_t)nx * ny * (DIM == 3 ? nzl : 1);
+  const int64_t pxy = (int64_t)px * py;
+  bool bad = false;
+  for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < ncell; c += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(c % nx);
+    const int64_t t = c / nx;
+    const int cj = (int)(t % ny), ck = (int)(t / ny);
+    double X[NB][DIM];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      const int64_t g = (ci + (b & 1)) + (int64_t)px * (cj + ((b >> 1) & 1)) + pxy * (ck + ((DIM == 3) ? (b >> 2) & 1 : 0));
+      X[b][0] = cx[g];
+      X[b][1] = cy[g];
+      if constexpr (DIM == 3) X[b][2] = cz[g];
+    }
+#pragma unroll
+    for (int e = 0; e < DIM; ++e)
+#pragma unroll
+      for (int b = 1; b < NB; ++b) {
+        if ((b >> e) & 1) continue;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) bad = bad || !(X[b | (1 << e)][d] - X[b][d] == X[1 << e][d] - X[0][d]);
+      }
+  }
+  if (bad) atomicOr(out, 1);
+}
+
+int pph_mesh_check_affine(pph_ctx* ctx, MeshData& mesh) {
+  mesh.all_affine = false;
+  if (mesh.kind != PPH_CELL_QUAD && mesh.kind != PPH_CELL_HEX) return PPH_OK;
+  DevBuf<int> flag;
+  PPH_TRY(flag.alloc(ctx, 1));
+  PPH_HIP(ctx, hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream));
+  const int64_t ncell = mesh.ncell;
+  const int grid = (int)(ceil_div64(ncell, 256) < 4096 ? ceil_div64(ncell, 256) : 4096);
+  if (mesh.dim == 2)
+    hipLaunchKernelGGL(k_affine_check<2>, dim3(grid), dim3(256), 0, ctx->stream, mesh.cx.p, mesh.cy.p, mesh.cz.p, mesh.nx,
+                       mesh.ny, 0, mesh.px, mesh.py, flag.p);
+  else
+    hipLaunchKernelGGL(k_affine_check<3>, dim3(grid), dim3(256), 0, ctx->stream, mesh.cx.p, mesh.cy.p, mesh.cz.p, mesh.nx,
+                       mesh.ny, mesh.nzl, mesh.px, mesh.py, flag.p);
+  int h = 1;
+  PPH_HIP(ctx, hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  flag.release();
+  mesh.all_affine = (h == 0);
+  return PPH_OK;
+}
+
 // Fused assembly of the fine level for multilinear cells (two-pass kernels): element rows, then ONE node-centred
 // pass that writes the eliminated blocks, the lifted right-hand side and the smoother's diagonal / spectral bound
 // (and K, M as well when `asm_keep_km` is set, so that later assemblies with other coefficients reuse them).
@@ -2083,6 +2298,19 @@ int pph_launch_fused_kernels(pph_ctx* ctx, MeshData& mesh, const FuseArgs& fa, d
       hipLaunchKernelGGL((k_asm_simplex_gather<3, true>), dim3(gs), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.cx.p,
                          mesh.cy.p, mesh.cz.p, mesh.rowptr.p, mesh.col.p, Kp, Mp, mesh.nx, mesh.ny, mesh.nzl, mesh.px,
                          mesh.py, mesh.n, fa);
+    PPH_HIP(ctx, hipGetLastError());
+    return PPH_OK;
+  }
+  // box meshes (every cell with equal parallel edges), stencil-ELL output: one thread per node, registers only
+  if (ctx->asm_node && ctx->asm_tile && ctx->asm_affine && mesh.all_affine && fa.ld != 0 && !fa.keep_km && !ctx->asm_tile_probe && !ctx->asm_ring) {
+    const int64_t nb = ((ceil_div64(mesh.n, 256) + 7) / 8) * 8;
+    const int grid = (int)(nb < 256 * 64 ? nb : 256 * 64);
+    if (mesh.kind == PPH_CELL_QUAD)
+      hipLaunchKernelGGL((k_asm_node<2, 2>), dim3(grid), dim3(256), 0, ctx->stream, mesh.cx.p, mesh.cy.p, mesh.cz.p, mesh.nx, mesh.ny, 0,
+                         mesh.px, mesh.py, 1, mesh.n, fa);
+    else
+      hipLaunchKernelGGL((k_asm_node<3, 2>), dim3(grid), dim3(256), 0, ctx->stream, mesh.cx.p, mesh.cy.p, mesh.cz.p, mesh.nx, mesh.ny,
+                         mesh.nzl, mesh.px, mesh.py, mesh.pzl, mesh.n, fa);
     PPH_HIP(ctx, hipGetLastError());
     return PPH_OK;
   }

@@ -164,6 +164,7 @@ struct MeshData {
   int64_t n = 0, ncell = 0, nnzb = 0;   // nodes, cells, nnz of one scalar block
   int max_row = 0;                      // stencil size = longest row of the scalar pattern
   bool km_valid = false;                // K and M hold the integrals of this mesh
+  bool all_affine = false;              // multilinear cells: every cell has equal parallel edges (exact test at mesh build)
   DevBuf<double> cx, cy, cz;            // nodal coordinates (SoA)
   DevBuf<int32_t> cells;                // cell -> dof map [ncell][m]
   DevBuf<int64_t> rowptr;               // scalar CSR pattern
@@ -260,6 +261,7 @@ struct pph_ctx {
   int asm_affine = 1;                   // tile kernel: cells with equal parallel edges get their (constant) geometry factor once per cell
   int asm_tile_probe = 0;               // timing probe of the tile kernel: 1 stop after phase A, 2 after phase B (wrong results)
   int64_t asm_tile_min_nodes = 30000;   // levels with fewer nodes use the two-pass kernels (asm_tile 2: tile kernel always)
+  int asm_node = 1;                     // box meshes, stencil-ELL output: one thread per node, registers only (k_asm_node); 0: tile / two-pass kernels
   int asm_tile_xmap = 1;                // tile kernel: x-adjacent tiles on ONE XCD (both halves of a 128-B line of a slot array meet in one L2)
   int asm_tile = 1;                     // multilinear fused assembly: 1 single-pass tile kernel (no element-row buffer), 0 two-pass
   int asm_ring = 0;                     // > 0 (experiment, slower): fused 3D assembly alternates element and node passes over a ring of cell layers, about asm_ring cells per launch
@@ -384,6 +386,7 @@ int pph_launch_mesh(pph_ctx* ctx, MeshData& mesh);
 int pph_launch_pattern(pph_ctx* ctx, int dim, int kind, int px, int py, int pz, DevBuf<int64_t>& rowptr,
                        DevBuf<int32_t>& col, int64_t* nnz_out);
 int pph_launch_assemble_KM(pph_ctx* ctx, MeshData& mesh);
+int pph_mesh_check_affine(pph_ctx* ctx, MeshData& mesh);   // sets mesh.all_affine (synchronises; mesh build only)
 int pph_launch_blocks(pph_ctx* ctx, int monolithic);
 bool pph_can_fuse_assembly(const pph_ctx* ctx);
 int pph_ensure_csr_blocks(pph_ctx* ctx);   // CSR values of A11, A22, A12 (, A21) from the stencil-ELL copies when missing

@@ -237,5 +237,6 @@ int pph_launch_mesh(pph_ctx* ctx, MeshData& mesh) {
   PPH_HIP(ctx, hipGetLastError());
   PPH_TRY(pph_launch_pattern(ctx, mesh.dim, mesh.kind, mesh.px, mesh.py, mesh.pzl, mesh.rowptr, mesh.col,
                              &mesh.nnzb));
+  PPH_TRY(pph_mesh_check_affine(ctx, mesh));
   return PPH_OK;
 }

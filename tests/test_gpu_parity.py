@@ -777,6 +777,59 @@ def test_hip_matches_cpu_port_mid_size(gpu_ctx_factory, hexa, N, norm, red):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("dim,kind,nx,ny,nz", [(2, o.CELL_QUAD, 9, 6, 0), (2, o.CELL_QUAD, 70, 33, 0), (3, o.CELL_HEX, 6, 5, 4),
+                                               (3, o.CELL_HEX, 1, 1, 1), (3, o.CELL_HEX, 35, 18, 9), (3, o.CELL_HEX, 64, 64, 64)])
+def test_node_assembly_kernel_equals_tile_kernel(gpu_ctx_factory, dim, kind, nx, ny, nz):
+    """k_asm_node (one thread per node, registers only; default on box meshes) against k_asm_tile (LDS element rows):
+    same formula per entry and the same order of every sum - what differs is the compiler's choice of multiply-add
+    contractions inside the two kernels, i.e. the last bit of some entries: operators and right-hand side equal to
+    1e-15 of the largest entry, u0 exactly, the multigrid-preconditioned Picard solve with the same sweeps and CG
+    iterations and the same solution to 1e-12; both against the oracle's matrix on the small meshes."""
+    f = _ffi()
+    om = o.build_mesh(dim, kind, nx, ny, nz) if nx * max(ny, 1) * max(nz, 1) <= 6000 else None
+    import perphil_amd.fd as fdm
+
+    mesh = fdm.UnitCubeMesh(nx, ny, nz, hexahedral=True) if dim == 3 else fdm.UnitSquareMesh(nx, ny, quadrilateral=True)
+    b = mesh.boundary_nodes()
+    g1, g2 = o.exact_pressures(mesh.node_coordinates(b), P)
+    out = []
+    for node in (1, 0):
+        ctx = gpu_ctx_factory()
+        ctx.set_option("asm_node", node)
+        ctx.set_option("asm_tile", 2)
+        ctx.mesh_build(dim, kind, nx, ny, nz)
+        ctx.set_dirichlet(0, b, g1)
+        ctx.set_dirichlet(1, b[: len(b) // 2], g2[: len(b) // 2])     # different Dirichlet sets: A21 stored on its own
+        ctx.assemble(P.k1, P.k2, P.beta, P.mu, monolithic=False)
+        mats = [ctx.csr(w) for w in (f.MAT_A11, f.MAT_A22, f.MAT_A12, f.MAT_A21)]
+        rhs, u0 = ctx.rhs()
+        xs, info, _ = ctx.solve(_cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_MG, inner_rtol=1e-10,
+                                     inner_reduction=1e-1, inner_norm=1, mg_smooth=1, picard_rtol=1e-8))
+        out.append((mats, rhs, u0, xs, (info.iterations, info.inner_iterations)))
+        ctx.close()
+    for A, B in zip(out[0][0], out[1][0]):
+        np.testing.assert_array_equal(A.indptr, B.indptr)
+        np.testing.assert_array_equal(A.indices, B.indices)
+        np.testing.assert_allclose(A.data, B.data, rtol=0, atol=1e-15 * np.abs(B.data).max())
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=0, atol=1e-15 * np.abs(out[1][1]).max())
+    np.testing.assert_array_equal(out[0][2], out[1][2])
+    np.testing.assert_allclose(out[0][3], out[1][3], rtol=0, atol=1e-12 * np.abs(out[1][3]).max())
+    assert out[0][4] == out[1][4]
+    if om is not None:
+        # the oracle with the same (differing) Dirichlet sets
+        m1, m2 = np.zeros(om.num_nodes, bool), np.zeros(om.num_nodes, bool)
+        m1[b] = True
+        m2[b[: len(b) // 2]] = True
+        e1, e2 = o.exact_pressures(om.coords, P)
+        osys = o.build_system(om, P, g1=e1, g2=e2, mms=False, mask1=m1, mask2=m2)
+        n = osys.n
+        A = osys.A.tocsr()
+        for blk, (r0, c0) in zip(out[0][0], ((0, 0), (n, n), (0, n), (n, 0))):
+            assert abs(blk - A[r0:r0 + n, c0:c0 + n]).max() <= 1e-12 * abs(A).max()
+        np.testing.assert_allclose(out[0][1], osys.rhs, rtol=0, atol=1e-12 * np.abs(osys.rhs).max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kern", [3])
 def test_spmv_long_rows_and_residual_forms(gpu_ctx_factory, kern):
     """Monolithic 3D rows (up to 54 entries) take more than one 32-entry step of the aligned-wide kernels; the
