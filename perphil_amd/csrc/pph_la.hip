@@ -185,7 +185,7 @@ static int stream_T(int max_row) {
 }
 
 #ifdef PPH_EXPERIMENTS
-#include "pph_spmv_experiments.inc"   // the A/B kernel variants of DESIGN.md section 4 (not part of the shipped library)
+#include "experiments/pph_spmv_experiments.inc"   // the A/B kernel variants of DESIGN.md section 4 (not part of the shipped library)
 #endif
 
 // Stencil-ELL product of a slab whose operand needs its ghost planes refreshed.  halo_overlap 0: exchange, then one

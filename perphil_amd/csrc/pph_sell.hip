@@ -18,6 +18,58 @@ __device__ inline double sell_wave_sum(double v) {
   return v;
 }
 
+// operands of the epilogue of a row block: requested before the matrix stream, not after the sums
+template <int MODE, int RPT, bool CLAMP>
+__device__ __forceinline__ void sell_prologue(const double* __restrict__ x, const double* __restrict__ b,
+                                              const double* __restrict__ dinv, const double* __restrict__ y,
+                                              const double* __restrict__ aux, const double* __restrict__ z0, int64_t n,
+                                              int64_t r0, double (&acc)[RPT], double (&bv)[RPT], double (&xr)[RPT],
+                                              double (&dv)[RPT], double (&tv)[RPT], double (&av)[RPT], bool (&act)[RPT]) {
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    acc[i] = 0.0; bv[i] = 0.0; xr[i] = 0.0; dv[i] = 0.0; tv[i] = 0.0; av[i] = 0.0;
+    act[i] = !CLAMP || (r0 + i < n);
+    if (act[i]) {
+      if (MODE == 1 || (MODE >= 3 && MODE <= 5) || MODE == 7) bv[i] = b[r0 + i];
+      if ((MODE >= 2 && MODE <= 4) || MODE == 7) xr[i] = x[r0 + i];
+      if (MODE == 3 || MODE == 4) dv[i] = dinv[r0 + i];
+      if (MODE == 5 || MODE == 6) { tv[i] = y[r0 + i]; av[i] = aux[r0 + i]; if (z0) dv[i] = dinv[r0 + i]; }
+    }
+  }
+}
+
+// what a mode does with the row sums acc = (A x)[r0 .. r0 + RPT) (modes: see sell_rows)
+template <int MODE, int RPT>
+__device__ __forceinline__ void sell_epilogue(const double (&acc)[RPT], const double (&bv)[RPT], const double (&xr)[RPT],
+                                              const double (&dv)[RPT], const double (&tv)[RPT], const double (&av)[RPT],
+                                              const bool (&act)[RPT], double w, double* __restrict__ y,
+                                              double* __restrict__ aux, double* __restrict__ z0, int64_t r0,
+                                              double& dotacc, int64_t dlo, int64_t dhi, double* dotx, int flags) {
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    if (!act[i]) continue;
+    const int64_t r = r0 + i;
+    if (MODE == 0) { if (flags & 1) __builtin_nontemporal_store(acc[i], y + r); else y[r] = acc[i]; }
+    else if (MODE == 1) y[r] = bv[i] - acc[i];
+    else if (MODE == 2) { y[r] = acc[i]; if (r >= dlo && r < dhi) dotacc += acc[i] * xr[i]; }   // (owned rows: ghost rows of a symmetric slab operator hold no row of this rank)
+    else if (MODE == 7) {
+      y[r] = acc[i];
+      if (r >= dlo && r < dhi) { dotacc += acc[i] * xr[i]; dotx[0] += acc[i] * bv[i]; dotx[1] += acc[i] * acc[i]; }
+    } else if (MODE >= 5) {
+      const double tn = (MODE == 5) ? bv[i] - acc[i] : acc[i];
+      const double rn = av[i] + ((MODE == 5) ? 1.0 : -1.0) * (tn - tv[i]);   // k_shift
+      aux[r] = rn;
+      y[r] = tn;
+      if (z0) z0[r] = dv[i] * rn * w;   // the next block solve's first pre-smoothing (k_cg_update_dev's order)
+      if (r >= dlo && r < dhi) dotacc += rn * rn;
+    } else {
+      const double yn = xr[i] + dv[i] * (bv[i] - acc[i]) * w;   // the order of k_cheb_init: dinv * r / theta
+      y[r] = yn;
+      if (MODE == 4 && r >= dlo && r < dhi) dotacc += bv[i] * yn;
+    }
+  }
+}
+
 // MODE 0: y = A x      1: y = b - A x      2: y = A x and per-workgroup partial sums of x.y over the rows [dlo, dhi)
 // MODE 3: y = x + w * dinv .* (b - A x)   (one damped-Jacobi / one-step Chebyshev sweep, out of place)
 // MODE 4: MODE 3 and the dot product b . y over the rows [dlo, dhi) (CG: r . z from the last kernel of the V-cycle)
@@ -39,18 +91,7 @@ __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_
   double acc[RPT];
   double bv[RPT], xr[RPT], dv[RPT], tv[RPT], av[RPT];
   bool act[RPT];
-#pragma unroll
-  for (int i = 0; i < RPT; ++i) {
-    acc[i] = 0.0; bv[i] = 0.0; xr[i] = 0.0; dv[i] = 0.0; tv[i] = 0.0; av[i] = 0.0;
-    act[i] = !CLAMP || (r0 + i < n);
-    // operands of the epilogue are requested before the matrix stream, not after the sums
-    if (act[i]) {
-      if (MODE == 1 || (MODE >= 3 && MODE <= 5) || MODE == 7) bv[i] = b[r0 + i];
-      if ((MODE >= 2 && MODE <= 4) || MODE == 7) xr[i] = x[r0 + i];
-      if (MODE == 3 || MODE == 4) dv[i] = dinv[r0 + i];
-      if (MODE == 5 || MODE == 6) { tv[i] = y[r0 + i]; av[i] = aux[r0 + i]; if (z0) dv[i] = dinv[r0 + i]; }
-    }
-  }
+  sell_prologue<MODE, RPT, CLAMP>(x, b, dinv, y, aux, z0, n, r0, acc, bv, xr, dv, tv, av, act);
   int slot = 0;
 #pragma unroll
   for (int l = 0; l < ST::NL; ++l) {
@@ -124,29 +165,7 @@ __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_
       ++slot;
     }
   }
-#pragma unroll
-  for (int i = 0; i < RPT; ++i) {
-    if (!act[i]) continue;
-    const int64_t r = r0 + i;
-    if (MODE == 0) { if (flags & 1) __builtin_nontemporal_store(acc[i], y + r); else y[r] = acc[i]; }
-    else if (MODE == 1) y[r] = bv[i] - acc[i];
-    else if (MODE == 2) { y[r] = acc[i]; if (r >= dlo && r < dhi) dotacc += acc[i] * xr[i]; }   // (owned rows: ghost rows of a symmetric slab operator hold no row of this rank)
-    else if (MODE == 7) {
-      y[r] = acc[i];
-      if (r >= dlo && r < dhi) { dotacc += acc[i] * xr[i]; dotx[0] += acc[i] * bv[i]; dotx[1] += acc[i] * acc[i]; }
-    } else if (MODE >= 5) {
-      const double tn = (MODE == 5) ? bv[i] - acc[i] : acc[i];
-      const double rn = av[i] + ((MODE == 5) ? 1.0 : -1.0) * (tn - tv[i]);   // k_shift
-      aux[r] = rn;
-      y[r] = tn;
-      if (z0) z0[r] = dv[i] * rn * w;   // the next block solve's first pre-smoothing (k_cg_update_dev's order)
-      if (r >= dlo && r < dhi) dotacc += rn * rn;
-    } else {
-      const double yn = xr[i] + dv[i] * (bv[i] - acc[i]) * w;   // the order of k_cheb_init: dinv * r / theta
-      y[r] = yn;
-      if (MODE == 4 && r >= dlo && r < dhi) dotacc += bv[i] * yn;
-    }
-  }
+  sell_epilogue<MODE, RPT>(acc, bv, xr, dv, tv, av, act, w, y, aux, z0, r0, dotacc, dlo, dhi, dotx, flags);
 }
 
 template <int KIND, int MODE, int RPT, bool SYM = false>
@@ -231,6 +250,10 @@ __global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ va
   }
 }
 
+#ifdef PPH_EXPERIMENTS
+#include "experiments/pph_sell_lds.inc"   // LDS hand-over product (option "sell_lds"; not part of the shipped library)
+#endif
+
 template <int KIND, int RPT>
 static void sell_launch_mode(pph_ctx* ctx, int mode, int grid, const Sell& E, const double* x, const double* b,
                              const double* dinv, const double* w, double* y, double* aux, double* z0, int64_t n, int64_t nchunks, int64_t chunk0,
@@ -286,6 +309,12 @@ int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x,
   // step (measured on the 256^3 block: 0.58 ms plain order, 0.51 ms z-walk with 4096 workgroups, 0.47 ms with 256;
   // profiles/r02_sell_sym_probe_256.txt, r02_sell_sym_probe2_256.txt)
   const bool zw = E.sym && E.pz > 2 && ctx->sell_zwalk > 0 && chunk0 == 0 && nchunks >= ctx->sell_zwalk_min_chunks;   // (smaller levels: too few chunks per workgroup)
+#ifdef PPH_EXPERIMENTS
+  if (zw && ctx->sell_lds && rpt == 2 && E.kind == PPH_CELL_HEX && cend < 0) {
+    const int g = sell_launch_lds(ctx, mode, E, x, b, dinv, w, y, aux, z0, n, nchunks, part, dlo, dhi);
+    if (g > 0) return g;
+  }
+#endif
   int cap = (ctx->sell_blocks >= 8 && ctx->sell_blocks <= 8192) ? (ctx->sell_blocks / 8) * 8
                                                                  : (zw ? ((ctx->num_cus + 7) / 8) * 8 : 4096);
   if ((mode == 2 || mode >= 4) && cap > PPH_PART_STRIDE) cap = PPH_PART_STRIDE;   // one partial sum per workgroup
