@@ -205,6 +205,36 @@ def parity_vs_port(ctx_solution, info, keep):
                           "each pair is [gpu, port]"}
 
 
+def api_wall(N, k1, k2, beta, mu):
+    """What a caller of the public API pays: solve_dpp_nonlinear(W, params, bcs, PICARD_MG_INEXACT_SOLVER_PARAMS) on the
+    N^3 Q1 cube through the reference's objects (mesh, spaces, DirichletBC with the manufactured pressures), protocol of
+    reference src/perphil/experiments/petsc_profiling_3d.py:73-86: one warm-up call, then one timed call (wall clock,
+    boundary-data application, assembly, solve and the copy of the solution to the host included)."""
+    import perphil_amd as pa
+    from perphil_amd import fd, solver_parameters as spar
+    from perphil_amd.manufactured_solutions import exact_expressions_3d
+
+    t0 = time.perf_counter()
+    mesh = fd.UnitCubeMesh(N, N, N, hexahedral=True)
+    V = fd.FunctionSpace(mesh, "CG", 1)
+    W = V * V
+    params = pa.DPPParameters(k1=k1, k2=k2, beta=beta, mu=mu)
+    _u1, p1e, _u2, p2e = exact_expressions_3d(mesh, params)
+    bcs = [fd.DirichletBC(W.sub(0), p1e, "on_boundary"), fd.DirichletBC(W.sub(1), p2e, "on_boundary")]
+    sol = pa.solve_dpp_nonlinear(W, params, bcs, solver_parameters=spar.PICARD_MG_INEXACT_SOLVER_PARAMS)
+    first = 1e3 * (time.perf_counter() - t0)
+    t1 = time.perf_counter()
+    sol = pa.solve_dpp_nonlinear(W, params, bcs, solver_parameters=spar.PICARD_MG_INEXACT_SOLVER_PARAMS)
+    wall = 1e3 * (time.perf_counter() - t1)
+    out = {"api_wall_ms": round(wall, 2), "api_first_call_ms": round(first, 2), "sweeps": int(sol.iteration_number),
+           "inner_cg_iterations": int(sol.info["inner_iterations"]),
+           "what": "second solve_dpp_nonlinear(W, params, bcs, PICARD_MG_INEXACT_SOLVER_PARAMS) call on the same objects: "
+                   "Dirichlet data, assembly, Picard solve, solution copied to the host; first call = objects, mesh, "
+                   "allocations and that solve"}
+    mesh.context().close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,6 +243,7 @@ def main():
     ap.add_argument("--cells", type=int, default=256, help="cells per direction of the unit cube")
     ap.add_argument("--cpu-sample-n", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-api-wall", action="store_true", help="omit the public-API wall-clock measurement (config.api)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0: cgroup share, at most 16)")
     ap.add_argument("--inner-rtol", type=float, default=1e-10)
     ap.add_argument("--smooth", type=int, default=1)
@@ -469,6 +500,8 @@ def main():
         },
         "roofline": roofline,
     }
+    if rank == 0 and world == 1 and not args.no_api_wall:
+        out["config"]["api"] = api_wall(N, k1, k2, beta, mu)
     parity_failed = False
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         keep = {}

@@ -180,6 +180,18 @@ int pph_bw_probe(pph_ctx* ctx, int64_t bytes, int mode, int blocks, double* ms_o
  * triangles / tetrahedra. */
 int pph_error_norms_mms(pph_ctx* ctx, int field, const double* nodal_host, double k1, double k2, double beta,
                         double mu, int nq, double* l2_out, double* h1s_out);
+/* The same two norms against ANY exact field, sampled by the caller at the quadrature points
+ * replaces: l2_error / h1_seminorm_error for an arbitrary UFL expression (reference src/perphil/utils/postprocessing.py:89-124:
+ * sqrt(assemble((p_h - p)^2 dx)), sqrt(assemble(|grad p_h - grad p|^2 dx))) and l2_errors_against_reference
+ * (src/perphil/experiments/iterative_bench.py:340-362).  pph_quadrature_points writes the physical coordinates of the
+ * nq^dim points of the cells [cell_begin, cell_begin + cell_count) to xq_host[((cell - cell_begin) npts + q) dim + d]
+ * (same rule and point order as pph_error_norms_mms); the caller evaluates its field (and gradient) there and
+ * pph_error_norms_sampled returns the SQUARED partial norms over those cells: exact_q_host[(cell - cell_begin) npts + q],
+ * grad_q_host[((cell - cell_begin) npts + q) dim + d]; either may be NULL (zero field / zero gradient), so the norms of
+ * a finite-element function itself come from the same call.  Chunking the cell range bounds the host arrays. */
+int pph_quadrature_points(pph_ctx* ctx, int nq, int64_t cell_begin, int64_t cell_count, double* xq_host);
+int pph_error_norms_sampled(pph_ctx* ctx, const double* nodal_host, int nq, int64_t cell_begin, int64_t cell_count,
+                            const double* exact_q_host, const double* grad_q_host, double* l2sq_out, double* h1sq_out);
 
 /* Darcy velocity u = -conductivity * grad(p_h), L2-projected onto the CG-1 vector space of the mesh
  * replaces: calculate_darcy_velocity_from_pressure() (reference src/perphil/utils/postprocessing.py:34-63,

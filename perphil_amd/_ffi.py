@@ -34,7 +34,7 @@ EXPORTS = [
     "pph_csr_sizes", "pph_get_csr", "pph_get_rhs", "pph_spmv", "pph_spmv_bench",
     "pph_get_timers", "pph_set_option", "pph_comm_set_callbacks",
     "pph_rccl_available", "pph_rccl_unique_id", "pph_comm_init_rccl", "pph_comm_selftest", "pph_comm_selftest2",
-    "pph_comm_stats", "pph_error_norms_mms", "pph_bw_probe",
+    "pph_comm_stats", "pph_error_norms_mms", "pph_quadrature_points", "pph_error_norms_sampled", "pph_bw_probe",
     "pph_darcy_velocity",
 ]
 
@@ -134,6 +134,8 @@ def _load() -> C.CDLL:
         "pph_error_norms_mms": ([p, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, f64p,
                                  f64p], C.c_int),
         "pph_darcy_velocity": ([p, C.c_void_p, C.c_double, C.c_void_p], C.c_int),
+        "pph_quadrature_points": ([p, C.c_int, C.c_int64, C.c_int64, C.c_void_p], C.c_int),
+        "pph_error_norms_sampled": ([p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, f64p, f64p], C.c_int),
     }
     for name, (argtypes, restype) in sig.items():
         fn = getattr(lib, name)  # AttributeError here = ABI mismatch: fail loudly
@@ -165,6 +167,7 @@ class Context:
         self.device = int(device)
         self.n = 0
         self.dim = 0
+        self._bc_state = {}
 
     # -- plumbing -----------------------------------------------------------------------------
     def _check(self, st: int, allow_diverged: bool = False) -> int:
@@ -211,6 +214,7 @@ class Context:
         n, nc, m, nnz = C.c_int64(), C.c_int64(), C.c_int32(), C.c_int64()
         self._check(lib.pph_mesh_sizes(self._h, C.byref(n), C.byref(nc), C.byref(m), C.byref(nnz)))
         self.n, self.ncell, self.m, self.nnzb, self.dim = n.value, nc.value, m.value, nnz.value, dim
+        self._bc_state = {}
 
     def dofmap(self) -> np.ndarray:
         out = np.empty((self.ncell, self.m), dtype=np.int32)
@@ -229,6 +233,14 @@ class Context:
         if nodes.shape != vals.shape:
             raise ValueError("nodes and vals must have the same shape")
         self._check(lib.pph_set_dirichlet(self._h, int(field), _ptr(nodes), _ptr(vals), nodes.size))
+        self._bc_state[int(field)] = (nodes.copy(), vals.copy())
+
+    def same_dirichlet(self, field: int, nodes: np.ndarray, vals: np.ndarray) -> bool:
+        """True when exactly this set (nodes and values) is what the device holds for `field` (callers skip the
+        upload then: pph_set_dirichlet drops the assembled system and makes the multigrid levels re-derive their masks)."""
+        old = self._bc_state.get(int(field))
+        return (old is not None and np.array_equal(old[0], np.asarray(nodes, dtype=np.int64))
+                and np.array_equal(old[1], np.asarray(vals, dtype=np.float64)))
 
     def assemble(self, k1: float, k2: float, beta: float, mu: float, monolithic: bool = True) -> None:
         self._check(lib.pph_assemble_dpp(self._h, float(k1), float(k2), float(beta), float(mu), int(monolithic)))
@@ -288,6 +300,45 @@ class Context:
         self._check(lib.pph_error_norms_mms(self._h, int(field), _ptr(nodal), float(k1), float(k2), float(beta), float(mu),
                                             int(nq), C.byref(l2), C.byref(h1)))
         return l2.value, h1.value
+
+    def quadrature_points(self, nq: int, cell_begin: int, cell_count: int) -> np.ndarray:
+        """Physical coordinates [cell_count * nq**dim, dim] of the Gauss points of a cell range (pph_quadrature_points)."""
+        npts = nq ** self.dim
+        out = np.empty((cell_count * npts, self.dim), dtype=np.float64)
+        self._check(lib.pph_quadrature_points(self._h, int(nq), int(cell_begin), int(cell_count), _ptr(out)))
+        return out
+
+    def error_norms_sampled(self, nodal: np.ndarray, exact, grad=None, nq: int = 6, chunk_cells: int = 1 << 16):
+        """(L2 error, H1-seminorm error) of a nodal CG-1 field against `exact`, a callable of point arrays [m, dim] -> [m]
+        (None: the zero field), with `grad` its gradient callable [m, dim] -> [m, dim] (None: central differences of
+        `exact` with step 1e-6).  The cells are processed in chunks: points out, samples in."""
+        nodal = np.ascontiguousarray(nodal, dtype=np.float64)
+        if nodal.shape != (self.n,):
+            raise ValueError("nodal array must have one value per mesh vertex")
+        l2, h1 = 0.0, 0.0
+        a, b = C.c_double(), C.c_double()
+        for c0 in range(0, self.ncell, chunk_cells):
+            cnt = min(chunk_cells, self.ncell - c0)
+            se = sg = None
+            if exact is not None:
+                X = self.quadrature_points(nq, c0, cnt)
+                se = np.ascontiguousarray(exact(X), dtype=np.float64).reshape(-1)
+                if grad is not None:
+                    sg = np.ascontiguousarray(grad(X), dtype=np.float64).reshape(-1, self.dim)
+                else:
+                    h = 1e-6
+                    sg = np.empty_like(X)
+                    for d in range(self.dim):
+                        E = np.zeros(self.dim)
+                        E[d] = h
+                        sg[:, d] = (np.asarray(exact(X + E), dtype=np.float64).reshape(-1)
+                                    - np.asarray(exact(X - E), dtype=np.float64).reshape(-1)) / (2 * h)
+                    sg = np.ascontiguousarray(sg)
+            self._check(lib.pph_error_norms_sampled(self._h, _ptr(nodal), int(nq), int(c0), int(cnt), _ptr(se), _ptr(sg),
+                                                    C.byref(a), C.byref(b)))
+            l2 += a.value
+            h1 += b.value
+        return float(np.sqrt(l2)), float(np.sqrt(h1))
 
     def darcy_velocity(self, nodal: np.ndarray, conductivity: float) -> np.ndarray:
         """L2 projection of -conductivity * grad(p_h) onto CG-1 vectors; returns [n, dim]."""

@@ -86,18 +86,35 @@ def assemble_bilinear_form(form, boundary_conditions: List[fd.DirichletBC]):
     return get_matrix_data_from_form(form, boundary_conditions).sparse_csr_data
 
 
-def _extreme_singular_values(A: csr_matrix):
-    """sigma_max and sigma_min by ARPACK without the full spectrum: largest singular value from svds, smallest from
-    the shift-inverted normal equations (a sparse LU of A^T A around 0); dense SVD when ARPACK does not converge."""
-    from scipy.sparse.linalg import ArpackError, ArpackNoConvergence, eigsh, svds
+def _dense_singular_values(A: csr_matrix) -> np.ndarray:
+    return np.linalg.svd(A.toarray(), compute_uv=False)
 
-    smax = float(svds(A.astype(np.float64), k=1, which="LM", return_singular_vectors=False, maxiter=10000)[0])
+
+def _extreme_singular_values(A: csr_matrix):
+    """sigma_max and sigma_min without the full spectrum, in the order of the reference's sparse branch
+    (conditioning.py:155-205): sigma_max from ARPACK `svds(which="LM")`; sigma_min from `svds(which="SM", tol=1e-8)`,
+    failing that from the smallest eigenvalue of the normal equations A^T A (`eigsh(which="SM")`), failing that from a
+    dense SVD - and any failure of the sigma_max call falls back to a dense SVD as well.  Returns (nan, None) semantics
+    like the reference: sigma_min None when every route failed."""
+    from scipy.sparse.linalg import eigsh, svds
+
+    A = A.astype(np.float64)
     try:
-        AtA = (A.T @ A).tocsc()
-        lam = eigsh(AtA, k=1, sigma=0.0, which="LM", return_eigenvectors=False, maxiter=20000)[0]
-        smin = float(np.sqrt(max(lam, 0.0)))
-    except (ArpackError, ArpackNoConvergence, RuntimeError):
-        smin = float(np.linalg.svd(A.toarray(), compute_uv=False).min())
+        smax = float(np.max(svds(A, k=1, which="LM", maxiter=10000, return_singular_vectors=False, solver="arpack")))
+    except Exception:
+        sv = _dense_singular_values(A)
+        smax = float(sv.max()) if sv.size else float("nan")
+    smin = None
+    try:
+        smin = float(np.min(svds(A, k=1, which="SM", maxiter=20000, return_singular_vectors=False, solver="arpack", tol=1e-8)))
+    except Exception:
+        try:
+            lam = eigsh((A.T @ A), k=1, which="SM", return_eigenvectors=False)
+            smin = float(np.sqrt(max(float(lam[0]), 0.0)))
+        except Exception:
+            sv = _dense_singular_values(A)
+            if sv.size:
+                smin = float(sv.min())
     return smax, smin
 
 
@@ -115,7 +132,7 @@ def calculate_condition_number(scipy_csr_sparse_matrix: csr_matrix, num_singular
         return float("nan")
     if use_sparse and k is not None and 0 < int(k) < nmin - 1:
         smax, smin = _extreme_singular_values(csr_matrix(A))
-        if not np.isfinite(smax):
+        if smin is None or not np.isfinite(smax):
             return float("nan")
         return float("inf") if smin <= zero_tol else float(smax / smin)
     s = np.linalg.svd(A.toarray() if hasattr(A, "toarray") else np.asarray(A), compute_uv=False)

@@ -359,6 +359,7 @@ int pph_assemble_dpp(pph_ctx* ctx, double k1, double k2, double beta, double mu,
 // ---- export -------------------------------------------------------------------------------------
 static int select_csr(pph_ctx* ctx, int which, Csr* A) {
   PPH_REQUIRE(ctx, ctx->mesh_ok, "no mesh");
+  PPH_TRY(pph_ensure_pattern(ctx, ctx->mesh));   // (exports are CSR)
   const MeshData& m = ctx->mesh;
   A->rowptr = m.rowptr.p; A->col = m.col.p; A->nrows = m.n; A->nnz = m.nnzb;
   A->lanes = pph_pick_lanes(ctx, A->nnz, A->nrows);

@@ -1097,6 +1097,7 @@ __global__ __launch_bounds__(256) void k_asm_simplex_gather(const int32_t* __res
 }
 
 int pph_launch_assemble_KM(pph_ctx* ctx_, MeshData& mesh) {
+  PPH_TRY(pph_ensure_pattern(ctx_, mesh));
   pph_ctx* ctx = ctx_;
   PPH_TRY(mesh.K.alloc(ctx, (size_t)mesh.nnzb));
   PPH_TRY(mesh.M.alloc(ctx, (size_t)mesh.nnzb));
@@ -1200,21 +1201,21 @@ int pph_launch_assemble_KM(pph_ctx* ctx_, MeshData& mesh) {
 // rownear[row] = 1 when the row is constrained / ghost in either field or one of its columns is constrained:
 // only those rows need the masks in k_blocks and have a non-zero lifting term.  Depends on the pattern and the
 // Dirichlet sets only, so it is rebuilt when they change, not per assembly.
-__global__ __launch_bounds__(256) void k_row_near(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                  const uint8_t* __restrict__ m1, const uint8_t* __restrict__ m2, int64_t n,
-                                                  uint8_t* __restrict__ rownear) {
-  const int sub = threadIdx.x % 8;
-  for (int64_t row = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / 8; row < n;
-       row += ((int64_t)gridDim.x * blockDim.x) / 8) {
+__global__ __launch_bounds__(256) void k_row_near(Stencil st, int px, int py, int pz, const uint8_t* __restrict__ m1,
+                                                  const uint8_t* __restrict__ m2, int64_t n, uint8_t* __restrict__ rownear) {
+  // (walks the stencil of the row's node: the columns of its CSR row, without the CSR pattern)
+  for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < n; row += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(row % px);
+    const int64_t t = row / px;
+    const int j = (int)(t % py), k = (int)(t / py);
     int f = (m1[row] | m2[row]) != 0;
-    for (int64_t k = rowptr[row] + sub; k < rowptr[row + 1]; k += 8) {
-      const int32_t j = col[k];
-      f |= ((m1[j] | m2[j]) & 1) != 0;
+    for (int q = 0; q < st.count; ++q) {
+      const int ii = i + st.d[q][0], jj = j + st.d[q][1], kk = k + st.d[q][2];
+      if (ii < 0 || ii >= px || jj < 0 || jj >= py || kk < 0 || kk >= pz) continue;
+      const int64_t c = ii + (int64_t)px * (jj + (int64_t)py * kk);
+      f |= ((m1[c] | m2[c]) & 1) != 0;
     }
-    f |= __shfl_down(f, 4, 8);
-    f |= __shfl_down(f, 2, 8);
-    f |= __shfl_down(f, 1, 8);
-    if (sub == 0) rownear[row] = (uint8_t)f;
+    rownear[row] = (uint8_t)f;
   }
 }
 
@@ -1423,12 +1424,10 @@ static int blocks_prepare(pph_ctx* ctx, bool want_csr) {
     PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->a21_alias = (h == 0);
     PPH_TRY(ctx->rownear.alloc(ctx, (size_t)n));
-    int64_t nbn = ceil_div64(n * 8, 256);
-    hipLaunchKernelGGL(k_row_near, dim3((int)(nbn < 4096 ? nbn : 4096)), dim3(256), 0, ctx->stream, ctx->mesh.rowptr.p,
-                       ctx->mesh.col.p, ctx->bcmask[0].p, ctx->bcmask[1].p, n, ctx->rownear.p);
+    pph_launch_row_near(ctx, ctx->mesh, ctx->bcmask[0].p, ctx->bcmask[1].p, ctx->rownear.p);
     ctx->bc_dirty = false;
   }
-  if (want_csr) PPH_TRY(blocks_alloc_csr(ctx));
+  if (want_csr) { PPH_TRY(pph_ensure_pattern(ctx, ctx->mesh)); PPH_TRY(blocks_alloc_csr(ctx)); }
   PPH_TRY(ctx->rhs.alloc(ctx, (size_t)(2 * n)));
   PPH_TRY(ctx->u0.alloc(ctx, (size_t)(2 * n)));
   PPH_TRY(ctx->sol.alloc(ctx, (size_t)(2 * n)));
@@ -1461,6 +1460,7 @@ static int blocks_mono(pph_ctx* ctx, int monolithic) {
 int pph_ensure_csr_blocks(pph_ctx* ctx) {
   if (ctx->csr_ok) return PPH_OK;
   PPH_REQUIRE(ctx, ctx->ell_ok, "blocks not assembled");
+  PPH_TRY(pph_ensure_pattern(ctx, ctx->mesh));
   PPH_TRY(blocks_alloc_csr(ctx));
   PPH_TRY(sell_to_csr(ctx, ctx->mesh, ctx->S11, ctx->A11.p));
   PPH_TRY(sell_to_csr(ctx, ctx->mesh, ctx->S22, ctx->A22.p));
@@ -2287,6 +2287,12 @@ bool pph_can_fuse_assembly(const pph_ctx* ctx) {
 // element rows (multilinear cells) + the fused node-centred pass on any level mesh
 int pph_launch_fused_kernels(pph_ctx* ctx, MeshData& mesh, const FuseArgs& fa, double* Kp, double* Mp) {
   const bool multilinear = (mesh.kind == PPH_CELL_QUAD || mesh.kind == PPH_CELL_HEX);
+  // CSR positions are needed for CSR output and for K / M; the simplex and two-pass gather kernels also walk the
+  // pattern's columns (the node and tile kernels address neighbours in closed form)
+  const bool closed_form = multilinear && ctx->asm_tile && !ctx->asm_ring &&
+                           ((ctx->asm_node && ctx->asm_affine && mesh.all_affine && !ctx->asm_tile_probe) ||
+                            ctx->asm_tile == 2 || mesh.n >= ctx->asm_tile_min_nodes);
+  if (fa.ld == 0 || fa.keep_km || !closed_form) PPH_TRY(pph_ensure_pattern(ctx, mesh));
   if (!multilinear) {
     int64_t nbs = ceil_div64(mesh.n, 256);
     const int gs = (int)(nbs < 256 * 32 ? nbs : 256 * 32);
@@ -2405,9 +2411,9 @@ int pph_launch_level_operators(pph_ctx* ctx, MeshData& mesh, const uint8_t* m1, 
 }
 
 void pph_launch_row_near(pph_ctx* ctx, const MeshData& mesh, const uint8_t* m1, const uint8_t* m2, uint8_t* out) {
-  int64_t nbn = ceil_div64(mesh.n * 8, 256);
-  hipLaunchKernelGGL(k_row_near, dim3((int)(nbn < 4096 ? nbn : 4096)), dim3(256), 0, ctx->stream, mesh.rowptr.p, mesh.col.p,
-                     m1, m2, mesh.n, out);
+  const int64_t nbn = ceil_div64(mesh.n, 256);
+  hipLaunchKernelGGL(k_row_near, dim3((int)(nbn < 4096 ? (nbn < 1 ? 1 : nbn) : 4096)), dim3(256), 0, ctx->stream,
+                     make_stencil(mesh.kind), mesh.px, mesh.py, mesh.pzl, m1, m2, mesh.n, out);
 }
 
 int pph_launch_assemble_fused(pph_ctx* ctx, int monolithic) {

@@ -42,24 +42,24 @@ __global__ __launch_bounds__(256) void k_ilu_diag(const int64_t* __restrict__ ro
 __global__ __launch_bounds__(128) void k_ilu_factor(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                     double* lu, const int64_t* __restrict__ diag,
                                                     const int32_t* __restrict__ perm, int64_t lo, int64_t hi) {
-  const int64_t t = lo + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (t >= hi) return;
-  const int64_t r = perm[t];
-  const int64_t rs = rowptr[r], re = rowptr[r + 1], rd = diag[r];
-  for (int64_t kk = rs; kk < rd; ++kk) {
-    const int64_t c = col[kk];
-    const double dc = lu[diag[c]];
-    if (dc == 0.0) continue;             // empty (ghost) row: nothing to eliminate with
-    const double piv = lu[kk] / dc;
-    lu[kk] = piv;
-    if (piv == 0.0) continue;
-    // row c beyond its diagonal against row r beyond kk: both sorted - merge
-    int64_t jr = kk + 1;
-    for (int64_t jc = diag[c] + 1; jc < rowptr[c + 1]; ++jc) {
-      const int32_t cj = col[jc];
-      while (jr < re && col[jr] < cj) ++jr;
-      if (jr == re) break;
-      if (col[jr] == cj) lu[jr] -= piv * lu[jc];
+  for (int64_t t = lo + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < hi; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = perm[t];
+    const int64_t rs = rowptr[r], re = rowptr[r + 1], rd = diag[r];
+    for (int64_t kk = rs; kk < rd; ++kk) {
+      const int64_t c = col[kk];
+      const double dc = lu[diag[c]];
+      if (dc == 0.0) continue;             // empty (ghost) row: nothing to eliminate with
+      const double piv = lu[kk] / dc;
+      lu[kk] = piv;
+      if (piv == 0.0) continue;
+      // row c beyond its diagonal against row r beyond kk: both sorted - merge
+      int64_t jr = kk + 1;
+      for (int64_t jc = diag[c] + 1; jc < rowptr[c + 1]; ++jc) {
+        const int32_t cj = col[jc];
+        while (jr < re && col[jr] < cj) ++jr;
+        if (jr == re) break;
+        if (col[jr] == cj) lu[jr] -= piv * lu[jc];
+      }
     }
   }
 }
@@ -69,26 +69,27 @@ __global__ __launch_bounds__(128) void k_ilu_lsolve(const int64_t* __restrict__ 
                                                     const double* __restrict__ lu, const int64_t* __restrict__ diag,
                                                     const int32_t* __restrict__ perm, int64_t lo, int64_t hi,
                                                     const double* __restrict__ b, double* y) {
-  const int64_t t = lo + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (t >= hi) return;
-  const int64_t r = perm[t];
-  double s = b[r];
-  for (int64_t kk = rowptr[r]; kk < diag[r]; ++kk) s -= lu[kk] * y[col[kk]];
-  y[r] = s;
+  // (grid-stride: a level wider than the capped grid is still swept completely; rows of one level are independent)
+  for (int64_t t = lo + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < hi; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = perm[t];
+    double s = b[r];
+    for (int64_t kk = rowptr[r]; kk < diag[r]; ++kk) s -= lu[kk] * y[col[kk]];
+    y[r] = s;
+  }
 }
 
 // x = U^-1 y on the rows of one level (x and y may be the same vector)
 __global__ __launch_bounds__(128) void k_ilu_usolve(const int64_t* __restrict__ rowptr, const int32_t* __restrict__ col,
                                                     const double* __restrict__ lu, const int64_t* __restrict__ diag,
                                                     const int32_t* __restrict__ perm, int64_t lo, int64_t hi, double* x) {
-  const int64_t t = lo + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (t >= hi) return;
-  const int64_t r = perm[t];
-  double s = x[r];
-  const int64_t d = diag[r];
-  for (int64_t kk = d + 1; kk < rowptr[r + 1]; ++kk) s -= lu[kk] * x[col[kk]];
-  const double dd = lu[d];
-  x[r] = (dd != 0.0) ? s / dd : s;       // empty (ghost) rows: identity
+  for (int64_t t = lo + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < hi; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = perm[t];
+    double s = x[r];
+    const int64_t d = diag[r];
+    for (int64_t kk = d + 1; kk < rowptr[r + 1]; ++kk) s -= lu[kk] * x[col[kk]];
+    const double dd = lu[d];
+    x[r] = (dd != 0.0) ? s / dd : s;       // empty (ghost) rows: identity
+  }
 }
 
 static inline int ilu_grid(int64_t n, int threads) {

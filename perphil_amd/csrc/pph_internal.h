@@ -164,6 +164,7 @@ struct MeshData {
   int64_t n = 0, ncell = 0, nnzb = 0;   // nodes, cells, nnz of one scalar block
   int max_row = 0;                      // stencil size = longest row of the scalar pattern
   bool km_valid = false;                // K and M hold the integrals of this mesh
+  bool pattern_ok = false;              // rowptr / col hold the scalar CSR pattern (built on demand: pph_ensure_pattern)
   bool all_affine = false;              // multilinear cells: every cell has equal parallel edges (exact test at mesh build)
   DevBuf<double> cx, cy, cz;            // nodal coordinates (SoA)
   DevBuf<int32_t> cells;                // cell -> dof map [ncell][m]
@@ -387,6 +388,7 @@ int pph_launch_mesh(pph_ctx* ctx, MeshData& mesh);
 int pph_launch_pattern(pph_ctx* ctx, int dim, int kind, int px, int py, int pz, DevBuf<int64_t>& rowptr,
                        DevBuf<int32_t>& col, int64_t* nnz_out);
 int pph_launch_assemble_KM(pph_ctx* ctx, MeshData& mesh);
+int pph_ensure_pattern(pph_ctx* ctx, MeshData& mesh);       // scalar CSR pattern on demand (synchronises when it builds)
 int pph_mesh_check_affine(pph_ctx* ctx, MeshData& mesh);   // sets mesh.all_affine (synchronises; mesh build only)
 int pph_launch_blocks(pph_ctx* ctx, int monolithic);
 bool pph_can_fuse_assembly(const pph_ctx* ctx);
@@ -396,7 +398,7 @@ int pph_launch_assemble_fused(pph_ctx* ctx, int monolithic);
 int pph_launch_level_operators(pph_ctx* ctx, MeshData& mesh, const uint8_t* m1, const uint8_t* m2, const uint8_t* near,
                                int same, double coefK1, double coefK2, double coefM, double* A1, double* A2,
                                double* dinv1, double* dinv2, unsigned long long* lam, int64_t ell_ld, int ell_sym);
-void pph_launch_row_near(pph_ctx* ctx, const MeshData& mesh, const uint8_t* m1, const uint8_t* m2, uint8_t* out);
+void pph_launch_row_near(pph_ctx* ctx, const MeshData& mesh, const uint8_t* m1, const uint8_t* m2, uint8_t* out);   // (stencil walk: no CSR pattern)
 
 // linear algebra on the context stream; all results that feed control flow go through ctx->scal
 void la_spmv(pph_ctx* ctx, const Csr& A, const double* x, double* y);
@@ -439,7 +441,7 @@ int la_reduce_device(pph_ctx* ctx, int slot, int count);
 int la_fetch_raw(pph_ctx* ctx, int slot, int count);
 void la_cg_update_dev(pph_ctx* ctx, double* x, double* r, const double* p, const double* q, int slot_num, int slot_den,
                       int64_t n, int slot_out, Seg sg, double* z0 = nullptr, const double* dinv0 = nullptr,
-                      const double* w0 = nullptr);
+                      const double* w0 = nullptr, int slot_bad = -1);   // slot_bad >= 0: scal[slot_bad] += 1 when p.Ap is 0 / NaN
 void la_p_update_dev(pph_ctx* ctx, double* p, const double* z, int slot_num, int slot_den, int64_t n);
 void la_shift(pph_ctx* ctx, double* R, double* told, const double* tnew, double sign, int64_t n);  // R += sign (tnew - told); told = tnew
 void la_block2_apply(pph_ctx* ctx, double* z, const double* binv /*[4][n]*/, const double* r, int64_t n);

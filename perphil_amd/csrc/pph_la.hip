@@ -825,9 +825,14 @@ __global__ __launch_bounds__(256) void k_cg_update_dev(double* __restrict__ x, d
                                                        const double* __restrict__ num, const double* __restrict__ den,
                                                        int64_t n, Seg sg, double* __restrict__ part,
                                                        double* __restrict__ z0, const double* __restrict__ dinv0,
-                                                       const double* __restrict__ w0p) {
+                                                       const double* __restrict__ w0p, double* bad) {
   __shared__ double lds[4];
-  const double alpha = *num / *den;
+  // p.Ap = 0 or not a number (a zero block residual, a breakdown): no update instead of NaNs in x and r, and a count in
+  // *bad for the host - the launch-only sweeps (cg_solve_fixed) see no scalar of this solve otherwise
+  const double dn = *den;
+  const bool okd = dn > 0.0 || dn < 0.0;
+  const double alpha = okd ? *num / dn : 0.0;
+  if (bad && !okd && blockIdx.x == 0 && threadIdx.x == 0) *bad += 1.0;
   const double w0 = z0 ? *w0p : 0.0;
   double a = 0.0;
   EW_LOOP(i, n) {
@@ -842,19 +847,20 @@ __global__ __launch_bounds__(256) void k_cg_update_dev(double* __restrict__ x, d
 }
 
 void la_cg_update_dev(pph_ctx* ctx, double* x, double* r, const double* p, const double* q, int slot_num, int slot_den,
-                      int64_t n, int slot_out, Seg sg, double* z0, const double* dinv0, const double* w0) {
+                      int64_t n, int slot_out, Seg sg, double* z0, const double* dinv0, const double* w0, int slot_bad) {
   double* part = partials(ctx);
   int grid = ew_grid(n);
   if (grid > RED_BLOCKS) grid = RED_BLOCKS;
   hipLaunchKernelGGL(k_cg_update_dev, dim3(grid), dim3(256), 0, ctx->stream, x, r, p, q, ctx->scal.p + slot_num,
-                     ctx->scal.p + slot_den, n, sg, part, z0, dinv0, w0);
+                     ctx->scal.p + slot_den, n, sg, part, z0, dinv0, w0, slot_bad >= 0 ? ctx->scal.p + slot_bad : (double*)nullptr);
   hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, ctx->stream, part, grid, ctx->scal.p + slot_out);
 }
 
 // p = z + beta p with beta = *num / *den read on the device
 __global__ void k_p_update_dev(double* __restrict__ p, const double* __restrict__ z, const double* __restrict__ num,
                                const double* __restrict__ den, int64_t n) {
-  const double beta = *num / *den;
+  const double dn = *den;
+  const double beta = (dn > 0.0 || dn < 0.0) ? *num / dn : 0.0;   // (r.z = 0: restart the direction, see k_cg_update_dev)
   EW_LOOP(i, n) p[i] = z[i] + beta * p[i];
 }
 

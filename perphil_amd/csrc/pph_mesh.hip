@@ -235,8 +235,37 @@ int pph_launch_mesh(pph_ctx* ctx, MeshData& mesh) {
   hipLaunchKernelGGL(k_dofmap, dim3(grid_for(nbox)), dim3(256), 0, ctx->stream, mesh.cells.p, mesh.kind, mesh.nx,
                      mesh.ny, mesh.dim == 3 ? mesh.nzl : 0, mesh.px, mesh.py);
   PPH_HIP(ctx, hipGetLastError());
-  PPH_TRY(pph_launch_pattern(ctx, mesh.dim, mesh.kind, mesh.px, mesh.py, mesh.pzl, mesh.rowptr, mesh.col,
-                             &mesh.nnzb));
+  // The CSR pattern (int64 row pointers + int32 columns: 1.8 GB at 256^3) is built when something asks for it
+  // (pph_ensure_pattern: CSR exports, the monolithic system, ILU(0), the two-step path, op_format 0); the default path -
+  // fused assembly into stencil-ELL operators, products and multigrid on them - never reads it.  Its size in closed
+  // form: every stencil offset (dx,dy,dz) contributes the nodes whose neighbour lies inside the box.
+  {
+    const Stencil st = make_stencil(mesh.kind);
+    int64_t nnz = 0;
+    for (int q = 0; q < st.count; ++q) {
+      const int64_t ax = mesh.px - (st.d[q][0] < 0 ? -st.d[q][0] : st.d[q][0]);
+      const int64_t ay = mesh.py - (st.d[q][1] < 0 ? -st.d[q][1] : st.d[q][1]);
+      const int64_t az = mesh.pzl - (st.d[q][2] < 0 ? -st.d[q][2] : st.d[q][2]);
+      if (ax > 0 && ay > 0 && az > 0) nnz += ax * ay * az;
+    }
+    mesh.nnzb = nnz;
+    mesh.pattern_ok = false;
+    mesh.rowptr.release();
+    mesh.col.release();
+  }
   PPH_TRY(pph_mesh_check_affine(ctx, mesh));
+  return PPH_OK;
+}
+
+// scalar CSR pattern of `mesh` on demand (see pph_launch_mesh)
+int pph_ensure_pattern(pph_ctx* ctx, MeshData& mesh) {
+  if (mesh.pattern_ok) return PPH_OK;
+  PPH_REQUIRE(ctx, mesh.nnzb > 0 && mesh.nnzb < (int64_t)2147483647,
+              "scalar block of %lld entries: beyond the int32 positions of the CSR pattern (the stencil-ELL path has no such limit)",
+              (long long)mesh.nnzb);
+  int64_t nnz = 0;
+  PPH_TRY(pph_launch_pattern(ctx, mesh.dim, mesh.kind, mesh.px, mesh.py, mesh.pzl, mesh.rowptr, mesh.col, &nnz));
+  PPH_REQUIRE(ctx, nnz == mesh.nnzb, "CSR pattern holds %lld entries, closed form says %lld", (long long)nnz, (long long)mesh.nnzb);
+  mesh.pattern_ok = true;
   return PPH_OK;
 }

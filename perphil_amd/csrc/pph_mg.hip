@@ -537,6 +537,7 @@ int mg_setup(pph_ctx* ctx) {
       if (build) PPH_TRY(pph_launch_mesh(ctx, m));
       // level operators straight from the element rows (fused pass) or from K, M of this level (two-step path)
       const bool fuse_lv = pph_can_fuse_assembly(ctx);
+      if (!(use_ell && fuse_lv)) PPH_TRY(pph_ensure_pattern(ctx, m));   // CSR level operators: the pattern of this level
       if (!fuse_lv && !m.km_valid) {
         PPH_TRY(pph_launch_assemble_KM(ctx, m));
         m.km_valid = true;

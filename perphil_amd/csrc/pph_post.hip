@@ -19,16 +19,23 @@ struct MmsPar {
   double mu;
 };
 
-template <int DIM>
+// SRC 0: the manufactured pressure in closed form (MmsPar).  SRC 1: the exact field sampled by the caller at the
+// quadrature points of the cells [c0, c1) - se[(cell - c0) npts + q] and, when sg != null, its gradient
+// sg[((cell - c0) npts + q) DIM + d]; se == null: the exact field is zero (norms of the finite-element function itself).
+// SRC 2: no sums - the physical coordinates of those quadrature points to xout[((cell - c0) npts + q) DIM + d].
+struct ErrSamples { const double* se; const double* sg; double* xout; int64_t c0, c1; };
+
+template <int DIM, int SRC = 0>
 __global__ __launch_bounds__(256) void k_error_norms(const int32_t* __restrict__ cells, const double* __restrict__ cx,
                                                      const double* __restrict__ cy, const double* __restrict__ cz,
                                                      const double* __restrict__ u, GaussRule g, MmsPar p,
-                                                     int64_t ncell, double* __restrict__ part) {
+                                                     int64_t ncell, double* __restrict__ part, ErrSamples es = ErrSamples()) {
   constexpr int NB = 1 << DIM;
   __shared__ double lds[4];
   const double PI = 3.14159265358979323846;
   double l2 = 0.0, h1 = 0.0;
-  for (int64_t cell = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; cell < ncell;
+  const int64_t cbeg = SRC ? es.c0 : 0, cend = SRC ? es.c1 : ncell;
+  for (int64_t cell = cbeg + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; cell < cend;
        cell += (int64_t)gridDim.x * blockDim.x) {
     double X[NB][DIM], U[NB];
 #pragma unroll
@@ -111,19 +118,35 @@ __global__ __launch_bounds__(256) void k_error_norms(const int32_t* __restrict__
         I[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) * r;
       }
       // exact pressure and gradient
-      const double ex = exp(PI * xq[0]);
-      double S = sin(PI * xq[1]), E = exp(p.eta * xq[1]);
-      double pe, ge[DIM];
-      if constexpr (DIM == 3) {
-        const double Sz = sin(PI * xq[2]), Ez = exp(p.eta * xq[2]);
-        pe = p.mu_over_pi * ex * (S + Sz) + p.coef_e * (E + Ez);
-        ge[0] = p.mu * ex * (S + Sz);
-        ge[1] = p.mu * ex * cos(PI * xq[1]) + p.coef_e * p.eta * E;
-        ge[2] = p.mu * ex * cos(PI * xq[2]) + p.coef_e * p.eta * Ez;
+      double pe = 0.0, ge[DIM];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) ge[d] = 0.0;
+      if constexpr (SRC == 2) {
+        const int64_t o = ((cell - es.c0) * npts + q) * DIM;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) es.xout[o + d] = xq[d];
+        continue;
+      } else if constexpr (SRC == 1) {
+        const int64_t o = (cell - es.c0) * npts + q;
+        if (es.se) pe = es.se[o];
+        if (es.sg) {
+#pragma unroll
+          for (int d = 0; d < DIM; ++d) ge[d] = es.sg[o * DIM + d];
+        }
       } else {
-        pe = p.mu_over_pi * ex * S + p.coef_e * E;
-        ge[0] = p.mu * ex * S;
-        ge[1] = p.mu * ex * cos(PI * xq[1]) + p.coef_e * p.eta * E;
+        const double ex = exp(PI * xq[0]);
+        double S = sin(PI * xq[1]), E = exp(p.eta * xq[1]);
+        if constexpr (DIM == 3) {
+          const double Sz = sin(PI * xq[2]), Ez = exp(p.eta * xq[2]);
+          pe = p.mu_over_pi * ex * (S + Sz) + p.coef_e * (E + Ez);
+          ge[0] = p.mu * ex * (S + Sz);
+          ge[1] = p.mu * ex * cos(PI * xq[1]) + p.coef_e * p.eta * E;
+          ge[2] = p.mu * ex * cos(PI * xq[2]) + p.coef_e * p.eta * Ez;
+        } else {
+          pe = p.mu_over_pi * ex * S + p.coef_e * E;
+          ge[0] = p.mu * ex * S;
+          ge[1] = p.mu * ex * cos(PI * xq[1]) + p.coef_e * p.eta * E;
+        }
       }
       const double wd = w * fabs(det);
       const double du = uh - pe;
@@ -159,16 +182,17 @@ __global__ __launch_bounds__(256) void k_error_norms(const int32_t* __restrict__
 
 // P1 simplices (left-diagonal triangles, Kuhn tetrahedra): constant gradient of p_h per cell; quadrature by the
 // collapsed (Duffy) tensor Gauss rule: lambda_1 = u, lambda_2 = v (1 - u), lambda_3 = w (1 - u)(1 - v) on [0,1]^d.
-template <int DIM>
+template <int DIM, int SRC = 0>
 __global__ __launch_bounds__(256) void k_error_norms_simplex(const int32_t* __restrict__ cells, const double* __restrict__ cx,
                                                              const double* __restrict__ cy, const double* __restrict__ cz,
                                                              const double* __restrict__ u, GaussRule g, MmsPar p,
-                                                             int64_t ncell, double* __restrict__ part) {
+                                                             int64_t ncell, double* __restrict__ part, ErrSamples es = ErrSamples()) {
   constexpr int NB = DIM + 1;
   __shared__ double lds[4];
   const double PI = 3.14159265358979323846;
   double l2 = 0.0, h1 = 0.0;
-  for (int64_t cell = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; cell < ncell;
+  const int64_t cbeg = SRC ? es.c0 : 0, cend = SRC ? es.c1 : ncell;
+  for (int64_t cell = cbeg + blockIdx.x * (int64_t)blockDim.x + threadIdx.x; cell < cend;
        cell += (int64_t)gridDim.x * blockDim.x) {
     double X[NB][DIM], U[NB];
 #pragma unroll
@@ -222,19 +246,35 @@ __global__ __launch_bounds__(256) void k_error_norms_simplex(const int32_t* __re
 #pragma unroll
         for (int d = 0; d < DIM; ++d) xq[d] += lam[r] * E[r][d];
       }
-      const double ex = exp(PI * xq[0]);
-      const double S = sin(PI * xq[1]), Ey = exp(p.eta * xq[1]);
-      double pe, ge[DIM];
-      if constexpr (DIM == 3) {
-        const double Sz = sin(PI * xq[2]), Ez = exp(p.eta * xq[2]);
-        pe = p.mu_over_pi * ex * (S + Sz) + p.coef_e * (Ey + Ez);
-        ge[0] = p.mu * ex * (S + Sz);
-        ge[1] = p.mu * ex * cos(PI * xq[1]) + p.coef_e * p.eta * Ey;
-        ge[2] = p.mu * ex * cos(PI * xq[2]) + p.coef_e * p.eta * Ez;
+      double pe = 0.0, ge[DIM];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) ge[d] = 0.0;
+      if constexpr (SRC == 2) {
+        const int64_t o = ((cell - es.c0) * npts + q) * DIM;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) es.xout[o + d] = xq[d];
+        continue;
+      } else if constexpr (SRC == 1) {
+        const int64_t o = (cell - es.c0) * npts + q;
+        if (es.se) pe = es.se[o];
+        if (es.sg) {
+#pragma unroll
+          for (int d = 0; d < DIM; ++d) ge[d] = es.sg[o * DIM + d];
+        }
       } else {
-        pe = p.mu_over_pi * ex * S + p.coef_e * Ey;
-        ge[0] = p.mu * ex * S;
-        ge[1] = p.mu * ex * cos(PI * xq[1]) + p.coef_e * p.eta * Ey;
+        const double ex = exp(PI * xq[0]);
+        const double S = sin(PI * xq[1]), Ey = exp(p.eta * xq[1]);
+        if constexpr (DIM == 3) {
+          const double Sz = sin(PI * xq[2]), Ez = exp(p.eta * xq[2]);
+          pe = p.mu_over_pi * ex * (S + Sz) + p.coef_e * (Ey + Ez);
+          ge[0] = p.mu * ex * (S + Sz);
+          ge[1] = p.mu * ex * cos(PI * xq[1]) + p.coef_e * p.eta * Ey;
+          ge[2] = p.mu * ex * cos(PI * xq[2]) + p.coef_e * p.eta * Ez;
+        } else {
+          pe = p.mu_over_pi * ex * S + p.coef_e * Ey;
+          ge[0] = p.mu * ex * S;
+          ge[1] = p.mu * ex * cos(PI * xq[1]) + p.coef_e * p.eta * Ey;
+        }
       }
       const double wd = w * fabs(det);
       const double du = uh - pe;
@@ -345,6 +385,83 @@ extern "C" int pph_error_norms_mms(pph_ctx* ctx, int field, const double* nodal_
   *h1s_out = std::sqrt(r[1]);
   u.release();
   part.release();
+  return PPH_OK;
+}
+
+// launches the kernel of the mesh's cell kind in source mode SRC
+template <int SRC>
+static void err_launch(pph_ctx* ctx, const MeshData& m, const double* u, const GaussRule& g, double* part, ErrSamples es, int grid) {
+  MmsPar p = MmsPar();
+  if (m.kind == PPH_CELL_QUAD)
+    hipLaunchKernelGGL((k_error_norms<2, SRC>), dim3(grid), dim3(256), 0, ctx->stream, m.cells.p, m.cx.p, m.cy.p, m.cz.p, u, g, p, m.ncell, part, es);
+  else if (m.kind == PPH_CELL_TRI)
+    hipLaunchKernelGGL((k_error_norms_simplex<2, SRC>), dim3(grid), dim3(256), 0, ctx->stream, m.cells.p, m.cx.p, m.cy.p, m.cz.p, u, g, p, m.ncell, part, es);
+  else if (m.kind == PPH_CELL_TET)
+    hipLaunchKernelGGL((k_error_norms_simplex<3, SRC>), dim3(grid), dim3(256), 0, ctx->stream, m.cells.p, m.cx.p, m.cy.p, m.cz.p, u, g, p, m.ncell, part, es);
+  else
+    hipLaunchKernelGGL((k_error_norms<3, SRC>), dim3(grid), dim3(256), 0, ctx->stream, m.cells.p, m.cx.p, m.cy.p, m.cz.p, u, g, p, m.ncell, part, es);
+}
+
+extern "C" int pph_quadrature_points(pph_ctx* ctx, int nq, int64_t cell_begin, int64_t cell_count, double* xq_host) {
+  if (!ctx) return PPH_ERR_INVALID;
+  PPH_REQUIRE(ctx, ctx->mesh_ok, "pph_quadrature_points before pph_mesh_build");
+  const MeshData& m = ctx->mesh;
+  PPH_REQUIRE(ctx, nq >= 1 && nq <= 8 && xq_host, "bad arguments");
+  PPH_REQUIRE(ctx, cell_begin >= 0 && cell_count >= 1 && cell_begin + cell_count <= m.ncell, "cell range outside the mesh");
+  PPH_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t npts = (m.dim == 2) ? nq * nq : nq * nq * nq;
+  DevBuf<double> xo;
+  PPH_TRY(xo.alloc(ctx, (size_t)(cell_count * npts * m.dim)));
+  GaussRule g;
+  g.nq = nq;
+  gauss_legendre(nq, g.x, g.w);
+  ErrSamples es{nullptr, nullptr, xo.p, cell_begin, cell_begin + cell_count};
+  const int64_t nb = ceil_div64(cell_count, 256);
+  err_launch<2>(ctx, m, m.cx.p /* unused nodal field: any valid array of n values */, g, nullptr, es, (int)(nb < 2048 ? nb : 2048));
+  PPH_HIP(ctx, hipMemcpyAsync(xq_host, xo.p, sizeof(double) * (size_t)(cell_count * npts * m.dim), hipMemcpyDeviceToHost, ctx->stream));
+  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  PPH_HIP(ctx, hipGetLastError());
+  xo.release();
+  return PPH_OK;
+}
+
+extern "C" int pph_error_norms_sampled(pph_ctx* ctx, const double* nodal_host, int nq, int64_t cell_begin, int64_t cell_count,
+                                       const double* exact_q_host, const double* grad_q_host, double* l2sq_out, double* h1sq_out) {
+  if (!ctx) return PPH_ERR_INVALID;
+  PPH_REQUIRE(ctx, ctx->mesh_ok, "pph_error_norms_sampled before pph_mesh_build");
+  PPH_REQUIRE(ctx, ctx->world == 1, "error norms are implemented for single-context meshes");
+  const MeshData& m = ctx->mesh;
+  PPH_REQUIRE(ctx, nq >= 1 && nq <= 8 && nodal_host && l2sq_out && h1sq_out, "bad arguments");
+  PPH_REQUIRE(ctx, cell_begin >= 0 && cell_count >= 1 && cell_begin + cell_count <= m.ncell, "cell range outside the mesh");
+  PPH_HIP(ctx, hipSetDevice(ctx->device));
+  const int64_t npts = (m.dim == 2) ? nq * nq : nq * nq * nq;
+  DevBuf<double> u, part, se, sg;
+  PPH_TRY(u.alloc(ctx, (size_t)m.n));
+  PPH_TRY(part.alloc(ctx, 2 * 2048 + 2));
+  PPH_HIP(ctx, hipMemcpyAsync(u.p, nodal_host, sizeof(double) * (size_t)m.n, hipMemcpyHostToDevice, ctx->stream));
+  if (exact_q_host) {
+    PPH_TRY(se.alloc(ctx, (size_t)(cell_count * npts)));
+    PPH_HIP(ctx, hipMemcpyAsync(se.p, exact_q_host, sizeof(double) * (size_t)(cell_count * npts), hipMemcpyHostToDevice, ctx->stream));
+  }
+  if (grad_q_host) {
+    PPH_TRY(sg.alloc(ctx, (size_t)(cell_count * npts * m.dim)));
+    PPH_HIP(ctx, hipMemcpyAsync(sg.p, grad_q_host, sizeof(double) * (size_t)(cell_count * npts * m.dim), hipMemcpyHostToDevice, ctx->stream));
+  }
+  GaussRule g;
+  g.nq = nq;
+  gauss_legendre(nq, g.x, g.w);
+  ErrSamples es{exact_q_host ? se.p : nullptr, grad_q_host ? sg.p : nullptr, nullptr, cell_begin, cell_begin + cell_count};
+  const int64_t nb = ceil_div64(cell_count, 256);
+  const int grid = (int)(nb < 2048 ? nb : 2048);
+  err_launch<1>(ctx, m, u.p, g, part.p, es, grid);
+  hipLaunchKernelGGL(k_sum_partials, dim3(2), dim3(256), 0, ctx->stream, part.p, grid, part.p + 4096);
+  double r[2];
+  PPH_HIP(ctx, hipMemcpyAsync(r, part.p + 4096, sizeof(r), hipMemcpyDeviceToHost, ctx->stream));
+  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  PPH_HIP(ctx, hipGetLastError());
+  *l2sq_out = r[0];
+  *h1sq_out = r[1];
+  u.release(); part.release(); se.release(); sg.release();
   return PPH_OK;
 }
 

@@ -11,7 +11,7 @@
 #include <functional>
 
 // slots in ctx->scal used by the drivers
-enum { S_A = 0, S_B = 2, S_C = 4, S_INNER = 8, S_COARSE = 16, S_MDOT = 64 };
+enum { S_A = 0, S_B = 2, S_BAD = 3, S_C = 4, S_INNER = 8, S_COARSE = 16, S_MDOT = 64 };   // S_BAD: breakdowns counted on the device (launch-only sweeps)
 
 // work vector ids
 enum {
@@ -297,9 +297,11 @@ static int cg_solve_fixed(pph_ctx* ctx, const Csr& A, const double* b, double* x
     }
     la_spmv_dot(ctx, A, p, q, sPQ, it > 0 ? sRZn : -1, sRZc);
     PPH_TRY(la_reduce_device(ctx, sPQ, 1));
-    la_cg_update_dev(ctx, x, r, p, q, sRZc, sPQ, n, sRR, sg, (pre.on && !last) ? z : nullptr, pre.dinv, pre.w);
+    la_cg_update_dev(ctx, x, r, p, q, sRZc, sPQ, n, sRR, sg, (pre.on && !last) ? z : nullptr, pre.dinv, pre.w, S_BAD);
     PPH_TRY(la_reduce_device(ctx, sRR, 1));
   }
+  // (a breakdown - p.Ap zero or NaN - is counted in scal[S_BAD] by the update kernel; the Picard loop publishes the count
+  // with the sweep's norms and reports it as inner_failed)
   out->its = its; out->res = -1.0; out->converged = true; out->breakdown = false; out->bnorm = -1.0;
   return PPH_OK;
 }
@@ -745,6 +747,7 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
     PPH_TRY(work(ctx, W_R1, (size_t)n, &R0));
     PPH_TRY(work(ctx, W_R2, (size_t)n, &R1));
     la_set(ctx, t12, 0.0, n);
+    la_set(ctx, ctx->scal.p + S_BAD, 0.0, 1);
     const bool recur = (cfg->inner_ksp_type == PPH_KSP_CG);
     const int64_t pob = ctx->mesh.own_begin(), pon = ctx->mesh.own_end() - ctx->mesh.own_begin();
     // true residual from direct products only: t12 = A12 du2 and rhs1 = b2 - A21 du1 were formed by SpMVs with
@@ -784,7 +787,7 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
           la_spmv_shift(ctx, A12, du2, nullptr, R0, t12, tn, S_A, pob, pob + pon, z0p[0], z0d[0], z0w[0]);    // t12 = A12 du2 ; R0 follows ; ||R0||^2
           z0r[0] = z0p[0] != nullptr;
           la_dot(ctx, R1 + pob, R1 + pob, pon, S_A + 1);
-          la_publish(ctx, S_A, 2);
+          la_publish(ctx, S_A, 4);   // ||R0||^2, ||R1||^2, (S_B), breakdowns counted by the block solves (S_BAD)
           return PPH_OK;
         };
         const int its_before = bs.total_its;
@@ -801,6 +804,7 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
         if (bs.total_its == its_before) bs.total_its += 2 * cfg->inner_max_it;   // a replayed sweep: counted here
         PPH_TRY(la_wait_published(ctx));
         ++its;
+        if (ctx->h_scal[S_BAD] != 0.0) bs.failed = true;
         res = std::sqrt(ctx->h_scal[S_A] + ctx->h_scal[S_A + 1]);
         if (hist && its < hist_cap) hist[its] = res;
         if (!(res == res)) break;

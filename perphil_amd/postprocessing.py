@@ -1,8 +1,10 @@
 """
 Post-processing — mirror of reference ``src/perphil/utils/postprocessing.py``:
 ``split_dpp_solution`` (:6-31), ``calculate_darcy_velocity_from_pressure`` (:34-63), ``slice_along_x`` (:66-86), ``l2_error`` (:89-105), ``h1_seminorm_error``
-(:108-124).  The two error norms run on the device (``pph_error_norms_mms``): a Gauss rule per cell on
-the isoparametric map with the manufactured pressure evaluated in closed form at every quadrature point.
+(:108-124).  The two error norms run on the device: a Gauss rule per cell on the isoparametric map, with the
+manufactured pressure evaluated in closed form at every quadrature point (``pph_error_norms_mms``) or, for any other
+exact field, with samples the caller's callable provides at those points (``pph_quadrature_points`` /
+``pph_error_norms_sampled``).
 """
 from __future__ import annotations
 
@@ -54,15 +56,29 @@ def slice_along_x(scalar_field: fd.Function, x_value: float) -> Tuple[np.ndarray
 
 
 def _norms(numerical: fd.Function, exact_expr, quadrature_points: int):
-    if not isinstance(exact_expr, MMSPressure):
-        raise NotImplementedError("device error norms are available against the manufactured pressures "
-                                  "returned by exact_expressions / exact_expressions_3d")
+    """Both norms on the device.  `exact_expr` may be what the reference's UFL argument can be: a manufactured pressure
+    (closed form evaluated in the kernel), any callable of point arrays `f(X[m, dim]) -> [m]` (optionally with a
+    `.grad(X) -> [m, dim]` attribute; central differences otherwise), a CG-1 `Function` on the same mesh, or a
+    `Constant` / number."""
     mesh = numerical.function_space().mesh()
-    if exact_expr.dim != mesh.dim:
-        raise ValueError("exact expression and mesh have different dimensions")
     ctx = mesh.context()
-    e = exact_expr
-    return ctx.error_norms_mms(e.field, numerical.vector(), e.k1, e.k2, e.beta, e.mu, quadrature_points)
+    if isinstance(exact_expr, MMSPressure):
+        if exact_expr.dim != mesh.dim:
+            raise ValueError("exact expression and mesh have different dimensions")
+        e = exact_expr
+        return ctx.error_norms_mms(e.field, numerical.vector(), e.k1, e.k2, e.beta, e.mu, quadrature_points)
+    if isinstance(exact_expr, fd.Function):
+        if exact_expr.function_space().mesh() is not mesh:
+            raise ValueError("both functions must live on the same mesh")
+        diff = np.asarray(numerical.vector(), dtype=np.float64) - np.asarray(exact_expr.vector(), dtype=np.float64)
+        return ctx.error_norms_sampled(diff, None, None, min(quadrature_points, 3))   # CG-1 difference: exact with 2-3 points
+    if isinstance(exact_expr, (int, float, fd.Constant)):
+        c = float(exact_expr)
+        return ctx.error_norms_sampled(numerical.vector(), lambda X: np.full(X.shape[0], c), lambda X: np.zeros_like(X),
+                                       quadrature_points)
+    if callable(exact_expr):
+        return ctx.error_norms_sampled(numerical.vector(), exact_expr, getattr(exact_expr, "grad", None), quadrature_points)
+    raise TypeError(f"cannot evaluate an exact expression of type {type(exact_expr).__name__}")
 
 
 def l2_error(numerical: fd.Function, exact_expr, quadrature_points: int = 6) -> float:

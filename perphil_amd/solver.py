@@ -178,8 +178,12 @@ def _apply_bcs(ctx: _ffi.Context, W, bcs: List[fd.DirichletBC]) -> None:
         if getattr(V, "parent", None) is not W:
             raise ValueError("DirichletBC must be built on W.sub(i) of the space being solved")
         per_field[bc.field] = bc.nodes_and_values()
+    # a set that is already on the device (same nodes, same values) is not applied again: pph_set_dirichlet drops the
+    # assembled system and makes the multigrid hierarchy re-derive its masks
     for f in (0, 1):
-        ctx.set_dirichlet(f, *per_field[f])
+        nodes, vals = per_field[f]
+        if not ctx.same_dirichlet(f, nodes, vals):
+            ctx.set_dirichlet(f, nodes, vals)
 
 
 def _run(W, model_params: DPPParameters, bcs, solver_parameters: Dict, nonlinear: bool, device: int = 0) -> Solution:

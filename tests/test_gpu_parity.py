@@ -880,6 +880,88 @@ def test_sell_lds_handover_product_is_bitwise_the_cached_one(gpu_ctx_factory, nx
 
 
 @pytest.mark.gpu
+def test_launch_only_sweeps_report_a_breakdown_instead_of_nans(gpu_ctx_factory):
+    """inner_norm 2 (exactly k CG iterations per block solve, every scalar on the device): a block whose residual is
+    exactly zero (no coupling, homogeneous data on field 0) gives p.Ap = 0 in every one of its solves.  The update kernel
+    must leave x and r alone (no 0 / 0), count the event on the device and the solve must report it as inner_failed -
+    like the host-scalar loop, which flags the same case as a breakdown - while field 1 still converges."""
+    f = _ffi()
+    N = 8
+    om = o.build_mesh(3, o.CELL_HEX, N, N, N)
+    b = o.boundary_nodes(om)
+    _, e2 = o.exact_pressures(om.coords, P)
+    ctx = gpu_ctx_factory()
+    ctx.mesh_build(3, f.CELL_HEX, N, N, N)
+    ctx.set_dirichlet(0, b, np.zeros(len(b)))
+    ctx.set_dirichlet(1, b, e2[b])
+    ctx.assemble(P.k1, P.k2, 0.0, P.mu, monolithic=False)      # beta = 0: the blocks do not couple
+    cfg = _cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_MG, inner_rtol=1e-10, inner_max_it=3, inner_norm=2,
+               mg_smooth=1, picard_rtol=1e-8, picard_max_it=100)
+    xs, info, _ = ctx.solve(cfg)
+    n = ctx.n
+    assert np.all(np.isfinite(xs)) and info.converged
+    assert np.all(xs[:n] == 0.0)
+    assert info.inner_failed == 1
+    A22 = ctx.csr(f.MAT_A22)
+    rhs, u0 = ctx.rhs()
+    r2 = rhs[n:] - A22 @ (xs[n:] - u0[n:])
+    assert np.linalg.norm(r2) <= 1e-8 * np.linalg.norm(rhs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,kind,nx,ny,nz", [(2, o.CELL_QUAD, 12, 9, 0), (2, o.CELL_TRI, 7, 10, 0), (3, o.CELL_HEX, 6, 5, 4),
+                                               (3, o.CELL_TET, 4, 5, 3)])
+def test_error_norms_for_an_arbitrary_exact_expression(gpu_ctx_factory, dim, kind, nx, ny, nz):
+    """l2_error / h1_seminorm_error take any exact expression like the reference's (utils/postprocessing.py:89-124 accept a
+    UFL expression): a Python callable of point arrays with a gradient attribute, the same callable without one (central
+    differences), a Constant, and another CG-1 Function - checked against the oracle's quadrature (o.error_norms) with a
+    NON-manufactured field, on all four cell kinds; chunked evaluation gives the same sums."""
+    import perphil_amd as pa
+    from perphil_amd import fd
+    from perphil_amd.postprocessing import h1_seminorm_error, l2_error
+
+    mesh = (pa.create_mesh(nx, ny, quadrilateral=(kind == o.CELL_QUAD)) if dim == 2
+            else fd.UnitCubeMesh(nx, ny, nz, hexahedral=(kind == o.CELL_HEX)))
+    V = fd.FunctionSpace(mesh, "CG", 1)
+    om = o.build_mesh(dim, kind, nx, ny, nz)
+
+    def ex(X):
+        r = np.cos(2.0 * X[:, 0]) * np.exp(-X[:, 1]) + 0.3 * X[:, 0] * X[:, 1]
+        return r + (np.sin(1.5 * X[:, 2]) if dim == 3 else 0.0)
+
+    def gr(X):
+        g = [-2.0 * np.sin(2.0 * X[:, 0]) * np.exp(-X[:, 1]) + 0.3 * X[:, 1],
+             -np.cos(2.0 * X[:, 0]) * np.exp(-X[:, 1]) + 0.3 * X[:, 0]]
+        if dim == 3:
+            g.append(1.5 * np.cos(1.5 * X[:, 2]))
+        return np.stack(g, axis=1)
+
+    rng = np.random.default_rng(3)
+    uh = ex(om.coords) + 1e-2 * rng.uniform(-1, 1, om.num_nodes)       # not the interpolant: a real error
+    fh = fd.Function(V, uh, name="uh")
+    rl2, rh1 = o.error_norms(om, uh, ex, gr, nq=5)
+
+    class WithGrad:
+        def __call__(self, X): return ex(X)
+        def grad(self, X): return gr(X)
+
+    assert l2_error(fh, WithGrad(), 5) == pytest.approx(rl2, rel=1e-10)
+    assert h1_seminorm_error(fh, WithGrad(), 5) == pytest.approx(rh1, rel=1e-10)
+    assert l2_error(fh, ex, 5) == pytest.approx(rl2, rel=1e-10)                 # gradient not needed
+    assert h1_seminorm_error(fh, ex, 5) == pytest.approx(rh1, rel=1e-6)         # central differences
+    ctx = mesh.context()
+    a = ctx.error_norms_sampled(uh, ex, gr, 5, chunk_cells=7)
+    assert a[0] == pytest.approx(rl2, rel=1e-10) and a[1] == pytest.approx(rh1, rel=1e-10)
+    c2, ch = o.error_norms(om, uh, lambda X: np.full(X.shape[0], 0.25), lambda X: np.zeros_like(X), nq=4)
+    assert l2_error(fh, fd.Constant(0.25), 4) == pytest.approx(c2, rel=1e-10)
+    assert h1_seminorm_error(fh, 0.25, 4) == pytest.approx(ch, rel=1e-10)
+    vh = ex(om.coords)
+    d2, dh = o.error_norms(om, uh - vh, lambda X: np.zeros(X.shape[0]), lambda X: np.zeros_like(X), nq=3)
+    gh = fd.Function(V, vh, name="vh")
+    assert l2_error(fh, gh) == pytest.approx(d2, rel=1e-10) and h1_seminorm_error(fh, gh) == pytest.approx(dh, rel=1e-10)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kern", [3])
 def test_spmv_long_rows_and_residual_forms(gpu_ctx_factory, kern):
     """Monolithic 3D rows (up to 54 entries) take more than one 32-entry step of the aligned-wide kernels; the
