@@ -298,6 +298,13 @@ def main():
     k1, k2, beta, mu = 1.0, 1e-2, 1.0, 1.0
 
     transport, ranks_seen = "none", 1
+    # HIP runtime start-up (the first HIP call of the process) + context: a per-process cost, reported apart from the
+    # problem's set-up
+    t_ctx0 = time.perf_counter()
+    _warm = _ffi.Context(device)
+    _warm.synchronize()
+    context_ms = 1e3 * (time.perf_counter() - t_ctx0)
+    _warm.close()
     t_setup0 = time.perf_counter()
     if world > 1:
         from perphil_amd.distributed import SlabSolver
@@ -406,7 +413,7 @@ def main():
     # offline with tools/pmc_summarize.py and committed under profiles/ (PMC cannot be sampled in-process).  The
     # file is stamped with the kernel and the launch count it was taken on: anything else reports null.
     traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_spmv_bench256.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r03_pmc_spmv_bench256.json")
     if os.path.exists(pmc_file) and N == 256 and world == 1 and sell:
         try:
             with open(pmc_file) as f:
@@ -484,9 +491,11 @@ def main():
                            if args.inner_norm == 2 else
                            f"to a reduction of the {'unpreconditioned' if args.inner_norm else 'preconditioned'} residual by "
                            f"{args.inner_reduction:g} (or rtol {args.inner_rtol:g})"),
-            "preallocation": "outside the timed step: mesh, sparsity pattern, boundary-data upload (setup_ms) and the first "
-                             "step's buffer / multigrid-hierarchy allocation (cold_step_ms = that first step)",
+            "preallocation": "outside the timed step: HIP runtime start-up + first context of the process (context_ms), mesh "
+                             "+ host-side boundary data + its upload (setup_ms; the CSR pattern is built only on demand) and "
+                             "the first step's buffer / multigrid-hierarchy allocation (cold_step_ms = that first step)",
             "setup_ms": round(setup_ms, 2), "cold_step_ms": None if cold_ms is None else round(cold_ms, 2),
+            "context_ms": round(context_ms, 2),
             "operator_format": ("stencil-ELL, symmetric storage" if sym else "stencil-ELL") if sell else "CSR",
             "transport": transport, "ranks_seen": int(ranks_seen),
             "allreduces_per_step": int(cs["allreduces"]),

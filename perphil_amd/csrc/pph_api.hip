@@ -357,6 +357,17 @@ int pph_assemble_dpp(pph_ctx* ctx, double k1, double k2, double beta, double mu,
 }
 
 // ---- export -------------------------------------------------------------------------------------
+// products (pph_spmv, pph_spmv_bench) on an assembled block run on its stencil-ELL copy when that is the operator format:
+// no CSR pattern, no CSR values needed (a 512^3 block has more entries than the pattern's int32 positions can address)
+static bool select_sell_only(pph_ctx* ctx, int which, Csr* A) {
+  if (!(ctx->mesh_ok && ctx->asm_ok && ctx->op_format == 1 && ctx->ell_ok && which >= 3 && which <= 6)) return false;
+  const MeshData& m = ctx->mesh;
+  A->rowptr = nullptr; A->col = nullptr; A->val = nullptr; A->nrows = m.n; A->nnz = m.nnzb; A->max_row = m.max_row;
+  A->lanes = pph_pick_lanes(ctx, A->nnz, A->nrows);
+  A->ell = (which == 3) ? ctx->S11 : (which == 4) ? ctx->S22 : (which == 5) ? ctx->S12 : ctx->S21;
+  return true;
+}
+
 static int select_csr(pph_ctx* ctx, int which, Csr* A) {
   PPH_REQUIRE(ctx, ctx->mesh_ok, "no mesh");
   PPH_TRY(pph_ensure_pattern(ctx, ctx->mesh));   // (exports are CSR)
@@ -436,8 +447,10 @@ int pph_spmv(pph_ctx* ctx, int which, const double* x_host, double* y_host) {
   PPH_REQUIRE(ctx, x_host && y_host, "NULL vector");
   PPH_HIP(ctx, hipSetDevice(ctx->device));
   Csr A;
-  PPH_TRY(select_csr(ctx, which, &A));
-  PPH_TRY(attach_sell(ctx, which, &A));
+  if (!select_sell_only(ctx, which, &A)) {
+    PPH_TRY(select_csr(ctx, which, &A));
+    PPH_TRY(attach_sell(ctx, which, &A));
+  }
   DevBuf<double> x, y;
   PPH_TRY(x.alloc(ctx, (size_t)A.nrows));
   PPH_TRY(y.alloc(ctx, (size_t)A.nrows));
@@ -465,12 +478,14 @@ int pph_spmv_bench(pph_ctx* ctx, int which, int reps, double* avg_ms) {
   PPH_REQUIRE(ctx, reps >= 1 && avg_ms, "reps must be >= 1 and avg_ms non-NULL");
   PPH_HIP(ctx, hipSetDevice(ctx->device));
   Csr A;
-  PPH_TRY(select_csr(ctx, which, &A));
-  A.lanes = pph_pick_lanes(ctx, A.nnz, A.nrows);
+  if (!select_sell_only(ctx, which, &A)) {
+    PPH_TRY(select_csr(ctx, which, &A));
+    A.lanes = pph_pick_lanes(ctx, A.nnz, A.nrows);
 #ifdef PPH_EXPERIMENTS
-  if (ctx->spmv_kernel == 16) return la_padded_experiment(ctx, A, reps, avg_ms);  // padded-row experiment
+    if (ctx->spmv_kernel == 16) return la_padded_experiment(ctx, A, reps, avg_ms);  // padded-row experiment
 #endif
-  PPH_TRY(attach_sell(ctx, which, &A));
+    PPH_TRY(attach_sell(ctx, which, &A));
+  }
   DevBuf<double> x, y;
   PPH_TRY(x.alloc(ctx, (size_t)A.nrows));
   PPH_TRY(y.alloc(ctx, (size_t)A.nrows));
@@ -599,6 +614,7 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
   if (!strcmp(name, "sell_flags")) { ctx->sell_flags = (int)value; la_release_graphs(ctx); return PPH_OK; }
   if (!strcmp(name, "sell_group")) { ctx->sell_group = (int)value; return PPH_OK; }
   if (!strcmp(name, "asm_tile")) { ctx->asm_tile = (value == 2.0) ? 2 : (value != 0.0 ? 1 : 0); return PPH_OK; }
+  if (!strcmp(name, "asm_node_xmap")) { ctx->asm_node_xmap = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "asm_node")) { ctx->asm_node = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "asm_tile_xmap")) { ctx->asm_tile_xmap = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "asm_affine")) { ctx->asm_affine = value != 0.0 ? 1 : 0; return PPH_OK; }

@@ -2081,7 +2081,7 @@ __global__ __launch_bounds__(512, 4) void k_asm_tile(const double* __restrict__ 
 template <int DIM, int WPS>
 __global__ __launch_bounds__(256, WPS) void k_asm_node(const double* __restrict__ cx, const double* __restrict__ cy,
                                                   const double* __restrict__ cz, int nx, int ny, int nzl, int px, int py,
-                                                  int pz, int64_t n, FuseArgs fa) {
+                                                  int pz, int64_t n, FuseArgs fa, int xmap) {
   constexpr int NB = 1 << DIM;
   constexpr int NSLOT = (DIM == 3) ? 27 : 9;
   constexpr int NV = NSLOT;                                // vertices around a node
@@ -2089,14 +2089,16 @@ __global__ __launch_bounds__(256, WPS) void k_asm_node(const double* __restrict_
   const TileRef<DIM>& R = tile_ref<DIM>();
   const int64_t pxy = (int64_t)px * py;
   double best1 = 0.0, best2 = 0.0;
-  // Blocks of 256 consecutive nodes; every XCD (blockIdx % 8) takes one contiguous eighth of them, its workgroups
-  // consecutive blocks of it: a node's 3^d vertex neighbourhood is shared with its neighbours in x, y AND z, and dealt
-  // round-robin every one of the eight non-coherent L2s ended up fetching every coordinate plane (PMC, 256^3: 4.1 GB
-  // read by a kernel with 0.5 GB of inputs)
+  // Blocks of 256 consecutive nodes, dealt round-robin to the workgroups (xmap 0, default).  A node's 3^d vertex
+  // neighbourhood is shared with its neighbours in x, y AND z, so with that order every one of the eight non-coherent
+  // L2s ends up fetching every coordinate plane (PMC, 256^3: 4.1 GB read - mostly from the Infinity Cache - by a kernel
+  // with 0.5 GB of inputs).  xmap 1 gives every XCD (blockIdx % 8) one contiguous eighth of the blocks: 2.0 GB read,
+  // but 4.5 instead of 3.5 ms - eight write streams 0.8 GB apart instead of one front; the reads were never the limit.
   const int64_t nblk = (n + 255) / 256;
-  const int64_t bpx = (int64_t)(gridDim.x >> 3), cpx = (nblk + 7) >> 3;   // (launcher: gridDim.x is a multiple of 8)
-  const int64_t blk0 = (int64_t)(blockIdx.x & 7) * cpx;
-  for (int64_t c = blockIdx.x >> 3; c < cpx; c += bpx) {
+  const int64_t bpx = xmap ? (int64_t)(gridDim.x >> 3) : (int64_t)gridDim.x;   // (launcher: gridDim.x is a multiple of 8)
+  const int64_t cpx = xmap ? (nblk + 7) >> 3 : nblk;
+  const int64_t blk0 = xmap ? (int64_t)(blockIdx.x & 7) * cpx : 0;
+  for (int64_t c = xmap ? (blockIdx.x >> 3) : blockIdx.x; c < cpx; c += bpx) {
     const int64_t node = (blk0 + c) * 256 + threadIdx.x;
     if (node >= n) continue;
     const int gi = (int)(node % px);
@@ -2313,10 +2315,10 @@ int pph_launch_fused_kernels(pph_ctx* ctx, MeshData& mesh, const FuseArgs& fa, d
     const int grid = (int)(nb < 256 * 64 ? nb : 256 * 64);
     if (mesh.kind == PPH_CELL_QUAD)
       hipLaunchKernelGGL((k_asm_node<2, 2>), dim3(grid), dim3(256), 0, ctx->stream, mesh.cx.p, mesh.cy.p, mesh.cz.p, mesh.nx, mesh.ny, 0,
-                         mesh.px, mesh.py, 1, mesh.n, fa);
+                         mesh.px, mesh.py, 1, mesh.n, fa, ctx->asm_node_xmap);
     else
       hipLaunchKernelGGL((k_asm_node<3, 2>), dim3(grid), dim3(256), 0, ctx->stream, mesh.cx.p, mesh.cy.p, mesh.cz.p, mesh.nx, mesh.ny,
-                         mesh.nzl, mesh.px, mesh.py, mesh.pzl, mesh.n, fa);
+                         mesh.nzl, mesh.px, mesh.py, mesh.pzl, mesh.n, fa, ctx->asm_node_xmap);
     PPH_HIP(ctx, hipGetLastError());
     return PPH_OK;
   }

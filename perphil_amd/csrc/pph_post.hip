@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256) void k_error_norms(const int32_t* __restrict__
     if (threadIdx.x == 0) for (int q = 0; q < (int)(blockDim.x >> 6); ++q) t += lds[q];
     return t;
   };
+  if constexpr (SRC == 2) return;   // (coordinates only: `part` is null)
   const double a = bsum(l2);
   const double b = bsum(h1);
   if (threadIdx.x == 0) {
@@ -296,6 +297,7 @@ __global__ __launch_bounds__(256) void k_error_norms_simplex(const int32_t* __re
     if (threadIdx.x == 0) for (int q = 0; q < (int)(blockDim.x >> 6); ++q) t += lds[q];
     return t;
   };
+  if constexpr (SRC == 2) return;   // (coordinates only: `part` is null)
   const double a = bsum(l2);
   const double b = bsum(h1);
   if (threadIdx.x == 0) {
