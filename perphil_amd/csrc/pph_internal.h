@@ -264,7 +264,7 @@ struct pph_ctx {
   int64_t asm_tile_min_nodes = 30000;   // levels with fewer nodes use the two-pass kernels (asm_tile 2: tile kernel always)
   int asm_node_xmap = 0;                // node kernel: blocks dealt round-robin to the XCDs (0, default) or one contiguous eighth per XCD (1: 2.0 instead of 4.1 GB read at 256^3, but 4.5 instead of 3.5 ms)
   int asm_node = 1;                     // box meshes, stencil-ELL output: one thread per node, registers only (k_asm_node); 0: tile / two-pass kernels
-  int asm_tile_xmap = 1;                // tile kernel: x-adjacent tiles on ONE XCD (both halves of a 128-B line of a slot array meet in one L2)
+  int asm_tile_xmap = 0;                // tile kernel: x-adjacent tiles on ONE XCD (both halves of a 128-B line of a slot array meet in one L2)
   int asm_tile = 1;                     // multilinear fused assembly: 1 single-pass tile kernel (no element-row buffer), 0 two-pass
   int asm_ring = 0;                     // > 0 (experiment, slower): fused 3D assembly alternates element and node passes over a ring of cell layers, about asm_ring cells per launch
   int asm_keep_km = 0;                  // 1: the fused pass also stores K and M (two more 8 B/nnz streams); 0: they are integrated on demand (pph_get_csr K/M, Darcy projection)

@@ -304,6 +304,14 @@ class DirichletBC:
         return 0 if self._V.index is None else int(self._V.index)
 
     def nodes_and_values(self) -> Tuple[np.ndarray, np.ndarray]:
+        """Boundary nodes and their values.  A callable datum (the manufactured pressures) is evaluated once per
+        condition object: every solve with the same conditions used to re-evaluate exp / sin at 394 k boundary nodes
+        (256^3: ~20 ms per field and call).  Constants, arrays and Functions are read afresh (they can be reassigned)."""
         mesh = self._V.mesh()
+        if callable(self.value) and not isinstance(self.value, (Function, Constant)):
+            if getattr(self, "_cache", None) is None:
+                nodes = mesh.boundary_nodes()
+                self._cache = (nodes, evaluate(self.value, mesh, nodes))
+            return self._cache
         nodes = mesh.boundary_nodes()
         return nodes, evaluate(self.value, mesh, nodes)

@@ -46,6 +46,19 @@ def test_slab_runs_match_single_context(world, cells, kind, pc, solver):
     assert line and "max rel diff" in line[0]
 
 
+def test_split_products_stay_inside_one_partial_sum_area():
+    """a product launched as interior + two boundary row ranges lays its per-workgroup partial sums
+    back to back in ONE reduction slot's area; more of them than the area holds would alias the next slot (mode 7 keeps
+    r.Ap and Ap.Ap there) and give CG a wrong alpha silently.  The grids are capped so that the three launches together
+    stay within `part_cap` (= the area, 4096; lowered to 32 here so that the interior launch of a 32^3 slab hits the
+    cap): device-scalar branch + merged all-reduce + split products, equal to the single context as always."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "slab_check.py"), "--cells", "32", "--backend",
+           "gloo", "--inexact", "--device-scalars", "--halo-overlap", "--set", "part_cap=32"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "partial sums (cap 32)" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_failed_halo_exchange_is_reported_not_computed_through():
     """A halo callback that fails (on every rank, at the same exchange) must surface as a COMM error from the solve -
     not as a result computed on stale ghost planes - and the context must keep refusing afterwards (sticky status)."""

@@ -92,6 +92,12 @@ if mono:
 info = solver.step()
 full = solver.gather_solution()
 ok = True
+cap = [float(kv.split("=")[1]) for kv in args.set if kv.split("=")[0] == "part_cap"]
+if cap:
+    # the three launches of a split product share one reduction slot's partial-sum area: never more than part_cap of them
+    got = solver.ctx.timers()["max_split_partials"]
+    print(f"rank {rank}: split products wrote at most {got} partial sums (cap {int(cap[0])})", flush=True)
+    ok = ok and 0 < got <= cap[0]
 sym = solver.ctx.timers()["symmetric_storage"]
 if not mono and not sym:
     print(f"rank {rank}: the slab operators are not in symmetric stencil-ELL storage", flush=True)
