@@ -609,7 +609,7 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
 #ifndef PPH_EXPERIMENTS
     PPH_REQUIRE(ctx, value == 0.0, "sell_lds needs a library built with EXPERIMENTS=1");
 #endif
-    ctx->sell_lds = value != 0.0 ? 1 : 0; la_release_graphs(ctx); return PPH_OK;
+    ctx->sell_lds = (value == 2.0) ? 2 : (value != 0.0 ? 1 : 0); la_release_graphs(ctx); return PPH_OK;
   }
   if (!strcmp(name, "sell_flags")) { ctx->sell_flags = (int)value; la_release_graphs(ctx); return PPH_OK; }
   if (!strcmp(name, "sell_group")) { ctx->sell_group = (int)value; return PPH_OK; }

@@ -830,8 +830,9 @@ def test_node_assembly_kernel_equals_tile_kernel(gpu_ctx_factory, dim, kind, nx,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("nx,ny,nz,blocks", [(40, 36, 30, 8), (64, 64, 64, 64), (33, 70, 25, 16), (96, 96, 96, 256), (130, 20, 40, 8)])
-def test_sell_lds_handover_product_is_bitwise_the_cached_one(gpu_ctx_factory, nx, ny, nz, blocks):
+def test_sell_lds_handover_product_is_bitwise_the_cached_one(gpu_ctx_factory, nx, ny, nz, blocks, variant):
     """k_spmv_sell_lds (experiment, `make EXPERIMENTS=1`: symmetric 27-point product, mirrored values and x handed from
     plane to plane through LDS) against k_spmv_sell (mirrors through L1 / L2): same per-row order of products and sums, so
     every product is BIT-identical - checked on y = A x for the three blocks (also against SciPy on the exported CSR);
@@ -847,7 +848,7 @@ def test_sell_lds_handover_product_is_bitwise_the_cached_one(gpu_ctx_factory, nx
     g1, g2 = o.exact_pressures(mesh.node_coordinates(b), P)
     rng = np.random.default_rng(11)
     res = []
-    for lds in (1, 0):
+    for lds in (variant, 0):
         ctx = gpu_ctx_factory()
         try:
             ctx.set_option("sell_lds", lds)

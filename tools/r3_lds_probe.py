@@ -1,14 +1,14 @@
-"""Round 3: LDS hand-over product vs the cached one on the 256^3 block (isolated launches, all defaults otherwise)."""
+"""Round 3 (EXPERIMENTS build): LDS hand-over product variants vs the cached one on the 256^3 block (isolated launches)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from perphil_amd import _ffi
 import bench
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 ctx = _ffi.Context(0); ctx.mesh_build(3, _ffi.CELL_HEX, N, N, N)
 b, g1, g2 = bench.mms_boundary(N, 1.0, 1e-2, 1.0, 1.0)
 ctx.set_dirichlet(0, b, g1); ctx.set_dirichlet(1, b, g2); ctx.assemble(1.0, 1e-2, 1.0, 1.0, monolithic=False)
-for lds, blocks in ((0, 0), (1, 0), (1, 512), (0, 0), (1, 0)):
+for lds in (0, 1, 2, 0, 2):
     ctx.set_option("sell_lds", lds)
-    ctx.set_option("sell_blocks", blocks)
-    ms = min(ctx.spmv_bench(_ffi.MAT_A11, 30) for _ in range(3))
-    print(f"N {N} sell_lds {lds} blocks {blocks}: {ms:.4f} ms", flush=True)
+    ms = min(ctx.spmv_bench(_ffi.MAT_A11, reps) for _ in range(1 if reps < 10 else 3))
+    print(f"N {N} sell_lds {lds}: {ms:.4f} ms", flush=True)
