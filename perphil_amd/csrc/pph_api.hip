@@ -605,6 +605,13 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
     PPH_REQUIRE(ctx, value >= 32 && value <= PPH_PART_STRIDE && ((int)value % 32) == 0, "part_cap must be a multiple of 32 in [32, %d]", PPH_PART_STRIDE);
     ctx->part_cap = (int)value; la_release_graphs(ctx); return PPH_OK;
   }
+  if (!strcmp(name, "sell_patch")) {
+#ifndef PPH_EXPERIMENTS
+    PPH_REQUIRE(ctx, value == 0.0, "sell_patch needs a library built with EXPERIMENTS=1");
+#endif
+    ctx->sell_patch = value != 0.0 ? 1 : 0; la_release_graphs(ctx); return PPH_OK;
+  }
+  if (!strcmp(name, "sell_patch_z")) { ctx->sell_patch_z = value >= 1 ? (int)value : 1; la_release_graphs(ctx); return PPH_OK; }
   if (!strcmp(name, "sell_lds")) {
 #ifndef PPH_EXPERIMENTS
     PPH_REQUIRE(ctx, value == 0.0, "sell_lds needs a library built with EXPERIMENTS=1");

@@ -369,6 +369,7 @@ struct pph_ctx {
   int64_t sell_zwalk_min_chunks = 5500; // levels with fewer 512-row chunks keep the plain chunk order (measured: 128^3 = 4200 chunks loses 4 % with the z-walk, 144^3 = 5950 equal, 160^3 gains 8 %, 192^3 4 %, 256^3 20 %)
   int sell_zwalk = 4;                   // > 0 (symmetric operators, 3D): a workgroup walks this many consecutive node planes at one in-plane position
   int sell_xmap = 1;                    // z-walk: consecutive in-plane positions on one XCD
+  int sell_patch = 0, sell_patch_z = 16; // (EXPERIMENTS build) a wave climbs a 16 x 8 patch, mirrors of its own rows from wave-private LDS; planes per climb
   int sell_lds = 0;                     // (EXPERIMENTS build) symmetric 27-point operators on z-walk levels: mirrored values handed over through LDS
   int sell_flags = 0;                   // experiments: 1 non-temporal y stores (mode 0), 2 non-temporal loads of the diagonal slot
   int sell_rpt = 2, sell_blocks = 0, sell_group = 0;   // SELL SpMV tuning: rows per thread, grid cap, XCD chunk group

@@ -251,7 +251,8 @@ __global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ va
 }
 
 #ifdef PPH_EXPERIMENTS
-#include "experiments/pph_sell_lds.inc"   // LDS hand-over product (option "sell_lds"; not part of the shipped library)
+#include "experiments/pph_sell_patch.inc"  // wave-private patch walk (option "sell_patch")
+#include "experiments/pph_sell_lds.inc"    // LDS hand-over product (option "sell_lds"); neither is part of the shipped library
 #endif
 
 template <int KIND, int RPT>
@@ -310,6 +311,10 @@ int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x,
   // profiles/r02_sell_sym_probe_256.txt, r02_sell_sym_probe2_256.txt)
   const bool zw = E.sym && E.pz > 2 && ctx->sell_zwalk > 0 && chunk0 == 0 && nchunks >= ctx->sell_zwalk_min_chunks;   // (smaller levels: too few chunks per workgroup)
 #ifdef PPH_EXPERIMENTS
+  if (zw && ctx->sell_patch && rpt == 2 && E.kind == PPH_CELL_HEX && cend < 0) {
+    const int g = sell_launch_patch(ctx, mode, E, x, b, dinv, w, y, aux, z0, n, part, dlo, dhi);
+    if (g > 0) return g;
+  }
   if (zw && ctx->sell_lds && rpt == 2 && E.kind == PPH_CELL_HEX && cend < 0) {
     const int g = sell_launch_lds(ctx, mode, E, x, b, dinv, w, y, aux, z0, n, nchunks, part, dlo, dhi);
     if (g > 0) return g;

@@ -830,6 +830,54 @@ def test_node_assembly_kernel_equals_tile_kernel(gpu_ctx_factory, dim, kind, nx,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nx,ny,nz,blocks,z", [(40, 36, 30, 8, 4), (64, 64, 64, 64, 16), (33, 70, 25, 16, 7), (96, 96, 96, 256, 16),
+                                                (130, 20, 40, 8, 3), (15, 15, 15, 8, 16), (64, 64, 64, 512, 1)])
+def test_sell_patch_walk_product_is_bitwise_the_cached_one(gpu_ctx_factory, nx, ny, nz, blocks, z):
+    """k_spmv_sell_patch (experiment, `make EXPERIMENTS=1`: a wave climbs a 16 x 8 node patch; mirrors of its own rows from wave-private LDS, the patch
+    edges through the caches) against k_spmv_sell: same per-row order of products and sums, so y = A x is BIT-identical
+    for the three blocks (also against SciPy on the exported CSR); a whole Picard solve, whose iterates pass every
+    epilogue mode, takes the same sweeps / iterations to the same solution (1e-12: the partial sums of the dot products
+    are grouped by workgroup, and the kernels deal the rows differently).  Line lengths that are / are not near a
+    multiple of 16 (shear 1, -7, 2, 3), patches cut by the end of a plane step, boundary planes, climbs of 1 .. 16 planes."""
+    f = _ffi()
+    import perphil_amd.fd as fdm
+
+    mesh = fdm.UnitCubeMesh(nx, ny, nz, hexahedral=True)
+    b = mesh.boundary_nodes()
+    g1, g2 = o.exact_pressures(mesh.node_coordinates(b), P)
+    rng = np.random.default_rng(12)
+    res = []
+    for patch in (1, 0):
+        ctx = gpu_ctx_factory()
+        try:
+            ctx.set_option("sell_patch", patch)
+        except ValueError:
+            pytest.skip("k_spmv_sell_patch is an experiment: library built without EXPERIMENTS=1")
+        ctx.set_option("sell_patch_z", z)
+        ctx.set_option("sell_zwalk_min_chunks", 1)
+        ctx.set_option("sell_blocks", blocks)
+        ctx.mesh_build(3, f.CELL_HEX, nx, ny, nz)
+        ctx.set_dirichlet(0, b, g1)
+        ctx.set_dirichlet(1, b, g2)
+        ctx.assemble(P.k1, P.k2, P.beta, P.mu, monolithic=False)
+        x = rng.uniform(-1, 1, ctx.n) if not res else res[0][0]
+        ys = [ctx.spmv(w, x) for w in (f.MAT_A11, f.MAT_A22, f.MAT_A12)]
+        xs, info, hist = ctx.solve(_cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_MG, inner_rtol=1e-10,
+                                        inner_reduction=1e-1, inner_norm=1, mg_smooth=1, picard_rtol=1e-8), hist_cap=64)
+        if patch:
+            A11 = ctx.csr(f.MAT_A11)
+            ref = A11 @ x
+            assert np.abs(ys[0] - ref).max() <= 1e-13 * np.abs(ref).max()
+        res.append((x, ys, xs, (info.iterations, info.inner_iterations), hist))
+        ctx.close()
+    for ya, yb in zip(res[0][1], res[1][1]):
+        np.testing.assert_array_equal(ya, yb)
+    np.testing.assert_allclose(res[0][2], res[1][2], rtol=0, atol=1e-12 * np.abs(res[1][2]).max())
+    np.testing.assert_allclose(res[0][4], res[1][4], rtol=1e-6)
+    assert res[0][3] == res[1][3]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("nx,ny,nz,blocks", [(40, 36, 30, 8), (64, 64, 64, 64), (33, 70, 25, 16), (96, 96, 96, 256), (130, 20, 40, 8)])
 def test_sell_lds_handover_product_is_bitwise_the_cached_one(gpu_ctx_factory, nx, ny, nz, blocks, variant):
