@@ -12,7 +12,7 @@ Sources:
   G5     notebooks/results-conforming-3d/conditioning/conditioning_3d.csv
   G6/G9  notebooks/results-conforming-3d/petsc_profiling/petsc_perf_breakdown_3d.csv
   G7/G9  notebooks/results-conforming-2d/petsc_profiling/petsc_perf_breakdown.csv
-  G10    notebooks/results-conforming-2d/convergence.csv
+  G10    notebooks/results-conforming-2d/convergence.csv, convergence_eoc.csv (observed orders)
   G12    src/perphil/experiments/_tests/test_petsc_profiling/test_perf_to_dict_regression.yml,
          src/perphil/forms/_tests/test_dpp_regressions/test_dpp_form_structure_regression.yml
 """
@@ -94,6 +94,10 @@ def main():
     g["G7_G9_perf_2d_q1"] = perf(os.path.join(NB, "results-conforming-2d/petsc_profiling/petsc_perf_breakdown.csv"))
     g["G10_convergence_2d"] = [
         {k: (v if k == "solver" else float(v)) for k, v in r.items()} for r in _rows(os.path.join(NB, "results-conforming-2d/convergence.csv"))]
+    g["G10_convergence_2d_eoc"] = [
+        {"solver": r["solver"], "err": r["err"], "slope": float(r["slope"])} for r in _rows(os.path.join(NB, "results-conforming-2d/convergence_eoc.csv"))]
+    with open(os.path.join(NB, "results-conforming-2d/convergence.csv")) as f:
+        g["convergence_csv_columns"] = f.readline().strip().split(",")
     with open(os.path.join(NB, "results-conforming-3d/petsc_profiling/petsc_perf_breakdown_3d.csv")) as f:
         g["perf_csv_columns_3d"] = f.readline().strip().split(",")
     g["G12_structure"] = {"mesh_2x2_dofs": 18, "mesh_2x2_num_cells": 4, "form_integrals": 4, "form_rank": 2}

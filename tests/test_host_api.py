@@ -188,3 +188,25 @@ def test_bench_gpus_n_launches_itself(monkeypatch):
     assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
     assert cmd[-6:] == ["--gpus", "4", "--steps", "2", "--warmup", "1"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_convergence_2d_host_logic(goldens):
+    """perphil_amd.convergence_2d (mirror of reference experiments/convergence_2d.py): solver lists, row schema, and the
+    observed-order fit checked against the reference's own convergence.csv -> convergence_eoc.csv pair (no GPU:
+    the rows are the committed ones)."""
+    from perphil_amd import convergence_2d as c2
+
+    specs = c2._default_solvers([1e-8, 1e-10])                        # reference convergence_2d.py:118-133
+    assert [s.name for s in specs] == ["mumps", "gmres_rtol=1e-08", "fs-lu_gmres_rtol=1e-08", "gmres_rtol=1e-10",
+                                       "fs-lu_gmres_rtol=1e-10"]
+    assert specs[1].params["ksp_rtol"] == 1e-8 and specs[1].params["pc_type"] == "none"
+    assert specs[4].params["ksp_type"] == "gmres" and specs[4].params["ksp_atol"] == 1e-12
+    assert specs[4].params["pc_type"] == "fieldsplit" and "ksp_rtol" not in sp.FIELDSPLIT_LU_PARAMS   # presets untouched
+    assert c2.ROW_FIELDS == goldens["convergence_csv_columns"]
+    assert [s.name for s in c2.approach_solvers()] == sorted({r["solver"] for r in goldens["G10_convergence_2d"]})
+    got = {(r["solver"], r["err"]): r["slope"] for r in c2.observed_orders(goldens["G10_convergence_2d"])}
+    assert len(got) == 20
+    for r in goldens["G10_convergence_2d_eoc"]:
+        assert got[(r["solver"], r["err"])] == pytest.approx(r["slope"], rel=1e-12)
+    with pytest.raises(NotImplementedError):
+        c2.run_one(4, specs[0], quad=True, degree=2, params=pa.DPPParameters())

@@ -101,3 +101,62 @@ def test_G5_conditioning_3d_hex_through_the_public_api(N):
         sparse = estimate_condition_numbers(W, params=params, bcs=bcs, use_sparse=True, num_of_factors=50)   # ARPACK branch
         for k, col in cols:
             assert sparse[k] == pytest.approx(g[col], rel=1e-6), (k, sparse[k], g[col])
+
+
+# ---- notebooks/results-conforming-2d/convergence.csv + convergence_eoc.csv through convergence_2d ----
+ROWS_CONV = [(r["solver"], int(r["N"])) for r in _G["G10_convergence_2d"]]
+_CONV_DONE = {}
+
+
+def _convergence_row(solver, N):
+    import perphil_amd as pa
+    from perphil_amd import convergence_2d as c2
+    from perphil_amd.iterative_bench import Approach
+
+    if (solver, N) not in _CONV_DONE:
+        spec = c2.approach_solvers([Approach(solver)])[0]
+        _CONV_DONE[(solver, N)] = c2.run_one(N=N, solver=spec, quad=True, degree=1, params=pa.DPPParameters())
+    return _CONV_DONE[(solver, N)]
+
+
+def check_convergence_row(row, g):
+    """One row of the h-convergence study against the reference's (shared with tools/r3_convergence_2d.py): iteration
+    counts exact (plain GMRES included: 10 ... 11 765); the four error norms to 2e-9 from N = 8 on and to 1e-6 on the 4 x 4
+    mesh (measured: 7.7e-8 there, <= 1.2e-10 elsewhere - the reference integrates the UFL error with the quadrature degree
+    its form compiler estimates, the device with 6 Gauss points per direction, and the difference is the coarse-mesh
+    quadrature error of the former)."""
+    assert list(row.keys()) == _G["convergence_csv_columns"]
+    assert row["h"] == g["h"] and row["degree"] == g["degree"] and row["quad"] == g["quad"]
+    name, its, ref = g["solver"], row["it"], int(g["it"])
+    if name == "GMRES":
+        assert its == ref, (its, ref)
+        assert row["res"] == pytest.approx(g["res"], rel=0.35 if N_dofs(g) < 300 else 5e-3)
+    elif name == "Monolithic LU with MUMPS":
+        assert its == ref == 1
+    else:
+        assert its == ref, (its, ref)
+        assert row["res"] == pytest.approx(g["res"], rel=1e-3)
+    for k in ("e1_L2", "e2_L2", "e1_H1s", "e2_H1s"):
+        assert row[k] == pytest.approx(g[k], rel=1e-6 if int(g["N"]) == 4 else 2e-9), (k, row[k], g[k])
+
+
+def N_dofs(g):
+    return 2 * (int(g["N"]) + 1) ** 2
+
+
+@pytest.mark.parametrize("solver,N", ROWS_CONV)
+def test_convergence_2d_row(solver, N):
+    g = next(r for r in _G["G10_convergence_2d"] if r["solver"] == solver and int(r["N"]) == N)
+    check_convergence_row(_convergence_row(solver, N), g)
+
+
+def test_convergence_2d_observed_orders():
+    """convergence_eoc.csv: the least-squares orders over N = 4 .. 128 (1.939 in L2, 0.9448 in the H1 seminorm) for every
+    solver and both pressures, to 1e-7 (measured 8e-9)."""
+    from perphil_amd import convergence_2d as c2
+
+    rows = [_convergence_row(s, N) for s, N in ROWS_CONV]
+    got = {(r["solver"], r["err"]): r["slope"] for r in c2.observed_orders(rows)}
+    assert len(got) == len(_G["G10_convergence_2d_eoc"]) == 20
+    for r in _G["G10_convergence_2d_eoc"]:
+        assert got[(r["solver"], r["err"])] == pytest.approx(r["slope"], rel=1e-7), r
