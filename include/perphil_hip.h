@@ -245,7 +245,11 @@ int pph_comm_stats(pph_ctx* ctx, int64_t* halo_exchanges, int64_t* allreduces, i
  * fine-level operators only (rows >= nodes of the mesh), i.e. without the coarser multigrid levels;
  * out[14] products of the last solve launched as interior + boundary rows (option "halo_overlap", slabs only);
  * out[15] 1 when the stencil-ELL blocks of the last assembly use symmetric storage;
- * out[16] the most partial sums a split product has written into one reduction slot so far (<= option "part_cap"). */
+ * out[16] the most partial sums a split product has written into one reduction slot so far (<= option "part_cap");
+ * out[17] stencil-ELL operators (fine blocks + multigrid levels) whose products run on a row dictionary (option
+ * "sell_dict": distinct rows stored once + a 2-byte class per row; their launches count (2 + 16 + e) nrows bytes),
+ * out[18] distinct rows of A11 found by the last build (0: not tried), out[19] its status on the device (1 in use,
+ * 0 not built, -1 more distinct rows than the cap, -2 a row failed the bitwise check: plain storage is used). */
 int pph_get_timers(pph_ctx* ctx, double* out, int n);
 /* tuning / profiling switches (no reference counterpart; defaults in brackets):
  *   "op_format" [1]      operator format of the scalar blocks inside block solves / Picard sweeps: 1 stencil-ELL

@@ -355,12 +355,13 @@ class Context:
         return {"halo_exchanges": h.value, "allreduces": a.value, "status": st.value}
 
     def timers(self) -> dict:
-        t = np.zeros(17, dtype=np.float64)
-        self._check(lib.pph_get_timers(self._h, _ptr(t), 17))
+        t = np.zeros(20, dtype=np.float64)
+        self._check(lib.pph_get_timers(self._h, _ptr(t), 20))
         return {"mesh_ms": t[0], "assemble_ms": t[1], "bc_blocks_ms": t[2], "solve_ms": t[3],
                 "spmv_ms": t[4], "spmv_launches": int(t[5]), "spmv_bytes": t[6],
                 "spmv_dot_ms": t[7], "spmv_dot_launches": int(t[8]), "spmv_dot_bytes": t[9],
                 "halo_exchanges": int(t[10]),
                 "spmv_fine_ms": t[11], "spmv_fine_launches": int(t[12]), "spmv_fine_bytes": t[13],
                 "split_products": int(t[14]), "symmetric_storage": bool(t[15]),
-                "max_split_partials": int(t[16])}
+                "max_split_partials": int(t[16]),
+                "dict_operators": int(t[17]), "dict_classes": int(t[18]), "dict_status": int(t[19])}

@@ -48,6 +48,7 @@ template struct DevBuf<float>;
 template struct DevBuf<int32_t>;
 template struct DevBuf<int64_t>;
 template struct DevBuf<uint8_t>;
+template struct DevBuf<uint16_t>;
 template struct DevBuf<unsigned long long>;
 
 // Dirichlet data of one field: the ghost-plane flag (bit 1) of the mask survives, the constrained flag (bit 0) and the
@@ -141,6 +142,7 @@ static void release_system(pph_ctx* ctx) {
 static void free_system(pph_ctx* ctx) {
   ctx->A11.release(); ctx->A22.release(); ctx->A12.release(); ctx->A21.release();
   ctx->E11.release(); ctx->E22.release(); ctx->E12.release(); ctx->E21.release();
+  ctx->D11.release(); ctx->D22.release(); ctx->D12.release();
   ctx->rhs.release(); ctx->u0.release(); ctx->sol.release();
   ctx->mrowptr.release(); ctx->mcol.release(); ctx->mval.release();
   mg_release(ctx);
@@ -620,6 +622,29 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
   }
   if (!strcmp(name, "sell_flags")) { ctx->sell_flags = (int)value; la_release_graphs(ctx); return PPH_OK; }
   if (!strcmp(name, "sell_group")) { ctx->sell_group = (int)value; return PPH_OK; }
+  // row dictionaries of the stencil-ELL blocks (pph_internal.h: struct SellDict); takes effect at the next assembly
+  if (!strcmp(name, "sell_dict")) {
+    ctx->sell_dict = value != 0;
+    if (!ctx->sell_dict) {   // off: at once (the plain storage is always there); on: built by the next assembly
+      ctx->S11.dict = ctx->S22.dict = ctx->S12.dict = ctx->S21.dict = nullptr;
+      for (auto& L : ctx->mg) L.ell[0].dict = L.ell[1].dict = nullptr;
+    }
+    la_release_graphs(ctx);
+    return PPH_OK;
+  }
+  if (!strcmp(name, "sell_dict_min_rows")) { ctx->sell_dict_min_rows = (int64_t)value; return PPH_OK; }
+  if (!strcmp(name, "sell_dict_blocks")) { ctx->sell_dict_blocks = (int)value; la_release_graphs(ctx); return PPH_OK; }
+  if (!strcmp(name, "sell_dict_zwalk")) { ctx->sell_dict_zwalk = (int)value; la_release_graphs(ctx); return PPH_OK; }
+  if (!strcmp(name, "sell_dict_cap")) { ctx->sell_dict_cap = (int)value; return PPH_OK; }
+  if (!strcmp(name, "sell_dict_poison")) {
+    // tests: mark the dictionaries of the fine blocks as failed ON THE DEVICE only, as a failed re-assembly check would -
+    // the products launched for them must then take the stored values (the plain path inside the dictionary kernel)
+    static const int bad = -2;
+    for (SellDict* D : {&ctx->D11, &ctx->D22, &ctx->D12})
+      if (D->state.p) PPH_HIP(ctx, hipMemcpyAsync(D->state.p + 1, &bad, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PPH_OK;
+  }
   if (!strcmp(name, "asm_tile")) { ctx->asm_tile = (value == 2.0) ? 2 : (value != 0.0 ? 1 : 0); return PPH_OK; }
   if (!strcmp(name, "asm_node_xmap")) { ctx->asm_node_xmap = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "asm_node")) { ctx->asm_node = value != 0.0 ? 1 : 0; return PPH_OK; }
@@ -669,12 +694,23 @@ int pph_comm_set_callbacks(pph_ctx* ctx, int rank, int world, pph_halo_fn halo, 
 int pph_get_timers(pph_ctx* ctx, double* out, int n) {
   if (!ctx || !out) return PPH_ERR_INVALID;
   la_harvest_spmv_times(ctx);
-  const double v[17] = {ctx->t_mesh, ctx->t_asm, ctx->t_bc, ctx->t_solve,
+  // row dictionaries: operators using one now (fine blocks and multigrid levels), classes of A11's, device status of A11's
+  int dn = 0;
+  for (const Sell* E : {&ctx->S11, &ctx->S22, &ctx->S12}) dn += (E->dict && E->dict->on) ? 1 : 0;
+  for (size_t l = 1; l < ctx->mg.size(); ++l)
+    for (int f = 0; f < 2; ++f) dn += (ctx->mg[l].ell[f].dict && ctx->mg[l].ell[f].dict->on) ? 1 : 0;
+  int dst[2] = {0, 0};
+  if (ctx->D11.on && ctx->D11.state.p) {
+    (void)hipMemcpyAsync(dst, ctx->D11.state.p, sizeof(dst), hipMemcpyDeviceToHost, ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
+  }
+  const double v[20] = {ctx->t_mesh, ctx->t_asm, ctx->t_bc, ctx->t_solve,
                         ctx->t_spmv[0], (double)ctx->n_spmv[0], ctx->spmv_bytes[0],
                         ctx->t_spmv[1], (double)ctx->n_spmv[1], ctx->spmv_bytes[1], (double)ctx->n_halo,
                         ctx->t_spmv_fine, (double)ctx->n_spmv_fine, ctx->spmv_bytes_fine, (double)ctx->n_split,
-                        (ctx->ell_ok && ctx->S11.sym) ? 1.0 : 0.0, (double)ctx->max_split_partials};
-  for (int i = 0; i < n && i < 17; ++i) out[i] = v[i];
+                        (ctx->ell_ok && ctx->S11.sym) ? 1.0 : 0.0, (double)ctx->max_split_partials,
+                        (double)dn, (double)(ctx->D11.tried ? ctx->D11.ncls : 0), (double)(ctx->D11.on ? dst[1] : ctx->D11.status)};
+  for (int i = 0; i < n && i < 20; ++i) out[i] = v[i];
   return PPH_OK;
 }
 

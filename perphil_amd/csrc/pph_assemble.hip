@@ -2451,6 +2451,13 @@ int pph_launch_assemble_fused(pph_ctx* ctx, int monolithic) {
   PPH_TRY(pph_launch_fused_kernels(ctx, mesh, fa, ctx->asm_keep_km ? mesh.K.p : nullptr,
                                    ctx->asm_keep_km ? mesh.M.p : nullptr));
   PPH_HIP(ctx, hipGetLastError());
+  if (ell) {
+    // row dictionaries of the three stored blocks (sell_dict): built on the first assembly, re-read and checked on the next
+    PPH_TRY(sell_dict_update(ctx, &ctx->S11, ctx->D11, n));
+    PPH_TRY(sell_dict_update(ctx, &ctx->S22, ctx->D22, n));
+    PPH_TRY(sell_dict_update(ctx, &ctx->S12, ctx->D12, n));
+    if (ctx->a21_alias) ctx->S21 = ctx->S12;
+  }
   mesh.km_valid = ctx->asm_keep_km != 0;
   ctx->diag0_valid = true;
   ctx->ell_ok = ell;

@@ -67,12 +67,39 @@ struct MeshData;
 // for s >= S/2.  Entry (r, r + o) with o < 0 is read as entry (r + o, r) from the mirror slot of row r + o: every stored
 // value is used by two rows, S/2 + 1 instead of S streams.
 #define PPH_SELL_COLUMN_WALK 1000   // sell_zwalk >= this: balanced column walk (pph_sell.hip)
+// Row dictionary of a stencil-ELL operator (pph_sell.hip, "sell_dict"): on the reference's meshes (uniform boxes, constant
+// coefficients) almost all rows of a block are the SAME 27 numbers - interior rows, rows next to a Dirichlet face, ...
+// The dictionary stores every distinct row once (tab[class][slot], all S slots: no mirrors to fetch) and a 2-byte class
+// per row; a product then streams 2 B instead of 8 (S/2 + 1) B per row and takes its coefficients from LDS.  Lossless: two
+// rows share a class only if all S coefficients the plain kernel would load for them are bitwise equal (checked for every
+// row by k_dict_verify after every assembly), the sums run in the plain kernel's order, so products are bit-identical.
+// More classes than PPH_DICT_CAP (graded / perturbed meshes, variable coefficients) or a failed check: the operator keeps
+// its plain storage and kernel.
+#define PPH_DICT_CAP 256      // classes (LDS: 256 x 27 x 8 B = 54 KB)
+#define PPH_DICT_HASH 4096    // open-addressing slots of the build
+struct SellDict {
+  DevBuf<uint16_t> cls;              // [ld] class of a row (hash slot between build and remap)
+  DevBuf<unsigned long long> keys;   // [PPH_DICT_HASH] 64-bit row hashes, 0 = empty
+  DevBuf<int64_t> rep;               // [PPH_DICT_HASH] a row of the class that won hash slot h; [PPH_DICT_HASH + c]: of class c
+  DevBuf<uint16_t> map;              // [PPH_DICT_HASH] hash slot -> class
+  DevBuf<double> tab;                // [PPH_DICT_CAP][S]
+  DevBuf<int> state;                 // [0] classes  [1] 1 usable / 0 not built / < 0 refused  (read by every product launch)
+  int ncls = 0;                      // host copy of state[0] after the build
+  bool on = false;                   // products use the dictionary
+  bool tried = false;                // a build was attempted for the current mesh / Dirichlet sets
+  int status = 0;                    // host copy of state[1] after the build
+  int64_t n = 0;
+  int px = 0, py = 0, bc_epoch = -1, cap = 0;   // ... and the configuration it was built (or refused) for
+  const double* val = nullptr;       // the storage it describes
+  void release() { cls.release(); keys.release(); rep.release(); map.release(); tab.release(); state.release(); ncls = 0; on = tried = false; n = 0; val = nullptr; }
+};
 struct Sell {
   const double* val = nullptr;
   int64_t ld = 0;            // leading dimension: rows rounded up to a multiple of 64
   int kind = -1;             // PPH_CELL_*
   int px = 0, py = 0, pz = 0;  // node dims of the local box
   int sym = 0;               // 1: upper half only (see above)
+  const SellDict* dict = nullptr;   // set while the row dictionary of this storage is usable
 };
 static inline int sell_slots(int kind) {
   return kind == PPH_CELL_QUAD ? 9 : kind == PPH_CELL_TRI ? 7 : kind == PPH_CELL_HEX ? 27 : 15;
@@ -189,6 +216,7 @@ struct MgLevel {
   int px = 0, py = 0, pz = 0;
   DevBuf<double> own_val[2];     // storage of val[] on coarse levels
   DevBuf<double> own_ell[2];     // stencil-ELL storage of the level operators (op_format 1; level 0 aliases the context's)
+  SellDict dict[2];              // row dictionaries of own_ell (sell_dict)
   Sell ell[2];                   // views used by the products when ell[f].val is set
   DevBuf<float> val32[2];        // fp32 copies of val[] for the smoother / residual SpMVs of the V-cycle
   DevBuf<double> dinv[2];
@@ -279,6 +307,7 @@ struct pph_ctx {
   // then materialised on demand (pph_ensure_csr_blocks: export, monolithic CSR, Jacobi / 2x2-block preconditioners)
   DevBuf<double> E11, E22, E12, E21;
   Sell S11, S22, S12, S21;              // views of E* (S21 == S12 when a21_alias)
+  SellDict D11, D22, D12;               // their row dictionaries (sell_dict; S21 shares D12 when aliased, else none)
   bool ell_ok = false;                  // S* hold the assembled blocks
   bool csr_ok = false;                  // A11 .. A21 hold the assembled blocks
   DevBuf<double> rhs, u0, sol;          // length 2n
@@ -372,6 +401,10 @@ struct pph_ctx {
   int sell_patch = 0, sell_patch_z = 16; // (EXPERIMENTS build) a wave climbs a 16 x 8 patch, mirrors of its own rows from wave-private LDS; planes per climb
   int sell_lds = 0;                     // (EXPERIMENTS build) symmetric 27-point operators on z-walk levels: mirrored values handed over through LDS
   int sell_flags = 0;                   // experiments: 1 non-temporal y stores (mode 0), 2 non-temporal loads of the diagonal slot
+  int sell_dict = 0;                    // row dictionaries for the stencil-ELL blocks (struct SellDict)
+  int64_t sell_dict_min_rows = 1000000; // ... of operators with at least this many rows
+  int sell_dict_blocks = 2048, sell_dict_zwalk = -1;   // grid cap of a dictionary product; z-walk (-1: as sell_zwalk)
+  int sell_dict_cap = PPH_DICT_CAP;     // classes accepted (tests lower it to force the plain path)
   int sell_rpt = 2, sell_blocks = 0, sell_group = 0;   // SELL SpMV tuning: rows per thread, grid cap, XCD chunk group
   DevBuf<double> sell_tmp;              // SELL copy of the matrix last selected by pph_spmv / pph_spmv_bench
 };
@@ -481,6 +514,13 @@ int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x,
               const double* w /* device */, double* y, double* part, int64_t dlo = 0, int64_t dhi = 0, double* aux = nullptr, double* z0 = nullptr,
               int64_t cbeg = 0, int64_t cend = -1, int grid_cap = 0);
 int sell_alloc(pph_ctx* ctx, const MeshData& mesh, DevBuf<double>& buf, Sell* out, int sym);
+// operator bytes a product streams per row: the stored values, or the 2-byte class with a usable row dictionary
+static inline double sell_stream_bytes(const pph_ctx* ctx, const Sell& E) {
+  const bool dict = ctx->sell_rpt != 1 && E.sym && E.dict && E.dict->on && (E.kind == PPH_CELL_HEX || E.kind == PPH_CELL_QUAD);
+  return dict ? 2.0 : 8.0 * sell_stored(E.kind, E.sym);
+}
+// (re)builds the row dictionary of E after its values were (re)written; sets / clears E->dict
+int sell_dict_update(pph_ctx* ctx, Sell* E, SellDict& D, int64_t n);
 int sell_from_csr(pph_ctx* ctx, const MeshData& mesh, const double* csr_val, DevBuf<double>& buf, Sell* out, int sym);
 // symmetric storage is used for operators that are symmetric on the local box: single context (a slab's ghost rows
 // are empty, which breaks the symmetry of the local matrix) and option sell_sym on

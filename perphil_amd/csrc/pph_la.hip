@@ -292,7 +292,7 @@ static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const doub
     // algorithmic bytes: every stored value once, x read once, y written once, plus the epilogue's vectors
     // (b for the residual form; b and 1 / a_ii for the Jacobi update)
     const double extra = jdinv ? 16.0 : (bvec ? 8.0 : 0.0);
-    const double bytes = (8.0 * sell_stored(A.ell.kind, A.ell.sym) + 16.0 + extra) * (double)A.nrows;
+    const double bytes = (sell_stream_bytes(ctx, A.ell) + 16.0 + extra) * (double)A.nrows;
     ctx->n_spmv[variant]++;
     ctx->spmv_bytes[variant] += bytes;
     if (A.nrows >= ctx->mesh.n) { ctx->n_spmv_fine++; ctx->spmv_bytes_fine += bytes; }
@@ -411,7 +411,7 @@ void la_spmv_shift(pph_ctx* ctx, const Csr& A, const double* x, const double* b,
   }
   const int grid = sell_product(ctx, A, b ? 5 : 6, x, b, z0 ? dinv0 : nullptr, z0 ? w0 : nullptr, told, part, dlo, dhi, R, z0, true);
   if (ev) (void)hipEventRecord(ev->e1, ctx->stream);
-  const double bytes = (8.0 * sell_stored(A.ell.kind, A.ell.sym) + 16.0 + (b ? 8.0 : 0.0) + 24.0 + (z0 ? 16.0 : 0.0)) * (double)A.nrows;
+  const double bytes = (sell_stream_bytes(ctx, A.ell) + 16.0 + (b ? 8.0 : 0.0) + 24.0 + (z0 ? 16.0 : 0.0)) * (double)A.nrows;
   ctx->n_spmv[0]++;
   ctx->spmv_bytes[0] += bytes;
   if (A.nrows >= ctx->mesh.n) { ctx->n_spmv_fine++; ctx->spmv_bytes_fine += bytes; }

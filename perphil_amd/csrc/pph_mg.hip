@@ -429,7 +429,7 @@ void mg_release(pph_ctx* ctx) {
     MgLevel& L = ctx->mg[l];
     if (l > 0) L.mesh.release_all();
     for (int f = 0; f < 2; ++f) {
-      L.own_val[f].release(); L.own_ell[f].release(); L.dinv[f].release(); L.mask[f].release(); L.val32[f].release();
+      L.own_val[f].release(); L.own_ell[f].release(); L.dict[f].release(); L.dinv[f].release(); L.mask[f].release(); L.val32[f].release();
       L.ell[f] = Sell();
     }
     L.x.release(); L.b.release(); L.r.release(); L.d.release(); L.t.release(); L.w.release();
@@ -593,6 +593,8 @@ int mg_setup(pph_ctx* ctx) {
                                            ell_only ? L.own_ell[1].p : L.own_val[1].p, L.dinv[0].p, L.dinv[1].p,
                                            lamdev.p + 2 * l, ell_only ? L.ell[0].ld : 0, ell_only ? L.ell[0].sym : 0));
         level_fused = true;
+        if (ell_only)
+          for (int f = 0; f < 2; ++f) PPH_TRY(sell_dict_update(ctx, &L.ell[f], L.dict[f], L.n));
       } else {
         for (int f = 0; f < 2; ++f) {
           pph_launch_scalar_block(ctx, m, L.maskp[f], coefK[f], ctx->b, L.own_val[f].p);

@@ -81,17 +81,30 @@ __device__ __forceinline__ void sell_epilogue(const double (&acc)[RPT], const do
 // MODE 2 / 4 / 5 / 6 / 7 write one partial sum per workgroup to part[blockIdx.x]; the caller finishes the sum.
 // One thread owns RPT consecutive rows; a workgroup a chunk of 256 RPT rows.  Chunks are dealt to the XCDs in groups
 // of `group` consecutive chunks (group 1 = plain grid-stride order); workgroups with equal blockIdx % 8 share an XCD.
-template <int KIND, int MODE, int RPT, bool CLAMP, bool SYM = false>
+// DICT: the coefficients come from the row dictionary (struct SellDict): dtab = its table in LDS, cls = the classes;
+// x loads, order of the sums and epilogue are the plain kernel's, so the products are bit-identical
+template <int KIND, int MODE, int RPT, bool CLAMP, bool SYM = false, bool DICT = false>
 __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_t ld, const double* __restrict__ x,
                                           const double* __restrict__ b, const double* __restrict__ dinv, double w,
                                           double* __restrict__ y, double* __restrict__ aux, double* __restrict__ z0,
                                           int64_t n, int px, int64_t pxy, int64_t r0, double& dotacc, int64_t dlo,
-                                          int64_t dhi, double* dotx = nullptr, int flags = 0) {
+                                          int64_t dhi, double* dotx = nullptr, int flags = 0,
+                                          const uint16_t* __restrict__ cls = nullptr, const double* dtab = nullptr) {
   using ST = SellSt<KIND>;
   double acc[RPT];
   double bv[RPT], xr[RPT], dv[RPT], tv[RPT], av[RPT];
   bool act[RPT];
   sell_prologue<MODE, RPT, CLAMP>(x, b, dinv, y, aux, z0, n, r0, acc, bv, xr, dv, tv, av, act);
+  int cb[RPT];   // DICT: offset of the row's class in the table
+  if constexpr (DICT) {
+    if constexpr (RPT == 2 && !CLAMP) {
+      const uint32_t two = *reinterpret_cast<const uint32_t*>(cls + r0);   // (r0 even, cls 256-byte aligned)
+      cb[0] = (int)(two & 0xffffu) * ST::S; cb[1] = (int)(two >> 16) * ST::S;
+    } else {
+#pragma unroll
+      for (int i = 0; i < RPT; ++i) cb[i] = act[i] ? (int)cls[r0 + i] * ST::S : 0;
+    }
+  }
   int slot = 0;
 #pragma unroll
   for (int l = 0; l < ST::NL; ++l) {
@@ -128,7 +141,10 @@ __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_
       constexpr int C0 = ST::S / 2;
       const double* vp = val + (int64_t)(SYM ? (slot >= C0 ? slot - C0 : 0) : slot) * ld + r0;
       double v[RPT];
-      if (SYM && slot < C0) {
+      if constexpr (DICT) {
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) v[i] = act[i] ? dtab[cb[i] + slot] : 0.0;
+      } else if (SYM && slot < C0) {
         const int64_t off = (int64_t)(d - 1) + (int64_t)ST::dy(l) * px + (int64_t)ST::dz(l) * pxy;
         const double* mp = val + (int64_t)(ST::S - 1 - slot - C0) * ld;
 #if defined(PPH_SELL_PROBE) && PPH_SELL_PROBE >= 2
@@ -168,7 +184,9 @@ __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_
   sell_epilogue<MODE, RPT>(acc, bv, xr, dv, tv, av, act, w, y, aux, z0, r0, dotacc, dlo, dhi, dotx, flags);
 }
 
-template <int KIND, int MODE, int RPT, bool SYM = false>
+struct SellDictArgs { const uint16_t* cls; const double* tab; const int* state; int ncls; };
+
+template <int KIND, int MODE, int RPT, bool SYM = false, bool DICT = false>
 __global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ val, int64_t ld,
                                                    const double* __restrict__ x, const double* __restrict__ b,
                                                    const double* __restrict__ dinv, const double* __restrict__ wp,
@@ -176,8 +194,19 @@ __global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ va
                                                    double* __restrict__ z0, int64_t n, int px, int64_t pxy, int64_t halo,
                                                    int64_t nchunks, int64_t chunk0,
                                                    int group, int zwalk, int xmap, double* __restrict__ part,
-                                                   int64_t dlo, int64_t dhi, int flags) {
+                                                   int64_t dlo, int64_t dhi, int flags, SellDictArgs da) {
   constexpr int CH = 256 * RPT;
+  // DICT: the table of distinct rows -> LDS, if the device-side state says this assembly's dictionary is the one the
+  // host sized the launch for; otherwise (check failed, rebuilt with another class count) the plain path below
+  extern __shared__ double dtab[];
+  bool dok = false;
+  if constexpr (DICT) {
+    dok = da.state[0] == da.ncls && da.state[1] == 1;
+    if (dok) {
+      for (int i = threadIdx.x; i < da.ncls * SellSt<KIND>::S; i += 256) dtab[i] = da.tab[i];
+      __syncthreads();
+    }
+  }
   const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, bpx = gridDim.x >> 3;   // launcher keeps gridDim.x a multiple of 8
   // the smoother weight lives in device memory (refreshed per assembly) so that captured graphs survive a re-assembly
   const double w = (MODE == 3 || MODE == 4 || ((MODE == 5 || MODE == 6) && z0)) ? *wp : 0.0;
@@ -226,6 +255,15 @@ __global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ va
     const int64_t r0 = c0 + (int64_t)threadIdx.x * RPT;
     // a chunk whose rows and x window lie inside [0, n) needs no index clamps and no row masks (all but the first
     // and last few chunks)
+    if constexpr (DICT) {
+      if (dok) {
+        if (c0 >= halo && c0 + CH + halo <= n)
+          sell_rows<KIND, MODE, RPT, false, SYM, true>(val, ld, x, b, dinv, w, y, aux, z0, n, px, pxy, r0, dotacc, dlo, dhi, dotx, flags, da.cls, dtab);
+        else
+          sell_rows<KIND, MODE, RPT, true, SYM, true>(val, ld, x, b, dinv, w, y, aux, z0, n, px, pxy, r0, dotacc, dlo, dhi, dotx, flags, da.cls, dtab);
+        continue;
+      }
+    }
     if (c0 >= halo && c0 + CH + halo <= n)
       sell_rows<KIND, MODE, RPT, false, SYM>(val, ld, x, b, dinv, w, y, aux, z0, n, px, pxy, r0, dotacc, dlo, dhi, dotx, flags);
     else
@@ -261,14 +299,40 @@ static void sell_launch_mode(pph_ctx* ctx, int mode, int grid, const Sell& E, co
                              int group, double* part, int64_t dlo, int64_t dhi) {
   const int64_t pxy = (int64_t)E.px * E.py;
   const int64_t halo = (E.pz > 1 ? pxy : 0) + E.px + 2;   // reach of the x window of a row (2D: no z lines)
-  const int zwalk = (E.sym && E.pz > 2 && ctx->sell_zwalk > 0 && chunk0 == 0 && nchunks >= ctx->sell_zwalk_min_chunks) ? ctx->sell_zwalk : 0;   // (no gain on full storage)
+  int zwalk = (E.sym && E.pz > 2 && ctx->sell_zwalk > 0 && chunk0 == 0 && nchunks >= ctx->sell_zwalk_min_chunks) ? ctx->sell_zwalk : 0;   // (no gain on full storage)
+  const SellDictArgs nod = {nullptr, nullptr, nullptr, 0};
 #define PPH_SELL_GO(MM)                                                                                              \
   hipLaunchKernelGGL((k_spmv_sell<KIND, MM, RPT>), dim3(grid), dim3(256), 0, ctx->stream, E.val, E.ld, x, b, dinv, w, \
-                     y, aux, z0, n, E.px, pxy, halo, nchunks, chunk0, group, zwalk, ctx->sell_xmap, part, dlo, dhi, ctx->sell_flags)
+                     y, aux, z0, n, E.px, pxy, halo, nchunks, chunk0, group, zwalk, ctx->sell_xmap, part, dlo, dhi, ctx->sell_flags, nod)
+  if constexpr (RPT == 2 && (KIND == PPH_CELL_HEX || KIND == PPH_CELL_QUAD)) {
+    if (E.sym && E.dict && E.dict->on) {
+      // row dictionary: 2 B per row instead of the value streams; the table of distinct rows goes to LDS
+      const SellDict& D = *E.dict;
+      const SellDictArgs da = {D.cls.p, D.tab.p, D.state.p, D.ncls};
+      const size_t lds = (size_t)D.ncls * SellSt<KIND>::S * sizeof(double);
+      if (ctx->sell_dict_zwalk >= 0) zwalk = (E.pz > 2 && chunk0 == 0) ? ctx->sell_dict_zwalk : 0;
+#define PPH_SELL_GOD(MM)                                                                                                       \
+  hipLaunchKernelGGL((k_spmv_sell<KIND, MM, 2, true, true>), dim3(grid), dim3(256), lds, ctx->stream, E.val, E.ld, x, b, dinv, \
+                     w, y, aux, z0, n, E.px, pxy, halo, nchunks, chunk0, group, zwalk, ctx->sell_xmap, part, dlo, dhi,         \
+                     ctx->sell_flags, da)
+      switch (mode) {
+        case 0: PPH_SELL_GOD(0); break;
+        case 1: PPH_SELL_GOD(1); break;
+        case 2: PPH_SELL_GOD(2); break;
+        case 3: PPH_SELL_GOD(3); break;
+        case 4: PPH_SELL_GOD(4); break;
+        case 5: PPH_SELL_GOD(5); break;
+        case 6: PPH_SELL_GOD(6); break;
+        default: PPH_SELL_GOD(7); break;
+      }
+#undef PPH_SELL_GOD
+      return;
+    }
+  }
   if (E.sym) {
 #define PPH_SELL_GOS(MM)                                                                                                   \
   hipLaunchKernelGGL((k_spmv_sell<KIND, MM, RPT, true>), dim3(grid), dim3(256), 0, ctx->stream, E.val, E.ld, x, b, dinv, w, \
-                     y, aux, z0, n, E.px, pxy, halo, nchunks, chunk0, group, zwalk, ctx->sell_xmap, part, dlo, dhi, ctx->sell_flags)
+                     y, aux, z0, n, E.px, pxy, halo, nchunks, chunk0, group, zwalk, ctx->sell_xmap, part, dlo, dhi, ctx->sell_flags, nod)
     switch (mode) {
       case 0: PPH_SELL_GOS(0); break;
       case 1: PPH_SELL_GOS(1); break;
@@ -320,8 +384,11 @@ int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x,
     if (g > 0) return g;
   }
 #endif
+  const bool dict = rpt == 2 && E.sym && E.dict && E.dict->on && (E.kind == PPH_CELL_HEX || E.kind == PPH_CELL_QUAD);
   int cap = (ctx->sell_blocks >= 8 && ctx->sell_blocks <= 8192) ? (ctx->sell_blocks / 8) * 8
                                                                  : (zw ? ((ctx->num_cus + 7) / 8) * 8 : 4096);
+  // (a dictionary product streams vectors only: nothing to keep in L2 for a second reader, many waves to hide latency)
+  if (dict && ctx->sell_dict_blocks >= 8) cap = (ctx->sell_dict_blocks / 8) * 8;
   if ((mode == 2 || mode >= 4) && cap > PPH_PART_STRIDE) cap = PPH_PART_STRIDE;   // one partial sum per workgroup
   // (a product launched as several row ranges shares the PPH_PART_STRIDE partial sums of a slot: sell_product)
   if (grid_cap >= 8 && cap > grid_cap) cap = (grid_cap / 8) * 8;
@@ -340,6 +407,181 @@ int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x,
   }
 #undef PPH_SELL_KIND
   return grid;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row dictionary (struct SellDict, pph_internal.h): build, table, check
+// ------------------------------------------------------------------------------------------------
+static inline int sell_grid(int64_t n) {
+  int64_t b = ceil_div64(n, 256);
+  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+// the coefficient k_spmv_sell multiplies x[r + off] with for row r and (full) slot s: the stored value, or - symmetric
+// storage, lower slot - the mirror slot of row r + off (0 outside [0, n): the kernel's clamped chunks)
+__device__ __forceinline__ double sell_coef(const double* __restrict__ val, int64_t ld, int sym, int S, int s, int64_t r,
+                                            int64_t off, int64_t n) {
+  const int c0 = S / 2;
+  if (!sym) return val[(int64_t)s * ld + r];
+  if (s >= c0) return val[(int64_t)(s - c0) * ld + r];
+  const int64_t rr = r + off;
+  return (rr >= 0 && rr < n) ? val[(int64_t)(S - 1 - s - c0) * ld + rr] : 0.0;
+}
+__device__ __forceinline__ int64_t sell_off(const Stencil& st, int s, int px, int64_t pxy) {
+  return (int64_t)st.d[s][0] + (int64_t)st.d[s][1] * px + (int64_t)st.d[s][2] * pxy;
+}
+__device__ __forceinline__ unsigned long long dict_mix(unsigned long long h, unsigned long long v) {
+  h = (h ^ v) * 0xFF51AFD7ED558CCDull;
+  h ^= h >> 29;
+  h *= 0xC4CEB9FE1A85EC53ull;
+  return h ^ (h >> 32);
+}
+
+// pass 1: hash of a row's S coefficients -> open-addressing table; cls[row] = the slot its hash lives in.  Rows whose
+// hash is already there (all but a handful) only read.  state[0] counts the distinct hashes; more than `cap`, or a
+// probe sequence longer than 64, refuses the dictionary (state[1] = -1) and lets the remaining rows return at once.
+__global__ __launch_bounds__(256) void k_dict_build(const double* __restrict__ val, int64_t ld, int sym, Stencil st, int px,
+                                                    int64_t pxy, int64_t n, unsigned long long* keys, int64_t* rep,
+                                                    uint16_t* __restrict__ cls, int* state, int cap) {
+  const int S = st.count;
+  volatile int* vstate = state;
+  for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < n; row += (int64_t)gridDim.x * blockDim.x) {
+    if (vstate[1] < 0) return;
+    unsigned long long h = 0x9E3779B97F4A7C15ull;
+    for (int s = 0; s < S; ++s)
+      h = dict_mix(h, (unsigned long long)__double_as_longlong(sell_coef(val, ld, sym, S, s, row, sell_off(st, s, px, pxy), n)));
+    if (h == 0ull) h = 1ull;
+    unsigned slot = (unsigned)(h >> 40) & (PPH_DICT_HASH - 1);
+    for (int probe = 0;; ++probe) {
+      unsigned long long k = __atomic_load_n(keys + slot, __ATOMIC_RELAXED);
+      if (k == 0ull) {
+        k = atomicCAS(keys + slot, 0ull, h);
+        if (k == 0ull) {   // this row's hash is new: it represents the class
+          rep[slot] = row;
+          if (atomicAdd(state, 1) + 1 > cap) atomicExch(state + 1, -1);
+          k = h;
+        }
+      }
+      if (k == h) break;
+      slot = (slot + 1) & (PPH_DICT_HASH - 1);
+      if (probe >= 64) { atomicExch(state + 1, -1); break; }
+    }
+    cls[row] = (uint16_t)slot;
+  }
+}
+
+// pass 2 (one workgroup): classes = occupied hash slots in slot order; tab[class] = the coefficients of its
+// representative row.  refresh: the classes are known from an earlier assembly, only the table is read again.
+__global__ __launch_bounds__(256) void k_dict_table(const double* __restrict__ val, int64_t ld, int sym, Stencil st, int px,
+                                                    int64_t pxy, int64_t n, const unsigned long long* __restrict__ keys,
+                                                    int64_t* rep, uint16_t* __restrict__ map, double* __restrict__ tab,
+                                                    int* state, int cap, int refresh, int ncls) {
+  const int S = st.count;
+  if (refresh) {
+    for (int c = threadIdx.x; c < ncls; c += 256) {
+      const int64_t row = rep[PPH_DICT_HASH + c];
+      for (int s = 0; s < S; ++s) tab[c * S + s] = sell_coef(val, ld, sym, S, s, row, sell_off(st, s, px, pxy), n);
+    }
+    if (threadIdx.x == 0) { state[0] = ncls; state[1] = 1; }
+    return;
+  }
+  constexpr int PER = PPH_DICT_HASH / 256;
+  __shared__ int first[257];
+  int mine = 0;
+  for (int k = 0; k < PER; ++k) mine += keys[threadIdx.x * PER + k] != 0ull;
+  first[threadIdx.x + 1] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    first[0] = 0;
+    for (int t = 1; t <= 256; ++t) first[t] += first[t - 1];
+  }
+  __syncthreads();
+  const int total = first[256];
+  if (state[1] < 0 || total > cap) {
+    if (threadIdx.x == 0) { state[0] = total; state[1] = -1; }
+    return;
+  }
+  int id = first[threadIdx.x];
+  for (int k = 0; k < PER; ++k) {
+    const int slot = threadIdx.x * PER + k;
+    if (keys[slot] == 0ull) continue;
+    const int64_t row = rep[slot];
+    map[slot] = (uint16_t)id;
+    rep[PPH_DICT_HASH + id] = row;
+    for (int s = 0; s < S; ++s) tab[id * S + s] = sell_coef(val, ld, sym, S, s, row, sell_off(st, s, px, pxy), n);
+    ++id;
+  }
+  if (threadIdx.x == 0) { state[0] = total; state[1] = 1; }
+}
+
+// pass 3: every row against the table entry of its class, bit for bit (a hash collision, or a row that left its class
+// in a re-assembly, refuses the dictionary: state[1] = -2); map != null: hash slots -> classes on the way
+__global__ __launch_bounds__(256) void k_dict_verify(const double* __restrict__ val, int64_t ld, int sym, Stencil st, int px,
+                                                     int64_t pxy, int64_t n, const uint16_t* __restrict__ map,
+                                                     uint16_t* __restrict__ cls, const double* __restrict__ tab, int* state) {
+  if (state[1] != 1) return;
+  const int S = st.count;
+  bool bad = false;
+  for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < n; row += (int64_t)gridDim.x * blockDim.x) {
+    int c = cls[row];
+    if (map) { c = map[c]; cls[row] = (uint16_t)c; }
+    for (int s = 0; s < S; ++s)
+      bad |= __double_as_longlong(sell_coef(val, ld, sym, S, s, row, sell_off(st, s, px, pxy), n)) != __double_as_longlong(tab[c * S + s]);
+  }
+  if (bad) atomicExch(state + 1, -2);
+}
+
+int sell_dict_update(pph_ctx* ctx, Sell* E, SellDict& D, int64_t n) {
+  E->dict = nullptr;
+  const bool want = ctx->sell_dict && E->val && E->sym && n >= ctx->sell_dict_min_rows && ctx->sell_rpt != 1 &&
+                    (E->kind == PPH_CELL_HEX || E->kind == PPH_CELL_QUAD);
+  if (!want) { D.on = false; return PPH_OK; }
+  const bool same = D.val == E->val && D.n == n && D.px == E->px && D.py == E->py && D.bc_epoch == ctx->bc_epoch &&
+                    D.cap == ctx->sell_dict_cap;
+  if (same && D.tried && !D.on) return PPH_OK;   // refused for this mesh and these Dirichlet sets: not tried again
+  const Stencil st = make_stencil(E->kind);
+  const int64_t pxy = (int64_t)E->px * E->py;
+  const int grid = sell_grid(n);
+  const int cap = ctx->sell_dict_cap < PPH_DICT_CAP ? (ctx->sell_dict_cap < 1 ? 1 : ctx->sell_dict_cap) : PPH_DICT_CAP;
+  if (same && D.on) {
+    // re-assembly: same classes expected - re-read the table from the representatives, check every row
+    hipLaunchKernelGGL(k_dict_table, dim3(1), dim3(256), 0, ctx->stream, E->val, E->ld, E->sym, st, E->px, pxy, n, D.keys.p,
+                       D.rep.p, D.map.p, D.tab.p, D.state.p, cap, 1, D.ncls);
+    hipLaunchKernelGGL(k_dict_verify, dim3(grid), dim3(256), 0, ctx->stream, E->val, E->ld, E->sym, st, E->px, pxy, n,
+                       (const uint16_t*)nullptr, D.cls.p, D.tab.p, D.state.p);
+    PPH_HIP(ctx, hipGetLastError());
+    E->dict = &D;
+    return PPH_OK;
+  }
+  const bool was_on = D.on;
+  const int was_ncls = D.ncls;
+  PPH_TRY(D.cls.alloc(ctx, (size_t)E->ld));
+  PPH_TRY(D.keys.alloc(ctx, (size_t)PPH_DICT_HASH));
+  PPH_TRY(D.rep.alloc(ctx, (size_t)(PPH_DICT_HASH + PPH_DICT_CAP)));
+  PPH_TRY(D.map.alloc(ctx, (size_t)PPH_DICT_HASH));
+  PPH_TRY(D.tab.alloc(ctx, (size_t)PPH_DICT_CAP * 27));
+  PPH_TRY(D.state.alloc(ctx, 4));
+  PPH_HIP(ctx, hipMemsetAsync(D.cls.p, 0, (size_t)E->ld * sizeof(uint16_t), ctx->stream));
+  PPH_HIP(ctx, hipMemsetAsync(D.keys.p, 0, (size_t)PPH_DICT_HASH * sizeof(unsigned long long), ctx->stream));
+  PPH_HIP(ctx, hipMemsetAsync(D.state.p, 0, 4 * sizeof(int), ctx->stream));
+  hipLaunchKernelGGL(k_dict_build, dim3(grid), dim3(256), 0, ctx->stream, E->val, E->ld, E->sym, st, E->px, pxy, n, D.keys.p,
+                     D.rep.p, D.cls.p, D.state.p, cap);
+  hipLaunchKernelGGL(k_dict_table, dim3(1), dim3(256), 0, ctx->stream, E->val, E->ld, E->sym, st, E->px, pxy, n, D.keys.p,
+                     D.rep.p, D.map.p, D.tab.p, D.state.p, cap, 0, 0);
+  hipLaunchKernelGGL(k_dict_verify, dim3(grid), dim3(256), 0, ctx->stream, E->val, E->ld, E->sym, st, E->px, pxy, n,
+                     (const uint16_t*)D.map.p, D.cls.p, D.tab.p, D.state.p);
+  PPH_HIP(ctx, hipGetLastError());
+  int h[2] = {0, 0};
+  PPH_HIP(ctx, hipMemcpyAsync(h, D.state.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  D.ncls = h[0];
+  D.on = h[1] == 1;
+  D.status = h[1];
+  D.tried = true;
+  D.val = E->val; D.n = n; D.px = E->px; D.py = E->py; D.bc_epoch = ctx->bc_epoch; D.cap = ctx->sell_dict_cap;
+  if (D.on != was_on || D.ncls != was_ncls) la_release_graphs(ctx);   // captured launches carry the old class count
+  if (D.on) E->dict = &D;
+  return PPH_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -377,11 +619,6 @@ __global__ __launch_bounds__(256) void k_sell_convert(const int64_t* __restrict_
       o += in ? 1 : 0;
     }
   }
-}
-
-static inline int sell_grid(int64_t n) {
-  int64_t b = ceil_div64(n, 256);
-  return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
 }
 
 // (re)allocates `buf` for a stencil-ELL operator on `mesh` with the padding rows [n, ld) zeroed, returns the view

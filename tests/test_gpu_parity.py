@@ -1459,3 +1459,75 @@ def test_fieldsplit_gmres_ilu_blocks(gpu_ctx_factory, goldens, dim, kind, nx):
     ref = o.gmres(osys.A, osys.rhs, o.fieldsplit_ilu_gmres_apply(osys.A, osys.n, preonly=True))
     assert info.converged and abs(info.iterations - ref.its) <= 1
     assert np.abs(xs - ud).max() <= 1e-6 * np.abs(ud).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nx,ny,nz", [(32, 16, 8), (64, 64, 64), (16, 128, 32), (40, 36, 30), (15, 15, 15)])
+def test_row_dictionary_products_are_bitwise_the_stored_ones(gpu_ctx_factory, nx, ny, nz):
+    """Option sell_dict (pph_internal.h: struct SellDict): the distinct rows of a stencil-ELL block stored once, a 2-byte
+    class per row, the product's coefficients from LDS.  Same x loads, same order of the sums: y = A x BIT-identical to the
+    stored-value kernel for the three blocks, a whole Picard solve (every epilogue mode, the multigrid levels' dictionaries
+    included) with the same sweeps / iterations; with the plain kernel's grid also the same residual history bit for bit.
+    A re-assembly with other coefficients keeps the classes (table re-read, every row checked again); more distinct rows
+    than the cap, or a failed check on the device, leave the stored values in charge - same results again.  Rows repeat
+    bit for bit when the node spacing is exact in binary (cells per direction a power of two: 27 interior / next-to-boundary
+    classes + the Dirichlet row); with 40 x 36 x 30 cells the rounding of i / 40 makes 1 574 distinct rows and the
+    dictionary is refused - the same assertions then hold on the stored values."""
+    exact = all(v & (v - 1) == 0 for v in (nx, ny, nz))
+    f = _ffi()
+    import perphil_amd.fd as fdm
+
+    mesh = fdm.UnitCubeMesh(nx, ny, nz, hexahedral=True)
+    b = mesh.boundary_nodes()
+    g1, g2 = o.exact_pressures(mesh.node_coordinates(b), P)
+    rng = np.random.default_rng(21)
+    cfg = _cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_MG, inner_rtol=1e-10, inner_reduction=1e-1, inner_norm=1,
+               mg_smooth=1, picard_rtol=1e-8)
+    x = None
+    res = {}
+    for name in ("plain", "dict", "dict_plain_grid", "cap", "poisoned"):
+        ctx = gpu_ctx_factory()
+        ctx.set_option("sell_zwalk_min_chunks", 1)
+        if name != "plain":
+            ctx.set_option("sell_dict", 1)
+            ctx.set_option("sell_dict_min_rows", 1)
+        if name == "dict_plain_grid":
+            ctx.set_option("sell_dict_blocks", 0)
+        if name == "cap":
+            ctx.set_option("sell_dict_cap", 4)
+        ctx.mesh_build(3, f.CELL_HEX, nx, ny, nz)
+        ctx.set_dirichlet(0, b, g1)
+        ctx.set_dirichlet(1, b, g2)
+        ctx.assemble(P.k1, 3.0 * P.k2, P.beta, P.mu, monolithic=False)
+        ctx.assemble(P.k1, P.k2, P.beta, P.mu, monolithic=False)      # the re-assembly path: classes kept, table re-read
+        t = ctx.timers()
+        if name in ("dict", "dict_plain_grid", "poisoned") and exact:
+            assert t["dict_operators"] >= 3 and t["dict_status"] == 1 and 8 <= t["dict_classes"] <= 64, t
+        elif name in ("dict", "dict_plain_grid", "poisoned"):
+            assert (t["dict_operators"] == 0 and t["dict_status"] == -1) or t["dict_classes"] <= 256, t
+        elif name == "cap":
+            assert t["dict_operators"] == 0 and t["dict_status"] == -1, t
+        else:
+            assert t["dict_operators"] == 0 and t["dict_classes"] == 0
+        if name == "poisoned":
+            ctx.set_option("sell_dict_poison", 1)
+        if x is None:
+            x = rng.uniform(-1, 1, ctx.n)
+        ys = [ctx.spmv(w, x) for w in (f.MAT_A11, f.MAT_A22, f.MAT_A12)]
+        xs, info, hist = ctx.solve(cfg, hist_cap=64)
+        assert info.converged
+        if name == "dict" and exact:
+            assert ctx.timers()["dict_operators"] >= 3
+        res[name] = (ys, xs, (info.iterations, info.inner_iterations), hist)
+        ctx.close()
+    ys0, xs0, its0, hist0 = res["plain"]
+    for name in ("dict", "dict_plain_grid", "cap", "poisoned"):
+        ys, xs, its, hist = res[name]
+        for ya, yb in zip(ys0, ys):
+            np.testing.assert_array_equal(ya, yb)
+        assert its == its0, name
+        np.testing.assert_allclose(xs, xs0, rtol=0, atol=1e-12 * np.abs(xs0).max())
+        np.testing.assert_allclose(hist, hist0, rtol=1e-6)
+    for name in ("dict_plain_grid", "cap"):
+        np.testing.assert_array_equal(res[name][1], xs0)
+        np.testing.assert_array_equal(res[name][3], hist0)
