@@ -401,7 +401,7 @@ struct pph_ctx {
   int sell_patch = 0, sell_patch_z = 16; // (EXPERIMENTS build) a wave climbs a 16 x 8 patch, mirrors of its own rows from wave-private LDS; planes per climb
   int sell_lds = 0;                     // (EXPERIMENTS build) symmetric 27-point operators on z-walk levels: mirrored values handed over through LDS
   int sell_flags = 0;                   // experiments: 1 non-temporal y stores (mode 0), 2 non-temporal loads of the diagonal slot
-  int sell_dict = 0;                    // row dictionaries for the stencil-ELL blocks (struct SellDict)
+  int sell_dict = 1;                    // row dictionaries for the stencil-ELL blocks (struct SellDict)
   int64_t sell_dict_min_rows = 1000000; // ... of operators with at least this many rows
   int sell_dict_blocks = 2048, sell_dict_zwalk = -1;   // grid cap of a dictionary product; z-walk (-1: as sell_zwalk)
   int sell_dict_cap = PPH_DICT_CAP;     // classes accepted (tests lower it to force the plain path)

@@ -246,7 +246,7 @@ static int sell_product(pph_ctx* ctx, const Csr& A, int mode, const double* x, c
         ctx->comm_status = PPH_ERR_INVALID;
         ctx->comm_error = "split product wrote more partial sums than one reduction slot holds";
       }
-      ctx->max_split_partials = total > ctx->max_split_partials ? total : ctx->max_split_partials;
+      if ((mode == 2 || mode >= 4) && total > ctx->max_split_partials) ctx->max_split_partials = total;   // (the other modes write no partial sums)
       return total;
     }
   }

@@ -515,20 +515,58 @@ __global__ __launch_bounds__(256) void k_dict_table(const double* __restrict__ v
 }
 
 // pass 3: every row against the table entry of its class, bit for bit (a hash collision, or a row that left its class
-// in a re-assembly, refuses the dictionary: state[1] = -2); map != null: hash slots -> classes on the way
-__global__ __launch_bounds__(256) void k_dict_verify(const double* __restrict__ val, int64_t ld, int sym, Stencil st, int px,
-                                                     int64_t pxy, int64_t n, const uint16_t* __restrict__ map,
-                                                     uint16_t* __restrict__ cls, const double* __restrict__ tab, int* state) {
+// in a re-assembly, refuses the dictionary: state[1] = -2); map != null: hash slots -> classes on the way.  Symmetric
+// storage, stencil unrolled, table in LDS: this runs after every assembly.
+template <int KIND>
+__global__ __launch_bounds__(256) void k_dict_verify_sym(const double* __restrict__ val, int64_t ld, int px, int64_t pxy,
+                                                         int64_t n, const uint16_t* __restrict__ map,
+                                                         uint16_t* __restrict__ cls, const double* __restrict__ tab,
+                                                         int* state, int lds_classes) {
+  using ST = SellSt<KIND>;
+  constexpr int S = ST::S, C0 = S / 2;
+  extern __shared__ double vtab[];
   if (state[1] != 1) return;
-  const int S = st.count;
+  const int ncls = state[0] < lds_classes ? state[0] : lds_classes;
+  for (int i = threadIdx.x; i < ncls * S; i += 256) vtab[i] = tab[i];
+  __syncthreads();
   bool bad = false;
   for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < n; row += (int64_t)gridDim.x * blockDim.x) {
     int c = cls[row];
     if (map) { c = map[c]; cls[row] = (uint16_t)c; }
-    for (int s = 0; s < S; ++s)
-      bad |= __double_as_longlong(sell_coef(val, ld, sym, S, s, row, sell_off(st, s, px, pxy), n)) != __double_as_longlong(tab[c * S + s]);
+    if (c >= ncls) { bad = true; continue; }
+    const double* t = vtab + c * S;
+    int slot = 0;
+#pragma unroll
+    for (int l = 0; l < ST::NL; ++l) {
+      const int mask = ST::mask(l);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        if (!((mask >> d) & 1)) continue;
+        double v;
+        if (slot >= C0) {
+          v = val[(int64_t)(slot - C0) * ld + row];
+        } else {
+          const int64_t rr = row + (int64_t)(d - 1) + (int64_t)ST::dy(l) * px + (int64_t)ST::dz(l) * pxy;
+          v = (rr >= 0 && rr < n) ? val[(int64_t)(S - 1 - slot - C0) * ld + rr] : 0.0;
+        }
+        bad |= __double_as_longlong(v) != __double_as_longlong(t[slot]);
+        ++slot;
+      }
+    }
   }
   if (bad) atomicExch(state + 1, -2);
+}
+
+static void dict_launch_verify(pph_ctx* ctx, const Sell& E, SellDict& D, int64_t n, const uint16_t* map, int lds_classes) {
+  const int64_t pxy = (int64_t)E.px * E.py;
+  const int grid = sell_grid(n);
+  const size_t lds = (size_t)lds_classes * sell_slots(E.kind) * sizeof(double);
+  if (E.kind == PPH_CELL_HEX)
+    hipLaunchKernelGGL(k_dict_verify_sym<PPH_CELL_HEX>, dim3(grid), dim3(256), lds, ctx->stream, E.val, E.ld, E.px, pxy, n, map,
+                       D.cls.p, D.tab.p, D.state.p, lds_classes);
+  else
+    hipLaunchKernelGGL(k_dict_verify_sym<PPH_CELL_QUAD>, dim3(grid), dim3(256), lds, ctx->stream, E.val, E.ld, E.px, pxy, n, map,
+                       D.cls.p, D.tab.p, D.state.p, lds_classes);
 }
 
 int sell_dict_update(pph_ctx* ctx, Sell* E, SellDict& D, int64_t n) {
@@ -547,8 +585,7 @@ int sell_dict_update(pph_ctx* ctx, Sell* E, SellDict& D, int64_t n) {
     // re-assembly: same classes expected - re-read the table from the representatives, check every row
     hipLaunchKernelGGL(k_dict_table, dim3(1), dim3(256), 0, ctx->stream, E->val, E->ld, E->sym, st, E->px, pxy, n, D.keys.p,
                        D.rep.p, D.map.p, D.tab.p, D.state.p, cap, 1, D.ncls);
-    hipLaunchKernelGGL(k_dict_verify, dim3(grid), dim3(256), 0, ctx->stream, E->val, E->ld, E->sym, st, E->px, pxy, n,
-                       (const uint16_t*)nullptr, D.cls.p, D.tab.p, D.state.p);
+    dict_launch_verify(ctx, *E, D, n, nullptr, D.ncls);
     PPH_HIP(ctx, hipGetLastError());
     E->dict = &D;
     return PPH_OK;
@@ -568,8 +605,7 @@ int sell_dict_update(pph_ctx* ctx, Sell* E, SellDict& D, int64_t n) {
                      D.rep.p, D.cls.p, D.state.p, cap);
   hipLaunchKernelGGL(k_dict_table, dim3(1), dim3(256), 0, ctx->stream, E->val, E->ld, E->sym, st, E->px, pxy, n, D.keys.p,
                      D.rep.p, D.map.p, D.tab.p, D.state.p, cap, 0, 0);
-  hipLaunchKernelGGL(k_dict_verify, dim3(grid), dim3(256), 0, ctx->stream, E->val, E->ld, E->sym, st, E->px, pxy, n,
-                     (const uint16_t*)D.map.p, D.cls.p, D.tab.p, D.state.p);
+  dict_launch_verify(ctx, *E, D, n, D.map.p, cap);
   PPH_HIP(ctx, hipGetLastError());
   int h[2] = {0, 0};
   PPH_HIP(ctx, hipMemcpyAsync(h, D.state.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
