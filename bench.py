@@ -407,35 +407,62 @@ def main():
     achieved = (byts / 1e9) / (ms / 1e3) if ms > 0 else 0.0
     sym = bool(ctx.timers().get("symmetric_storage", False))   # what the last assembly actually stored
     S = 14 if sym else 27        # stored slots per row: diagonal + upper half of the 27-point stencil, or all of it
-    sell_bytes = 8.0 * S * ctx.n + 16.0 * ctx.n
+    # row dictionaries (option sell_dict, default): the products of the fine blocks stream a 2-byte class per row
+    # instead of the S stored values (pph_get_timers: operators on a dictionary, distinct rows of A11)
+    dict_ops, dict_classes = int(tr.get("dict_operators", 0)), int(tr.get("dict_classes", 0))
+    dicton = sell and dict_ops >= 3
+    sell_bytes = (2.0 if dicton else 8.0 * S) * ctx.n + 16.0 * ctx.n
     csr_bytes = 12.0 * ctx.nnzb + 20.0 * ctx.n
     # HBM traffic of the same kernel mix from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB), taken
     # offline with tools/pmc_summarize.py and committed under profiles/ (PMC cannot be sampled in-process).  The
     # file is stamped with the kernel and the launch count it was taken on: anything else reports null.
     traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "r03_pmc_spmv_bench256.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r03_pmc_spmv_dict_bench256.json" if dicton else "r03_pmc_spmv_bench256.json")
     if os.path.exists(pmc_file) and N == 256 and world == 1 and sell:
         try:
             with open(pmc_file) as f:
                 pmc = json.load(f)
             if (int(pmc.get("launches_per_step", -1)) == int(launches) and pmc.get("kernel") == "k_spmv_sell"
-                    and bool(pmc.get("symmetric", False)) == bool(sym)):
+                    and bool(pmc.get("symmetric", False)) == bool(sym) and bool(pmc.get("dictionary", False)) == dicton):
                 traffic = pmc.get("traffic_bytes_per_launch")
         except (OSError, ValueError):
             traffic = None
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-        "kernel": ((f"k_spmv_sell<kind,mode,2,{'sym' if sym else 'full'}> (stencil-ELL SpMV, "
+        "kernel": ((f"k_spmv_sell<kind,mode,2,sym,dict> (stencil-ELL SpMV on row dictionaries: {dict_classes} distinct rows of A11 "
+                    "in LDS, a 2-byte class per row instead of the 14 stored values; operators below 1 M rows - the coarse "
+                    "multigrid levels - on their stored values; all multigrid levels of one step)")
+                   if dicton else
+                   (f"k_spmv_sell<kind,mode,2,{'sym' if sym else 'full'}> (stencil-ELL SpMV, "
                     + ("symmetric storage: 14 of 27 slot arrays, every value serves two rows, " if sym else "")
                     + "8 B per stored entry, all multigrid levels of one step)")
                    if sell else "k_spmv_wide<8,*,2> (aligned-wide CSR-vector SpMV, all multigrid levels of one step)"),
-        "format": ("stencil-ELL (symmetric)" if sym else "stencil-ELL") if sell else "CSR",
+        "format": (("row dictionary over " if dicton else "") + ("stencil-ELL (symmetric)" if sym else "stencil-ELL")) if sell else "CSR",
+        "dictionary": {"operators": dict_ops, "classes_A11": dict_classes} if sell else None,
         "launches_per_step": int(launches), "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
         "algorithmic_bytes_per_launch": round(byts / max(launches, 1), 0),
         "fine_level": fine_block(sell_bytes if sell else csr_bytes),
         "fine_level_in_solver": in_solver(tr),
     }
+    if dicton and not args.skip_csr:
+        # the same step with the products on the STORED values (symmetric stencil-ELL, the dominant kernel of rounds 2-3
+        # and the path of every mesh whose rows do not repeat): untimed, for the record
+        ctx.set_option("sell_dict", 0)
+        step()
+        tv, lv, msv, bv = instrumented_step()
+        t0v = time.perf_counter()
+        step()
+        ctx.synchronize()
+        stored_ms = 1e3 * (time.perf_counter() - t0v)
+        av = (bv / 1e9) / (msv / 1e3) if msv > 0 else 0.0
+        stored_bytes = 8.0 * S * ctx.n + 16.0 * ctx.n
+        roofline["stored_values"] = {"kernel": "k_spmv_sell<kind,mode,2,sym> (14 stored slot arrays, every value serves two rows)",
+                                     "achieved": round(av, 1), "frac": round(av / HBM_PEAK_GBS, 4), "launches_per_step": int(lv),
+                                     "algorithmic_bytes_per_launch": round(bv / max(lv, 1), 0), "ms_per_step": round(stored_ms, 3),
+                                     "fine_level": fine_block(stored_bytes), "fine_level_in_solver": in_solver(tv)}
+        ctx.set_option("sell_dict", 1)
+        step()                                   # (the dictionaries are rebuilt by the next assembly)
     if sell and sym and not args.skip_csr:
         # the same step on full (27-slot) stencil-ELL storage: untimed, for the record
         ctx.set_option("sell_sym", 0)
@@ -496,7 +523,8 @@ def main():
                              "the first step's buffer / multigrid-hierarchy allocation (cold_step_ms = that first step)",
             "setup_ms": round(setup_ms, 2), "cold_step_ms": None if cold_ms is None else round(cold_ms, 2),
             "context_ms": round(context_ms, 2),
-            "operator_format": ("stencil-ELL, symmetric storage" if sym else "stencil-ELL") if sell else "CSR",
+            "operator_format": ((("row dictionary (%d distinct rows) over " % dict_classes) if dicton else "")
+                                + ("stencil-ELL, symmetric storage" if sym else "stencil-ELL")) if sell else "CSR",
             "transport": transport, "ranks_seen": int(ranks_seen),
             "allreduces_per_step": int(cs["allreduces"]),
             "halo_overlap": int(args.halo_overlap), "split_products_per_step": int(tm.get("split_products", 0)),

@@ -636,6 +636,7 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
   if (!strcmp(name, "sell_dict_blocks")) { ctx->sell_dict_blocks = (int)value; la_release_graphs(ctx); return PPH_OK; }
   if (!strcmp(name, "sell_dict_zwalk")) { ctx->sell_dict_zwalk = (int)value; la_release_graphs(ctx); return PPH_OK; }
   if (!strcmp(name, "sell_dict_cap")) { ctx->sell_dict_cap = (int)value; return PPH_OK; }
+  if (!strcmp(name, "sell_dict_walk")) { ctx->sell_dict_walk = value != 0; la_release_graphs(ctx); return PPH_OK; }
   if (!strcmp(name, "sell_dict_poison")) {
     // tests: mark the dictionaries of the fine blocks as failed ON THE DEVICE only, as a failed re-assembly check would -
     // the products launched for them must then take the stored values (the plain path inside the dictionary kernel)

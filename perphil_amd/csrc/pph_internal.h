@@ -403,7 +403,8 @@ struct pph_ctx {
   int sell_flags = 0;                   // experiments: 1 non-temporal y stores (mode 0), 2 non-temporal loads of the diagonal slot
   int sell_dict = 1;                    // row dictionaries for the stencil-ELL blocks (struct SellDict)
   int64_t sell_dict_min_rows = 1000000; // ... of operators with at least this many rows
-  int sell_dict_blocks = 2048, sell_dict_zwalk = -1;   // grid cap of a dictionary product; z-walk (-1: as sell_zwalk)
+  int sell_dict_blocks = 1024, sell_dict_zwalk = -1;   // grid (cap) of a dictionary product; chunk z-walk of k_spmv_sell<DICT> (-1: as sell_zwalk)
+  int sell_dict_walk = 1;               // whole-operator dictionary products of hexahedral blocks: x window in registers (k_spmv_dict_walk)
   int sell_dict_cap = PPH_DICT_CAP;     // classes accepted (tests lower it to force the plain path)
   int sell_rpt = 2, sell_blocks = 0, sell_group = 0;   // SELL SpMV tuning: rows per thread, grid cap, XCD chunk group
   DevBuf<double> sell_tmp;              // SELL copy of the matrix last selected by pph_spmv / pph_spmv_bench

@@ -18,6 +18,20 @@ __device__ inline double sell_wave_sum(double v) {
   return v;
 }
 
+// two consecutive rows' entries of a vector as ONE 16-byte access per lane (8-byte alignment is enough for the hardware):
+// a wave then touches 1 KB of consecutive bytes per instruction - with one 8-byte store per row, each of the two store
+// instructions of a row pair writes every other 8 bytes of the lines it touches (byte-masked partial writes)
+typedef double pph_d2 __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ void sell_st2(double* p, double a, double b) {
+  pph_d2 v;
+  v.x = a; v.y = b;
+  *reinterpret_cast<pph_d2*>(p) = v;
+}
+__device__ __forceinline__ void sell_ld2(const double* p, double& a, double& b) {
+  const pph_d2 v = *reinterpret_cast<const pph_d2*>(p);
+  a = v.x; b = v.y;
+}
+
 // operands of the epilogue of a row block: requested before the matrix stream, not after the sums
 template <int MODE, int RPT, bool CLAMP>
 __device__ __forceinline__ void sell_prologue(const double* __restrict__ x, const double* __restrict__ b,
@@ -25,6 +39,15 @@ __device__ __forceinline__ void sell_prologue(const double* __restrict__ x, cons
                                               const double* __restrict__ aux, const double* __restrict__ z0, int64_t n,
                                               int64_t r0, double (&acc)[RPT], double (&bv)[RPT], double (&xr)[RPT],
                                               double (&dv)[RPT], double (&tv)[RPT], double (&av)[RPT], bool (&act)[RPT]) {
+  if constexpr (RPT == 2 && !CLAMP) {   // both rows inside: 16-byte loads (sell_ld2)
+    acc[0] = acc[1] = 0.0; bv[0] = bv[1] = 0.0; xr[0] = xr[1] = 0.0; dv[0] = dv[1] = 0.0; tv[0] = tv[1] = 0.0; av[0] = av[1] = 0.0;
+    act[0] = act[1] = true;
+    if (MODE == 1 || (MODE >= 3 && MODE <= 5) || MODE == 7) sell_ld2(b + r0, bv[0], bv[1]);
+    if ((MODE >= 2 && MODE <= 4) || MODE == 7) sell_ld2(x + r0, xr[0], xr[1]);
+    if (MODE == 3 || MODE == 4) sell_ld2(dinv + r0, dv[0], dv[1]);
+    if (MODE == 5 || MODE == 6) { sell_ld2(y + r0, tv[0], tv[1]); sell_ld2(aux + r0, av[0], av[1]); if (z0) sell_ld2(dinv + r0, dv[0], dv[1]); }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
     acc[i] = 0.0; bv[i] = 0.0; xr[i] = 0.0; dv[i] = 0.0; tv[i] = 0.0; av[i] = 0.0;
@@ -45,27 +68,49 @@ __device__ __forceinline__ void sell_epilogue(const double (&acc)[RPT], const do
                                               const bool (&act)[RPT], double w, double* __restrict__ y,
                                               double* __restrict__ aux, double* __restrict__ z0, int64_t r0,
                                               double& dotacc, int64_t dlo, int64_t dhi, double* dotx, int flags) {
+  double yo[RPT], ao[RPT], zo[RPT];   // what goes to y, aux, z0
 #pragma unroll
   for (int i = 0; i < RPT; ++i) {
+    yo[i] = 0.0; ao[i] = 0.0; zo[i] = 0.0;
     if (!act[i]) continue;
     const int64_t r = r0 + i;
-    if (MODE == 0) { if (flags & 1) __builtin_nontemporal_store(acc[i], y + r); else y[r] = acc[i]; }
-    else if (MODE == 1) y[r] = bv[i] - acc[i];
-    else if (MODE == 2) { y[r] = acc[i]; if (r >= dlo && r < dhi) dotacc += acc[i] * xr[i]; }   // (owned rows: ghost rows of a symmetric slab operator hold no row of this rank)
+    if (MODE == 0) yo[i] = acc[i];
+    else if (MODE == 1) yo[i] = bv[i] - acc[i];
+    else if (MODE == 2) { yo[i] = acc[i]; if (r >= dlo && r < dhi) dotacc += acc[i] * xr[i]; }   // (owned rows: ghost rows of a symmetric slab operator hold no row of this rank)
     else if (MODE == 7) {
-      y[r] = acc[i];
+      yo[i] = acc[i];
       if (r >= dlo && r < dhi) { dotacc += acc[i] * xr[i]; dotx[0] += acc[i] * bv[i]; dotx[1] += acc[i] * acc[i]; }
     } else if (MODE >= 5) {
       const double tn = (MODE == 5) ? bv[i] - acc[i] : acc[i];
       const double rn = av[i] + ((MODE == 5) ? 1.0 : -1.0) * (tn - tv[i]);   // k_shift
-      aux[r] = rn;
-      y[r] = tn;
-      if (z0) z0[r] = dv[i] * rn * w;   // the next block solve's first pre-smoothing (k_cg_update_dev's order)
+      ao[i] = rn;
+      yo[i] = tn;
+      zo[i] = dv[i] * rn * w;   // the next block solve's first pre-smoothing (k_cg_update_dev's order)
       if (r >= dlo && r < dhi) dotacc += rn * rn;
     } else {
       const double yn = xr[i] + dv[i] * (bv[i] - acc[i]) * w;   // the order of k_cheb_init: dinv * r / theta
-      y[r] = yn;
+      yo[i] = yn;
       if (MODE == 4 && r >= dlo && r < dhi) dotacc += bv[i] * yn;
+    }
+  }
+  if constexpr (RPT == 2) {
+    if (act[0] && act[1] && !(MODE == 0 && (flags & 1))) {
+      sell_st2(y + r0, yo[0], yo[1]);
+      if (MODE == 5 || MODE == 6) {
+        sell_st2(aux + r0, ao[0], ao[1]);
+        if (z0) sell_st2(z0 + r0, zo[0], zo[1]);
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RPT; ++i) {
+    if (!act[i]) continue;
+    const int64_t r = r0 + i;
+    if (MODE == 0 && (flags & 1)) __builtin_nontemporal_store(yo[i], y + r); else y[r] = yo[i];
+    if (MODE == 5 || MODE == 6) {
+      aux[r] = ao[i];
+      if (z0) z0[r] = zo[i];
     }
   }
 }
@@ -127,6 +172,9 @@ __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_
         for (int d = 0; d < 3; ++d)
           if (((mask >> d) & 1) && i + d == e) need = true;
       xs[e] = 0.0;
+#ifdef PPH_DICT_PROBE
+      if (DICT && (flags & 16)) { if (need) xs[e] = 1.0 + e + l + (double)threadIdx.x; } else   // timing probe: no x loads
+#endif
       if (need) {
         int64_t idx = L + e - 1;
         if (CLAMP) idx = idx < 0 ? 0 : (idx > n - 1 ? n - 1 : idx);
@@ -142,6 +190,12 @@ __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_
       const double* vp = val + (int64_t)(SYM ? (slot >= C0 ? slot - C0 : 0) : slot) * ld + r0;
       double v[RPT];
       if constexpr (DICT) {
+#ifdef PPH_DICT_PROBE
+        if (flags & 8) {   // timing probe (wrong results): no LDS reads
+#pragma unroll
+          for (int i = 0; i < RPT; ++i) v[i] = 1.0 + slot;
+        } else
+#endif
 #pragma unroll
         for (int i = 0; i < RPT; ++i) v[i] = act[i] ? dtab[cb[i] + slot] : 0.0;
       } else if (SYM && slot < C0) {
@@ -288,6 +342,259 @@ __global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ va
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Dictionary product, z-walk with the x window in registers (hexahedra, whole-operator launches)
+// ------------------------------------------------------------------------------------------------
+// With the coefficients in LDS the product of k_spmv_sell<.., DICT> is bound by its 36 x loads per row pair (L1), of which
+// 24 repeat what the pair one plane below loaded.  Here a thread keeps the in-plane position of its two rows and climbs
+// the planes: the x lines of planes z - 1, z, z + 1 sit in three register sets that rotate, 12 loads per step.  The work
+// (in-plane chunks of 512 positions x planes, column-major) is cut into gridDim.x equal contiguous ranges.  Sums, their
+// order and the epilogue are k_spmv_sell's: products stay bit-identical (the per-workgroup partial sums of the dot
+// modes group other rows, as with any other grid).
+template <bool CLAMP>
+__device__ __forceinline__ void dictw_load_plane(const double* __restrict__ x, int64_t base, int px, int64_t n, double (&win)[3][4]) {
+  // base = first row of the pair in the plane to load; lines dy = -1, 0, +1, entries base + dy px - 1 .. + 2
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int64_t idx = base + (int64_t)(j - 1) * px + e - 1;
+      if (CLAMP) idx = idx < 0 ? 0 : (idx > n - 1 ? n - 1 : idx);   // (k_spmv_sell's clamp: the coefficient there is 0)
+      win[j][e] = x[idx];
+    }
+}
+
+// operands of one step besides the x window: classes and the epilogue's vectors, requested one step ahead
+struct DwOps { double bv[2], dv[2], tv[2], av[2]; uint32_t cls2; };   // cls2: the two classes as loaded (low / high half)
+
+// ALL: both rows of every lane are inside the plane (all position chunks but the last of a plane) - no lane masks, no
+// branches: the 4-step loop must stay straight-line code, or the compiler's wait-count pass drains every outstanding
+// request at each join and the requests of the next step are never in flight while this one computes
+template <int MODE, bool ALL>
+__device__ __forceinline__ void dictw_fetch(DwOps& o, const uint16_t* __restrict__ cls, const double* __restrict__ b,
+                                            const double* __restrict__ dinv, const double* __restrict__ y,
+                                            const double* __restrict__ aux, const double* __restrict__ z0, int64_t r0, bool a0,
+                                            bool a1) {
+  const bool act[2] = {a0, a1};
+  if (ALL || (a0 && a1)) {
+    o.bv[0] = o.bv[1] = 0.0; o.dv[0] = o.dv[1] = 0.0; o.tv[0] = o.tv[1] = 0.0; o.av[0] = o.av[1] = 0.0;
+    if (ALL) {
+      typedef uint32_t u32a2 __attribute__((aligned(2)));
+      o.cls2 = *reinterpret_cast<const u32a2*>(cls + r0);   // (kept as loaded: decoding it here would make this step wait for it)
+    } else {
+      o.cls2 = (uint32_t)cls[r0] | ((uint32_t)cls[r0 + 1] << 16);
+    }
+    if (MODE == 1 || (MODE >= 3 && MODE <= 5) || MODE == 7) sell_ld2(b + r0, o.bv[0], o.bv[1]);
+    if (MODE == 3 || MODE == 4) sell_ld2(dinv + r0, o.dv[0], o.dv[1]);
+    if (MODE == 5 || MODE == 6) { sell_ld2(y + r0, o.tv[0], o.tv[1]); sell_ld2(aux + r0, o.av[0], o.av[1]); if (z0) sell_ld2(dinv + r0, o.dv[0], o.dv[1]); }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    if (i == 0) o.cls2 = 0;
+    o.bv[i] = 0.0; o.dv[i] = 0.0; o.tv[i] = 0.0; o.av[i] = 0.0;
+    if (act[i]) {
+      o.cls2 |= (uint32_t)cls[r0 + i] << (16 * i);
+      if (MODE == 1 || (MODE >= 3 && MODE <= 5) || MODE == 7) o.bv[i] = b[r0 + i];
+      if (MODE == 3 || MODE == 4) o.dv[i] = dinv[r0 + i];
+      if (MODE == 5 || MODE == 6) { o.tv[i] = y[r0 + i]; o.av[i] = aux[r0 + i]; if (z0) o.dv[i] = dinv[r0 + i]; }
+    }
+  }
+}
+
+template <int MODE, bool ALL>
+__device__ __forceinline__ void dictw_step(const double (&lo)[3][4], const double (&mid)[3][4], const double (&hi)[3][4],
+                                           const DwOps& o, const double* dtab, const double (&cm)[27], uint32_t main2,
+                                           double w, double* __restrict__ y, double* __restrict__ aux,
+                                           double* __restrict__ z0, int64_t r0, bool a0, bool a1, double& dotacc, int64_t dlo,
+                                           int64_t dhi, double* dotx, int flags) {
+  double acc[2] = {0.0, 0.0}, xr[2] = {0.0, 0.0};
+  const bool act[2] = {ALL || a0, ALL || a1};
+  if ((MODE >= 2 && MODE <= 4) || MODE == 7) {   // x[r0 + i]
+    xr[0] = act[0] ? mid[1][1] : 0.0;
+    xr[1] = act[1] ? mid[1][2] : 0.0;
+  }
+  // every row of the wave in the block's main class (the interior rows: about half of the wave steps of a 256^3 block):
+  // its 27 coefficients are wave-uniform values read once per kernel - no LDS reads, whose latency two waves per SIMD
+  // do not hide
+  if (ALL && __all(o.cls2 == main2)) {
+    int slot = 0;
+#pragma unroll
+    for (int l = 0; l < 9; ++l) {
+      const double (&win)[3][4] = (l < 3) ? lo : (l < 6 ? mid : hi);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i] += cm[slot] * win[l % 3][i + d];
+        ++slot;
+      }
+    }
+  } else {
+    const int cb[2] = {(int)(o.cls2 & 0xffffu) * 27, (int)(o.cls2 >> 16) * 27};
+    int slot = 0;
+#pragma unroll
+    for (int l = 0; l < 9; ++l) {
+      const double (&win)[3][4] = (l < 3) ? lo : (l < 6 ? mid : hi);
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        double v[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) v[i] = dtab[cb[i] + slot];   // (a row that is not active reads class 0 and is not stored)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[i] += v[i] * win[l % 3][i + d];
+        ++slot;
+      }
+    }
+  }
+  sell_epilogue<MODE, 2>(acc, o.bv, xr, o.dv, o.tv, o.av, act, w, y, aux, z0, r0, dotacc, dlo, dhi, dotx, 0);   // (no store-hint experiments here: a branch around the stores costs the pipelining)
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_spmv_dict_walk(const double* __restrict__ val, int64_t ld,
+                                                        const double* __restrict__ x, const double* __restrict__ b,
+                                                        const double* __restrict__ dinv, const double* __restrict__ wp,
+                                                        double* __restrict__ y, double* __restrict__ aux,
+                                                        double* __restrict__ z0, int64_t n, int px, int64_t pxy, int planes,
+                                                        double* __restrict__ part, int64_t dlo, int64_t dhi, int flags,
+                                                        SellDictArgs da) {
+  extern __shared__ double dtab[];
+  const bool dok = da.state[0] == da.ncls && da.state[1] == 1;
+  if (dok) {
+    for (int i = threadIdx.x; i < da.ncls * 27; i += 256) dtab[i] = da.tab[i];
+    __syncthreads();
+  }
+  const double w = (MODE == 3 || MODE == 4 || ((MODE == 5 || MODE == 6) && z0)) ? *wp : 0.0;
+  double dotacc = 0.0;
+  double dotx[2] = {0.0, 0.0};
+  // main class = the class of the row in the middle of the box
+  const uint32_t cmain = dok ? da.cls[(int64_t)(planes / 2) * pxy + (int64_t)(pxy / px / 2) * px + px / 2] : 0u;
+  const uint32_t main2 = (flags & 4) ? 0xffffffffu : (cmain | (cmain << 16));
+  double cm[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) cm[k] = dok ? da.tab[cmain * 27 + k] : 0.0;
+  const int64_t P = (pxy + 511) / 512;
+  const int64_t total = P * planes;
+  int64_t q = total * (int64_t)blockIdx.x / gridDim.x;
+  const int64_t q1 = total * ((int64_t)blockIdx.x + 1) / gridDim.x;
+  while (q < q1) {
+    const int64_t pos = q / planes;
+    int z = (int)(q - pos * planes);
+    const int zend = (int)((q1 - q) < (int64_t)(planes - z) ? z + (q1 - q) : planes);   // this range's steps in the column
+    q += zend - z;
+    const int64_t p = pos * 512 + (int64_t)threadIdx.x * 2;
+    const bool a0 = p < pxy, a1 = p + 1 < pxy;
+    if (!dok) {
+      // this assembly's dictionary was refused on the device: the stored values, one row at a time
+      for (; z < zend; ++z)
+        for (int i = 0; i < 2; ++i)
+          if (p + i < pxy)
+            sell_rows<PPH_CELL_HEX, MODE, 1, true, true>(val, ld, x, b, dinv, w, y, aux, z0, n, px, pxy, (int64_t)z * pxy + p + i,
+                                                         dotacc, dlo, dhi, dotx, flags);
+      continue;
+    }
+    // Register sets A, B, C = x lines of planes z - 1, z, z + 1; D = the plane two steps ahead, O0 / O1 = this step's and
+    // the next step's other operands: everything a step needs was requested one step earlier, so that a wave always has a
+    // step's worth of loads in flight behind the one it computes on (the memory counter retires in order: all requests of
+    // step z + 1 are issued before step z waits for its own).  Planes 0, planes - 1 and beyond reach outside [0, n):
+    // clamped loads, kept out of the 4-step loop.
+    double A[3][4], B[3][4], C[3][4], D[3][4];
+    DwOps O0, O1;
+#define PPH_DW_LOADC(W, ZZ)                                                                                     \
+    do {                                                                                                          \
+      const int zz_ = (ZZ);                                                                                       \
+      if (zz_ >= 1 && zz_ <= planes - 2) dictw_load_plane<false>(x, (int64_t)zz_ * pxy + p, px, n, W);            \
+      else dictw_load_plane<true>(x, (int64_t)zz_ * pxy + p, px, n, W);                                           \
+    } while (0)
+#define PPH_DW_LOAD(W, ZZ) dictw_load_plane<false>(x, (int64_t)(ZZ) * pxy + p, px, n, W)
+#define PPH_DW_FETCH(O, ZZ) dictw_fetch<MODE, false>(O, da.cls, b, dinv, y, aux, z0, (int64_t)(ZZ) * pxy + p, a0, a1)
+#define PPH_DW_STEP(LO, MID, HI, O, ZZ)                                                                         \
+    dictw_step<MODE, false>(LO, MID, HI, O, dtab, cm, main2, w, y, aux, z0, (int64_t)(ZZ) * pxy + p, a0, a1, dotacc, dlo, dhi, dotx, flags)
+#define PPH_DW_FETCHA(O, ZZ) dictw_fetch<MODE, true>(O, da.cls, b, dinv, y, aux, z0, (int64_t)(ZZ) * pxy + p, true, true)
+#define PPH_DW_STEPA(LO, MID, HI, O, ZZ)                                                                        \
+    dictw_step<MODE, true>(LO, MID, HI, O, dtab, cm, main2, w, y, aux, z0, (int64_t)(ZZ) * pxy + p, true, true, dotacc, dlo, dhi, dotx, flags)
+    PPH_DW_LOADC(A, z - 1);
+    PPH_DW_LOADC(B, z);
+    PPH_DW_LOADC(C, z + 1);
+    PPH_DW_FETCH(O0, z);
+#define PPH_DW_SINGLE()                                                                                         \
+    do {                                                                                                          \
+      PPH_DW_LOADC(D, z + 2);                                                                                     \
+      if (z + 1 < zend) PPH_DW_FETCH(O1, z + 1);                                                                  \
+      PPH_DW_STEP(A, B, C, O0, z);                                                                                \
+      _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                               \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) { A[j][e] = B[j][e]; B[j][e] = C[j][e]; C[j][e] = D[j][e]; } \
+      O0 = O1;                                                                                                    \
+      ++z;                                                                                                        \
+    } while (0)
+    if (z == 0 && z < zend) PPH_DW_SINGLE();   // (plane 0 needs the clamped loads: one step outside the 4-step loop)
+    if (pos * 512 + 512 <= pxy) {   // every lane has both rows in the plane
+      while (z + 4 <= zend && z + 5 <= planes - 2 && z >= 1) {
+        PPH_DW_LOAD(D, z + 2); PPH_DW_FETCHA(O1, z + 1); PPH_DW_STEPA(A, B, C, O0, z);
+        PPH_DW_LOAD(A, z + 3); PPH_DW_FETCHA(O0, z + 2); PPH_DW_STEPA(B, C, D, O1, z + 1);
+        PPH_DW_LOAD(B, z + 4); PPH_DW_FETCHA(O1, z + 3); PPH_DW_STEPA(C, D, A, O0, z + 2);
+        PPH_DW_LOAD(C, z + 5); PPH_DW_FETCHA(O0, z + 4); PPH_DW_STEPA(D, A, B, O1, z + 3);
+        z += 4;
+      }
+    }
+    while (z < zend) PPH_DW_SINGLE();
+#undef PPH_DW_SINGLE
+#undef PPH_DW_LOADC
+#undef PPH_DW_LOAD
+#undef PPH_DW_FETCH
+#undef PPH_DW_STEP
+#undef PPH_DW_FETCHA
+#undef PPH_DW_STEPA
+  }
+  if (MODE == 2 || MODE >= 4) {
+    __shared__ double lds[4];
+    dotacc = sell_wave_sum(dotacc);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = dotacc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+    if (MODE == 7) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        __syncthreads();
+        const double t = sell_wave_sum(dotx[k]);
+        if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) part[(int64_t)(k + 1) * PPH_PART_STRIDE + blockIdx.x] = lds[0] + lds[1] + lds[2] + lds[3];
+      }
+    }
+  }
+}
+
+// launches the walk kernel for a whole-operator product on a usable dictionary; returns the grid, 0 = not applicable
+static int sell_launch_dict_walk(pph_ctx* ctx, int mode, const Sell& E, const double* x, const double* b, const double* dinv,
+                                 const double* w, double* y, double* aux, double* z0, int64_t n, double* part, int64_t dlo,
+                                 int64_t dhi) {
+  const int64_t pxy = (int64_t)E.px * E.py;
+  if (!ctx->sell_dict_walk || E.kind != PPH_CELL_HEX || E.pz < 4 || pxy < 2048 || n != pxy * E.pz) return 0;
+  const SellDict& D = *E.dict;
+  const SellDictArgs da = {D.cls.p, D.tab.p, D.state.p, D.ncls};
+  const size_t lds = (size_t)D.ncls * 27 * sizeof(double);
+  const int64_t items = ((pxy + 511) / 512) * E.pz;
+  int64_t g = ctx->sell_dict_blocks >= 8 ? ctx->sell_dict_blocks : 1024;
+  if ((mode == 2 || mode >= 4) && g > ctx->part_cap) g = ctx->part_cap;
+  if (g > items) g = items;
+  const int grid = (int)g;
+#define PPH_DW_GO(MM)                                                                                                       \
+  hipLaunchKernelGGL((k_spmv_dict_walk<MM>), dim3(grid), dim3(256), lds, ctx->stream, E.val, E.ld, x, b, dinv, w, y, aux, z0, n, \
+                     E.px, pxy, E.pz, part, dlo, dhi, ctx->sell_flags, da)
+  switch (mode) {
+    case 0: PPH_DW_GO(0); break;
+    case 1: PPH_DW_GO(1); break;
+    case 2: PPH_DW_GO(2); break;
+    case 3: PPH_DW_GO(3); break;
+    case 4: PPH_DW_GO(4); break;
+    case 5: PPH_DW_GO(5); break;
+    case 6: PPH_DW_GO(6); break;
+    default: PPH_DW_GO(7); break;
+  }
+#undef PPH_DW_GO
+  return grid;
+}
+
 #ifdef PPH_EXPERIMENTS
 #include "experiments/pph_sell_patch.inc"  // wave-private patch walk (option "sell_patch")
 #include "experiments/pph_sell_lds.inc"    // LDS hand-over product (option "sell_lds"); neither is part of the shipped library
@@ -385,6 +692,10 @@ int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x,
   }
 #endif
   const bool dict = rpt == 2 && E.sym && E.dict && E.dict->on && (E.kind == PPH_CELL_HEX || E.kind == PPH_CELL_QUAD);
+  if (dict && cend < 0) {
+    const int g = sell_launch_dict_walk(ctx, mode, E, x, b, dinv, w, y, aux, z0, n, part, dlo, dhi);
+    if (g > 0) return g;
+  }
   int cap = (ctx->sell_blocks >= 8 && ctx->sell_blocks <= 8192) ? (ctx->sell_blocks / 8) * 8
                                                                  : (zw ? ((ctx->num_cus + 7) / 8) * 8 : 4096);
   // (a dictionary product streams vectors only: nothing to keep in L2 for a second reader, many waves to hide latency)

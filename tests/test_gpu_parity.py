@@ -1491,7 +1491,8 @@ def test_row_dictionary_products_are_bitwise_the_stored_ones(gpu_ctx_factory, nx
         if name != "plain":
             ctx.set_option("sell_dict", 1)
             ctx.set_option("sell_dict_min_rows", 1)
-        if name == "dict_plain_grid":
+        if name == "dict_plain_grid":     # k_spmv_sell<DICT> in the stored-value kernel's chunk order and grid
+            ctx.set_option("sell_dict_walk", 0)
             ctx.set_option("sell_dict_blocks", 0)
         if name == "cap":
             ctx.set_option("sell_dict_cap", 4)

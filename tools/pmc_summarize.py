@@ -6,7 +6,7 @@ bench.py run into profiles/<name>.json: HBM-side traffic per launch of the kerne
 k_bw_read / k_bw_copy in profiles/r01_pmc_calibration.txt).  The result is stamped with the kernel and the launch
 count per step it was taken on: bench.py reports `roofline.traffic` from it only when both still match.
 
-usage: pmc_summarize.py <fetch_dir> <write_dir> <out.json> <kernel substring> <steps in the run> [label]"""
+usage: pmc_summarize.py <fetch_dir> <write_dir> <out.json> <kernel substring> <steps in the run> [label] [sym] [dict]"""
 import csv
 import glob
 import json
@@ -15,6 +15,7 @@ import sys
 fetch_dir, write_dir, out, substr, steps = sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], int(sys.argv[5])
 label = sys.argv[6] if len(sys.argv) > 6 else substr
 symmetric = (len(sys.argv) > 7 and sys.argv[7] == "sym")
+dictionary = (len(sys.argv) > 8 and sys.argv[8] == "dict")
 
 
 def load(d):
@@ -38,6 +39,7 @@ for name in F:
                                  "fetch_kb_max": max(f), "write_kb_max": max(w) if w else 0.0}
     tot_f += sum(f); tot_w += sum(w); n += len(f)
 res["symmetric"] = symmetric
+res["dictionary"] = dictionary
 res["launches_in_run"] = n
 res["launches_per_step"] = n // max(steps, 1)
 res["traffic_bytes_per_launch"] = (2.0 * tot_f + tot_w) * 1024.0 / max(n, 1)

@@ -4,5 +4,5 @@ timeout -k 5 300 python -m pytest tests/test_gpu_parity.py -x -q -k "row_diction
 grep -q "pytest exit 0" $O/test.log || exit 1
 timeout -k 5 200 python tools/r3_dict_probe.py 256 30 > $O/probe.txt 2>&1; tail -20 $O/probe.txt
 B="bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-api-wall --skip-csr"
-timeout -k 5 200 python $B > $O/bench_plain.json 2> $O/bench_plain.err && cut -c1-400 $O/bench_plain.json
-timeout -k 5 200 python $B --set sell_dict=1 > $O/bench_dict.json 2> $O/bench_dict.err && cut -c1-400 $O/bench_dict.json
+
+timeout -k 5 200 python $B > $O/bench_dict.json 2> $O/bench_dict.err && cut -c1-400 $O/bench_dict.json

@@ -24,10 +24,9 @@ def make(dict_on):
 
 for dict_on in (0, 1):
     ctx = make(dict_on)
-    cfgs = [{}] if not dict_on else [{}, {"sell_dict_blocks": 0}, {"sell_dict_blocks": 512}, {"sell_dict_blocks": 1024}, {"sell_dict_blocks": 4096},
-                                      {"sell_dict_blocks": 8192}, {"sell_dict_zwalk": 0}, {"sell_dict_zwalk": 0, "sell_dict_blocks": 4096},
-                                      {"sell_dict_zwalk": 2}, {"sell_dict_zwalk": 8}, {"sell_dict_zwalk": 16, "sell_dict_blocks": 1024}]
-    base = {"sell_dict_blocks": 2048, "sell_dict_zwalk": -1}
+    W0 = {"sell_dict_walk": 0, "sell_dict_zwalk": 0, "sell_dict_blocks": 2048}
+    cfgs = [{}] if not dict_on else [{}, {"sell_dict_blocks": 512}, {"sell_dict_blocks": 2048}, {"sell_dict_blocks": 4096}, {"sell_flags": 4}, {"sell_flags": 4, "sell_dict_blocks": 2048}, W0]
+    base = {"sell_dict_blocks": 1024, "sell_dict_zwalk": -1, "sell_dict_walk": 1, "sell_flags": 0}
     for c in cfgs:
         if dict_on:
             o = dict(base); o.update(c)
