@@ -422,7 +422,7 @@ def main():
         try:
             with open(pmc_file) as f:
                 pmc = json.load(f)
-            if (int(pmc.get("launches_per_step", -1)) == int(launches) and pmc.get("kernel") == "k_spmv_sell"
+            if (int(pmc.get("launches_per_step", -1)) == int(launches) and pmc.get("kernel") in ("k_spmv_sell", "k_spmv")
                     and bool(pmc.get("symmetric", False)) == bool(sym) and bool(pmc.get("dictionary", False)) == dicton):
                 traffic = pmc.get("traffic_bytes_per_launch")
         except (OSError, ValueError):
@@ -430,9 +430,10 @@ def main():
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-        "kernel": ((f"k_spmv_sell<kind,mode,2,sym,dict> (stencil-ELL SpMV on row dictionaries: {dict_classes} distinct rows of A11 "
-                    "in LDS, a 2-byte class per row instead of the 14 stored values; operators below 1 M rows - the coarse "
-                    "multigrid levels - on their stored values; all multigrid levels of one step)")
+        "kernel": ((f"k_spmv_dict_walk<mode> (stencil-ELL SpMV on row dictionaries: {dict_classes} distinct rows of A11 in LDS, a "
+                    "2-byte class per row instead of the 14 stored values, x window of three planes in registers; operators "
+                    "below 1 M rows - the coarse multigrid levels - k_spmv_sell on their stored values; all multigrid "
+                    "levels of one step)")
                    if dicton else
                    (f"k_spmv_sell<kind,mode,2,{'sym' if sym else 'full'}> (stencil-ELL SpMV, "
                     + ("symmetric storage: 14 of 27 slot arrays, every value serves two rows, " if sym else "")

@@ -59,6 +59,20 @@ def test_split_products_stay_inside_one_partial_sum_area():
     assert r.returncode == 0 and "partial sums (cap 32)" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
 
+@pytest.mark.parametrize("cells,overlap", [(32, True), (64, True), (64, False)])
+def test_slab_operators_on_row_dictionaries(cells, overlap):
+    """The row dictionaries (option sell_dict) on slab operators - ghost planes, symmetric storage, products split into
+    interior + boundary row ranges (k_spmv_sell<DICT> on chunk ranges) and whole-slab products (k_spmv_dict_walk from
+    64^3 on): same sweeps / iterations / solution as the single context, dictionaries in use on every rank's blocks."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "slab_check.py"), "--cells", str(cells), "--backend",
+           "gloo", "--inexact", "--device-scalars", "--set", "sell_dict_min_rows=1"] + (["--halo-overlap"] if overlap else [])
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=280)
+    line = [l for l in r.stdout.splitlines() if l.startswith("world=")]
+    assert r.returncode == 0 and line, (r.stdout[-2000:], r.stderr[-2000:])
+    assert int(line[0].split("row dictionaries on ")[1].split()[0]) >= 3, line[0]
+
+
 def test_failed_halo_exchange_is_reported_not_computed_through():
     """A halo callback that fails (on every rank, at the same exchange) must surface as a COMM error from the solve -
     not as a result computed on stale ghost planes - and the context must keep refusing afterwards (sticky status)."""

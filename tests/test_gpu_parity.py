@@ -1501,6 +1501,7 @@ def test_row_dictionary_products_are_bitwise_the_stored_ones(gpu_ctx_factory, nx
         ctx.set_dirichlet(1, b, g2)
         ctx.assemble(P.k1, 3.0 * P.k2, P.beta, P.mu, monolithic=False)
         ctx.assemble(P.k1, P.k2, P.beta, P.mu, monolithic=False)      # the re-assembly path: classes kept, table re-read
+        ctx.assemble(P.k1, P.k2, P.beta, P.mu, monolithic=False)      # ... and with unchanged values: checked by the assembly kernel itself
         t = ctx.timers()
         if name in ("dict", "dict_plain_grid", "poisoned") and exact:
             assert t["dict_operators"] >= 3 and t["dict_status"] == 1 and 8 <= t["dict_classes"] <= 64, t

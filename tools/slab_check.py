@@ -127,7 +127,7 @@ if rank == 0:
     print(f"world={world} n={args.cells} kind={args.kind} solver={args.solver} pc={args.inner_pc}: sweeps {info.iterations} vs {info1.iterations}, "
           f"inner its {info.inner_iterations} vs {info1.inner_iterations}, residual {info.resnorm:.3e} vs {info1.resnorm:.3e}, "
           f"max rel diff {err:.3e}, halo calls {solver.comm.halo_calls}, allreduce calls {solver.comm.allreduce_calls}, "
-          f"symmetric storage {sym}", flush=True)
+          f"symmetric storage {sym}, row dictionaries on {solver.ctx.timers()['dict_operators']} slab operators", flush=True)
     ok = ok and (err < (1e-9 if not mono else 1e-7) and abs(info.iterations - info1.iterations) <= (0 if not mono else 2) and abs(info.inner_iterations - info1.inner_iterations) <= max(1, info1.inner_iterations // 50)
           and info.converged == 1)
 flag = torch.tensor([1.0 if ok else 0.0])
