@@ -291,7 +291,15 @@ int pph_get_timers(pph_ctx* ctx, double* out, int n);
  *                        stream while the interior rows are computed, 2: the same launches, exchange first (the two
  *                        give bit-identical results).  The three launches share one reduction slot's partial-sum area:
  *                        their grids are capped so that together they write at most "part_cap" [4096, the area's size;
- *                        tests lower it] partial sums */
+ *                        tests lower it] partial sums
+ *   "sell_dict" [1]      row dictionaries for the symmetric stencil-ELL operators of at least "sell_dict_min_rows" [1e6]
+ *                        rows: after an assembly the distinct rows (all 27 / 9 coefficients a product would load for a row,
+ *                        bit patterns) are stored once and every row gets a 2-byte class; every assembly checks every row
+ *                        against its class bit for bit; products then read the class instead of the stored values and are
+ *                        bit-identical.  More than "sell_dict_cap" [256] distinct rows (graded meshes, node spacing not
+ *                        exact in binary) or a failed check: stored values as before.  "sell_dict_walk" [1]: whole-operator
+ *                        products on hexahedra keep the x window in registers (k_spmv_dict_walk), "sell_dict_blocks"
+ *                        [1024] their grid; 0 takes effect at once, 1 at the next assembly */
 int pph_set_option(pph_ctx* ctx, const char* name, double value);
 
 #ifdef __cplusplus
