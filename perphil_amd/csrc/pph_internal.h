@@ -514,6 +514,22 @@ void la_reset_spmv_stats(pph_ctx* ctx);
 int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x, const double* b, const double* dinv,
               const double* w /* device */, double* y, double* part, int64_t dlo = 0, int64_t dhi = 0, double* aux = nullptr, double* z0 = nullptr,
               int64_t cbeg = 0, int64_t cend = -1, int grid_cap = 0);
+#ifdef __HIPCC__
+// two consecutive rows' entries of a vector as ONE 16-byte access per lane (8-byte alignment is enough for the hardware):
+// a wave then touches 1 KB of consecutive bytes per instruction - with one 8-byte store per row, each of the two store
+// instructions of a row pair writes every other 8 bytes of the lines it touches (byte-masked partial writes)
+typedef double pph_d2 __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ void sell_st2(double* p, double a, double b) {
+  pph_d2 v;
+  v.x = a; v.y = b;
+  *reinterpret_cast<pph_d2*>(p) = v;
+}
+__device__ __forceinline__ void sell_ld2(const double* p, double& a, double& b) {
+  const pph_d2 v = *reinterpret_cast<const pph_d2*>(p);
+  a = v.x; b = v.y;
+}
+#endif
+
 int sell_alloc(pph_ctx* ctx, const MeshData& mesh, DevBuf<double>& buf, Sell* out, int sym);
 // operator bytes a product streams per row: the stored values, or the 2-byte class with a usable row dictionary
 static inline double sell_stream_bytes(const pph_ctx* ctx, const Sell& E) {

@@ -267,7 +267,8 @@ __global__ __launch_bounds__(256) void k_prolong_to_q1(double* __restrict__ xout
     const int64_t sy = g.pxc, sz = (int64_t)g.pxc * g.pyc;
     const int64_t c = m + sy * (j >> 1) + sz * ((kg >> 1) - g.gzc);
     const int64_t ex = has1 ? 1 : 0, ey = oy ? sy : 0, ez = oz ? sz : 0;
-    const double x0 = xf[id0], x1 = has1 ? xf[id0 + 1] : 0.0;
+    double x0, x1 = 0.0;
+    if (has1) sell_ld2(xf + id0, x0, x1); else x0 = xf[id0];   // (16-byte accesses per pair: pph_internal.h)
     const uint8_t m0 = mf[id0], m1 = has1 ? mf[id0 + 1] : 1;
     const double a00 = xc[c], b00 = xc[c + ex], a10 = xc[c + ey], b10 = xc[c + ey + ex];
     const double a01 = xc[c + ez], b01 = xc[c + ez + ex], a11 = xc[c + ez + ey], b11 = xc[c + ez + ey + ex];
@@ -284,8 +285,9 @@ __global__ __launch_bounds__(256) void k_prolong_to_q1(double* __restrict__ xout
       else if (oy | oz) s1 = 0.5 * (v00 + (oy ? v10 : v01));
       else s1 = v00;
     }
-    xout[id0] = ((m0 & 1) != 0) ? x0 : x0 + s0;
-    if (has1) xout[id0 + 1] = ((m1 & 1) != 0) ? x1 : x1 + s1;
+    const double r0 = ((m0 & 1) != 0) ? x0 : x0 + s0;
+    if (has1) sell_st2(xout + id0, r0, ((m1 & 1) != 0) ? x1 : x1 + s1);
+    else xout[id0] = r0;
   }
 }
 

@@ -18,20 +18,6 @@ __device__ inline double sell_wave_sum(double v) {
   return v;
 }
 
-// two consecutive rows' entries of a vector as ONE 16-byte access per lane (8-byte alignment is enough for the hardware):
-// a wave then touches 1 KB of consecutive bytes per instruction - with one 8-byte store per row, each of the two store
-// instructions of a row pair writes every other 8 bytes of the lines it touches (byte-masked partial writes)
-typedef double pph_d2 __attribute__((ext_vector_type(2), aligned(8)));
-__device__ __forceinline__ void sell_st2(double* p, double a, double b) {
-  pph_d2 v;
-  v.x = a; v.y = b;
-  *reinterpret_cast<pph_d2*>(p) = v;
-}
-__device__ __forceinline__ void sell_ld2(const double* p, double& a, double& b) {
-  const pph_d2 v = *reinterpret_cast<const pph_d2*>(p);
-  a = v.x; b = v.y;
-}
-
 // operands of the epilogue of a row block: requested before the matrix stream, not after the sums
 template <int MODE, int RPT, bool CLAMP>
 __device__ __forceinline__ void sell_prologue(const double* __restrict__ x, const double* __restrict__ b,
