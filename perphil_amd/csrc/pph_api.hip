@@ -698,7 +698,7 @@ int pph_get_timers(pph_ctx* ctx, double* out, int n) {
   // row dictionaries: operators using one now (fine blocks and multigrid levels), classes of A11's, device status of A11's
   int dn = 0;
   for (const Sell* E : {&ctx->S11, &ctx->S22, &ctx->S12}) dn += (E->dict && E->dict->on) ? 1 : 0;
-  for (size_t l = 1; l < ctx->mg.size(); ++l)
+  for (size_t l = 1; ctx->mg_ok && l < ctx->mg.size(); ++l)   // (levels: only while the hierarchy matches the assembled system)
     for (int f = 0; f < 2; ++f) dn += (ctx->mg[l].ell[f].dict && ctx->mg[l].ell[f].dict->on) ? 1 : 0;
   int dst[2] = {0, 0};
   if (ctx->D11.on && ctx->D11.state.p) {

@@ -965,6 +965,7 @@ int sell_alloc(pph_ctx* ctx, const MeshData& mesh, DevBuf<double>& buf, Sell* ou
   }
   out->val = buf.p; out->ld = ld; out->kind = mesh.kind; out->px = mesh.px; out->py = mesh.py; out->pz = mesh.pzl;
   out->sym = sym;
+  out->dict = nullptr;   // whoever fills the values next decides (sell_dict_update): a dictionary never outlives the values it was checked on
   return PPH_OK;
 }
 

@@ -1520,6 +1520,15 @@ def test_row_dictionary_products_are_bitwise_the_stored_ones(gpu_ctx_factory, nx
         assert info.converged
         if name == "dict" and exact:
             assert ctx.timers()["dict_operators"] >= 3
+            # the same context through the two-step assembly (K, M, then elimination kernels): other kernels rewrite the stored
+            # values, the dictionaries must not survive that
+            ctx.set_option("asm_fused", 0)
+            ctx.assemble(P.k1, 2.0 * P.k2, P.beta, P.mu, monolithic=False)
+            assert ctx.timers()["dict_operators"] == 0
+            A11 = ctx.csr(f.MAT_A11)
+            y2 = ctx.spmv(f.MAT_A11, x)
+            ref = A11 @ x
+            assert np.abs(y2 - ref).max() <= 1e-13 * np.abs(ref).max()
         res[name] = (ys, xs, (info.iterations, info.inner_iterations), hist)
         ctx.close()
     ys0, xs0, its0, hist0 = res["plain"]
