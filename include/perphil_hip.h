@@ -155,6 +155,12 @@ int pph_solve(pph_ctx* ctx, const pph_solver_cfg* cfg, double* x_host, pph_solve
 /* same solve, result left on the device (timing without the PCIe copy); fetch with pph_get_solution */
 int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* info, double* hist, int hist_cap);
 int pph_get_solution(pph_ctx* ctx, double* x_host /* len 2n */);
+/* Page-locked host memory for the x_host / result arrays above (no reference counterpart: PETSc's Vec lives in host memory
+ * already).  A copy into pageable memory is staged by the HIP runtime and pays the first touch of a fresh array's pages; the
+ * Python host side keeps a small pool of pinned result buffers (perphil_amd/_ffi.py: Context.solution).  Freed with
+ * pph_host_free; both are independent of any context. */
+int pph_host_alloc(size_t bytes, void** out);
+int pph_host_free(void* p);
 
 /* ---- export for parity checks -----------------------------------------------------------
  * replaces: get_matrix_data_from_form() -> petsc_matrix.getValuesCSR()

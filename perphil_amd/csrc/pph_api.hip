@@ -692,6 +692,30 @@ int pph_comm_set_callbacks(pph_ctx* ctx, int rank, int world, pph_halo_fn halo, 
   return PPH_OK;
 }
 
+// page-locked host memory for result vectors (perphil_amd/_ffi.py keeps a small pool of them): a device-to-host copy into
+// pageable memory is staged by the runtime and pays the first touch of every page of a fresh array - 15 - 27 ms for the 272 MB
+// solution of a 256^3 problem against 5 - 6 ms into pinned memory
+int pph_host_alloc(size_t bytes, void** out) {
+  if (!out) return PPH_ERR_INVALID;
+  *out = nullptr;
+  void* q = nullptr;
+  const hipError_t e = hipHostMalloc(&q, bytes ? bytes : 1, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    g_last_error = std::string("hipHostMalloc failed: ") + hipGetErrorString(e);
+    return (e == hipErrorOutOfMemory) ? PPH_ERR_NOMEM : PPH_ERR_HIP;
+  }
+  *out = q;
+  return PPH_OK;
+}
+
+int pph_host_free(void* p) {
+  if (!p) return PPH_OK;
+  const hipError_t e = hipHostFree(p);
+  if (e != hipSuccess) { (void)hipGetLastError(); return PPH_ERR_HIP; }
+  return PPH_OK;
+}
+
 int pph_get_timers(pph_ctx* ctx, double* out, int n) {
   if (!ctx || !out) return PPH_ERR_INVALID;
   la_harvest_spmv_times(ctx);

@@ -1542,3 +1542,41 @@ def test_row_dictionary_products_are_bitwise_the_stored_ones(gpu_ctx_factory, nx
     for name in ("dict_plain_grid", "cap"):
         np.testing.assert_array_equal(res[name][1], xs0)
         np.testing.assert_array_equal(res[name][3], hist0)
+
+
+@pytest.mark.gpu
+def test_large_results_come_back_in_pinned_arrays_that_are_safe_to_keep(gpu_ctx_factory):
+    """Context.solution() / solve(fetch=True) hand large results out in page-locked arrays from a pool of three per context
+    (pph_host_alloc): an array somebody still refers to - directly or through a view - is never written again, one that
+    nobody keeps is reused, a fourth live result falls back to a pageable array; values equal the pageable path's."""
+    f = _ffi()
+    import perphil_amd.fd as fdm
+
+    N = 80      # 2 x 81^3 = 1 062 882 entries: above the pinning threshold
+    ctx = gpu_ctx_factory()
+    ctx.mesh_build(3, f.CELL_HEX, N, N, N)
+    hm = fdm.UnitCubeMesh(N, N, N, hexahedral=True)
+    b = hm.boundary_nodes()
+    g1, g2 = o.exact_pressures(hm.node_coordinates(b), P)
+    ctx.set_dirichlet(0, b, g1)
+    ctx.set_dirichlet(1, b, g2)
+    ctx.assemble(P.k1, P.k2, P.beta, P.mu, monolithic=False)
+    cfg = _cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_MG, inner_rtol=1e-10, inner_reduction=1e-1, inner_norm=1,
+               mg_smooth=1, picard_rtol=1e-8)
+    x1, info, _ = ctx.solve(cfg)
+    assert info.converged and 2 * ctx.n >= ctx._PIN_MIN
+    ref = x1.copy()
+    addr = lambda a: a.__array_interface__["data"][0]
+    a1 = addr(x1)
+    view = x1[5:50]                       # a view keeps the block busy
+    del x1
+    x2 = ctx.solution()
+    assert addr(x2) != a1 and np.array_equal(x2, ref) and np.array_equal(view, ref[5:50])
+    del view
+    x3 = ctx.solution()                   # the first block is free again
+    assert addr(x3) == a1 and np.array_equal(x3, ref)
+    x4, x5 = ctx.solution(), ctx.solution()
+    assert len({addr(x2), addr(x3), addr(x4), addr(x5)}) == 4 and np.array_equal(x5, ref)   # the fourth live one is pageable
+    assert len(ctx._pinned) == 3
+    ctx.close()
+    assert np.array_equal(x2, ref)        # results outlive their context
