@@ -364,12 +364,7 @@ __device__ __forceinline__ void dictw_fetch(DwOps& o, const uint16_t* __restrict
   const bool act[2] = {a0, a1};
   if (ALL || (a0 && a1)) {
     o.bv[0] = o.bv[1] = 0.0; o.dv[0] = o.dv[1] = 0.0; o.tv[0] = o.tv[1] = 0.0; o.av[0] = o.av[1] = 0.0;
-    if (ALL) {
-      typedef uint32_t u32a2 __attribute__((aligned(2)));
-      o.cls2 = *reinterpret_cast<const u32a2*>(cls + r0);   // (kept as loaded: decoding it here would make this step wait for it)
-    } else {
-      o.cls2 = (uint32_t)cls[r0] | ((uint32_t)cls[r0 + 1] << 16);
-    }
+    o.cls2 = (uint32_t)cls[r0] | ((uint32_t)cls[r0 + 1] << 16);   // (two aligned 2-byte loads: r0 is odd on every other plane)
     if (MODE == 1 || (MODE >= 3 && MODE <= 5) || MODE == 7) sell_ld2(b + r0, o.bv[0], o.bv[1]);
     if (MODE == 3 || MODE == 4) sell_ld2(dinv + r0, o.dv[0], o.dv[1]);
     if (MODE == 5 || MODE == 6) { sell_ld2(y + r0, o.tv[0], o.tv[1]); sell_ld2(aux + r0, o.av[0], o.av[1]); if (z0) sell_ld2(dinv + r0, o.dv[0], o.dv[1]); }
