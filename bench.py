@@ -410,6 +410,11 @@ def main():
     # row dictionaries (option sell_dict, default): the products of the fine blocks stream a 2-byte class per row
     # instead of the S stored values (pph_get_timers: operators on a dictionary, distinct rows of A11)
     dict_ops, dict_classes = int(tr.get("dict_operators", 0)), int(tr.get("dict_classes", 0))
+    if dist is not None:
+        # every rank must take the same extra (collective) steps below: the dictionaries count only if every slab has them
+        t = torch.tensor([dict_ops], dtype=torch.int64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        dict_ops = int(t.item())
     dicton = sell and dict_ops >= 3
     sell_bytes = (2.0 if dicton else 8.0 * S) * ctx.n + 16.0 * ctx.n
     csr_bytes = 12.0 * ctx.nnzb + 20.0 * ctx.n
