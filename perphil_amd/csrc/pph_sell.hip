@@ -385,8 +385,7 @@ __device__ __forceinline__ void dictw_fetch(DwOps& o, const uint16_t* __restrict
 
 template <int MODE, bool ALL>
 __device__ __forceinline__ void dictw_step(const double (&lo)[3][4], const double (&mid)[3][4], const double (&hi)[3][4],
-                                           const DwOps& o, const double* dtab, const double (&cm)[27], uint32_t main2,
-                                           double w, double* __restrict__ y, double* __restrict__ aux,
+                                           const DwOps& o, const double* dtab, double w, double* __restrict__ y, double* __restrict__ aux,
                                            double* __restrict__ z0, int64_t r0, bool a0, bool a1, double& dotacc, int64_t dlo,
                                            int64_t dhi, double* dotx, int flags) {
   double acc[2] = {0.0, 0.0}, xr[2] = {0.0, 0.0};
@@ -395,22 +394,7 @@ __device__ __forceinline__ void dictw_step(const double (&lo)[3][4], const doubl
     xr[0] = act[0] ? mid[1][1] : 0.0;
     xr[1] = act[1] ? mid[1][2] : 0.0;
   }
-  // every row of the wave in the block's main class (the interior rows: about half of the wave steps of a 256^3 block):
-  // its 27 coefficients are wave-uniform values read once per kernel - no LDS reads, whose latency two waves per SIMD
-  // do not hide
-  if (ALL && __all(o.cls2 == main2)) {
-    int slot = 0;
-#pragma unroll
-    for (int l = 0; l < 9; ++l) {
-      const double (&win)[3][4] = (l < 3) ? lo : (l < 6 ? mid : hi);
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) acc[i] += cm[slot] * win[l % 3][i + d];
-        ++slot;
-      }
-    }
-  } else {
+  {
     const int cb[2] = {(int)(o.cls2 & 0xffffu) * 27, (int)(o.cls2 >> 16) * 27};
     int slot = 0;
 #pragma unroll
@@ -447,12 +431,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
   const double w = (MODE == 3 || MODE == 4 || ((MODE == 5 || MODE == 6) && z0)) ? *wp : 0.0;
   double dotacc = 0.0;
   double dotx[2] = {0.0, 0.0};
-  // main class = the class of the row in the middle of the box
-  const uint32_t cmain = dok ? da.cls[(int64_t)(planes / 2) * pxy + (int64_t)(pxy / px / 2) * px + px / 2] : 0u;
-  const uint32_t main2 = (flags & 4) ? 0xffffffffu : (cmain | (cmain << 16));
-  double cm[27];
-#pragma unroll
-  for (int k = 0; k < 27; ++k) cm[k] = dok ? da.tab[cmain * 27 + k] : 0.0;
   const int64_t P = (pxy + 511) / 512;
   const int64_t total = P * planes;
   int64_t q = total * (int64_t)blockIdx.x / gridDim.x;
@@ -489,10 +467,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
 #define PPH_DW_LOAD(W, ZZ) dictw_load_plane<false>(x, (int64_t)(ZZ) * pxy + p, px, n, W)
 #define PPH_DW_FETCH(O, ZZ) dictw_fetch<MODE, false>(O, da.cls, b, dinv, y, aux, z0, (int64_t)(ZZ) * pxy + p, a0, a1)
 #define PPH_DW_STEP(LO, MID, HI, O, ZZ)                                                                         \
-    dictw_step<MODE, false>(LO, MID, HI, O, dtab, cm, main2, w, y, aux, z0, (int64_t)(ZZ) * pxy + p, a0, a1, dotacc, dlo, dhi, dotx, flags)
+    dictw_step<MODE, false>(LO, MID, HI, O, dtab, w, y, aux, z0, (int64_t)(ZZ) * pxy + p, a0, a1, dotacc, dlo, dhi, dotx, flags)
 #define PPH_DW_FETCHA(O, ZZ) dictw_fetch<MODE, true>(O, da.cls, b, dinv, y, aux, z0, (int64_t)(ZZ) * pxy + p, true, true)
 #define PPH_DW_STEPA(LO, MID, HI, O, ZZ)                                                                        \
-    dictw_step<MODE, true>(LO, MID, HI, O, dtab, cm, main2, w, y, aux, z0, (int64_t)(ZZ) * pxy + p, true, true, dotacc, dlo, dhi, dotx, flags)
+    dictw_step<MODE, true>(LO, MID, HI, O, dtab, w, y, aux, z0, (int64_t)(ZZ) * pxy + p, true, true, dotacc, dlo, dhi, dotx, flags)
     PPH_DW_LOADC(A, z - 1);
     PPH_DW_LOADC(B, z);
     PPH_DW_LOADC(C, z + 1);
