@@ -791,7 +791,7 @@ template <int KIND>
 __global__ __launch_bounds__(256) void k_dict_verify_sym(const double* __restrict__ val, int64_t ld, int px, int64_t pxy,
                                                          int64_t n, const uint16_t* __restrict__ map,
                                                          uint16_t* __restrict__ cls, const double* __restrict__ tab,
-                                                         int* state, int lds_classes) {
+                                                         int* state, int lds_classes, int walk) {
   using ST = SellSt<KIND>;
   constexpr int S = ST::S, C0 = S / 2;
   extern __shared__ double vtab[];
@@ -800,7 +800,31 @@ __global__ __launch_bounds__(256) void k_dict_verify_sym(const double* __restric
   for (int i = threadIdx.x; i < ncls * S; i += 256) vtab[i] = tab[i];
   __syncthreads();
   bool bad = false;
-  for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < n; row += (int64_t)gridDim.x * blockDim.x) {
+  // Row order.  3D (walk > 0; the launcher keeps gridDim.x a multiple of 8): a workgroup takes `walk` consecutive planes
+  // at one in-plane chunk of 256 positions, the workgroups of an XCD consecutive chunks - the mirror values of a plane
+  // are the stored values of the plane below and of the in-plane neighbours, read a step earlier into the same L2
+  // (plain grid-stride order: 1.87 x the stored bytes from the fabric).  2D: grid-stride.
+  const int64_t P = (pxy + 255) / 256;
+  const int64_t planes = walk > 0 ? n / pxy : 0;
+  const int64_t nslab = walk > 0 ? (planes + walk - 1) / walk : 0;
+  const int64_t vb = walk > 0 ? (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const int64_t nsteps = walk > 0 ? nslab * P * walk : (n + 255) / 256;
+  for (int64_t q = walk > 0 ? vb * walk : vb;; ) {
+    if (q >= nsteps) break;
+    int64_t row;
+    bool in = true;
+    if (walk > 0) {
+      const int64_t item = q / walk, t = q % walk, slab = item / P, pos = item % P;
+      const int64_t z = slab * walk + t, pp = pos * 256 + threadIdx.x;
+      in = z < planes && pp < pxy;
+      row = z * pxy + pp;
+      q += (t == walk - 1) ? (int64_t)(gridDim.x - 1) * walk + 1 : 1;
+    } else {
+      row = q * 256 + threadIdx.x;
+      in = row < n;
+      q += gridDim.x;
+    }
+    if (!in) continue;
     int c = cls[row];
     if (map) { c = map[c]; cls[row] = (uint16_t)c; }
     if (c >= ncls) { bad = true; continue; }
@@ -829,14 +853,22 @@ __global__ __launch_bounds__(256) void k_dict_verify_sym(const double* __restric
 
 static void dict_launch_verify(pph_ctx* ctx, const Sell& E, SellDict& D, int64_t n, const uint16_t* map, int lds_classes) {
   const int64_t pxy = (int64_t)E.px * E.py;
-  const int grid = sell_grid(n);
   const size_t lds = (size_t)lds_classes * sell_slots(E.kind) * sizeof(double);
-  if (E.kind == PPH_CELL_HEX)
+  if (E.kind == PPH_CELL_HEX) {
+    const int walk = (E.pz >= 8 && n == pxy * E.pz) ? 8 : 0;
+    int grid = sell_grid(n);
+    if (walk) {   // a few workgroups per CU, a multiple of 8, no more than there are (slab, chunk) items
+      const int64_t items = ((E.pz + walk - 1) / walk) * ((pxy + 255) / 256);
+      int64_t g = (int64_t)ctx->num_cus * 4;
+      if (g > items) g = items;
+      grid = (int)(((g + 7) / 8) * 8);
+    }
     hipLaunchKernelGGL(k_dict_verify_sym<PPH_CELL_HEX>, dim3(grid), dim3(256), lds, ctx->stream, E.val, E.ld, E.px, pxy, n, map,
-                       D.cls.p, D.tab.p, D.state.p, lds_classes);
-  else
-    hipLaunchKernelGGL(k_dict_verify_sym<PPH_CELL_QUAD>, dim3(grid), dim3(256), lds, ctx->stream, E.val, E.ld, E.px, pxy, n, map,
-                       D.cls.p, D.tab.p, D.state.p, lds_classes);
+                       D.cls.p, D.tab.p, D.state.p, lds_classes, walk);
+  } else {
+    hipLaunchKernelGGL(k_dict_verify_sym<PPH_CELL_QUAD>, dim3(sell_grid(n)), dim3(256), lds, ctx->stream, E.val, E.ld, E.px, pxy, n,
+                       map, D.cls.p, D.tab.p, D.state.p, lds_classes, 0);
+  }
 }
 
 int sell_dict_update(pph_ctx* ctx, Sell* E, SellDict& D, int64_t n) {
