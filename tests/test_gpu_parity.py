@@ -1580,3 +1580,46 @@ def test_large_results_come_back_in_pinned_arrays_that_are_safe_to_keep(gpu_ctx_
     assert len(ctx._pinned) == 3
     ctx.close()
     assert np.array_equal(x2, ref)        # results outlive their context
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nx,ny", [(64, 64), (256, 128), (100, 60)])
+def test_row_dictionary_on_quadrilateral_blocks(gpu_ctx_factory, nx, ny):
+    """The 2D counterpart (k_spmv_sell<quad, mode, 2, sym, DICT>: 9-point rows, no walk kernel): products of the three blocks
+    bit-identical to the stored-value kernel, a Picard solve with the same sweeps / iterations; 100 x 60 cells (spacing not exact
+    in binary) keeps its stored values unless its distinct rows fit the table."""
+    f = _ffi()
+    import perphil_amd.fd as fdm
+
+    mesh = fdm.UnitSquareMesh(nx, ny, quadrilateral=True)
+    b = mesh.boundary_nodes()
+    P2 = o.Params()
+    g1, g2 = o.exact_pressures(mesh.node_coordinates(b), P2)
+    cfg = _cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_MG, inner_rtol=1e-10, inner_reduction=1e-1, inner_norm=1,
+               mg_smooth=1, picard_rtol=1e-8)
+    rng = np.random.default_rng(5)
+    x = None
+    res = {}
+    for name in ("plain", "dict"):
+        ctx = gpu_ctx_factory()
+        ctx.set_option("sell_dict", 1 if name == "dict" else 0)
+        ctx.set_option("sell_dict_min_rows", 1)
+        ctx.mesh_build(2, f.CELL_QUAD, nx, ny, 0)
+        ctx.set_dirichlet(0, b, g1)
+        ctx.set_dirichlet(1, b, g2)
+        ctx.assemble(P2.k1, P2.k2, P2.beta, P2.mu, monolithic=False)
+        ctx.assemble(P2.k1, P2.k2, P2.beta, P2.mu, monolithic=False)
+        t = ctx.timers()
+        if name == "dict" and nx & (nx - 1) == 0 and ny & (ny - 1) == 0:
+            assert t["dict_operators"] >= 3 and t["dict_status"] == 1 and 4 <= t["dict_classes"] <= 16, t
+        if x is None:
+            x = rng.uniform(-1, 1, ctx.n)
+        ys = [ctx.spmv(w, x) for w in (f.MAT_A11, f.MAT_A22, f.MAT_A12)]
+        xs, info, hist = ctx.solve(cfg, hist_cap=64)
+        assert info.converged
+        res[name] = (ys, xs, (info.iterations, info.inner_iterations))
+        ctx.close()
+    for ya, yb in zip(res["plain"][0], res["dict"][0]):
+        np.testing.assert_array_equal(ya, yb)
+    assert res["plain"][2] == res["dict"][2]
+    np.testing.assert_allclose(res["dict"][1], res["plain"][1], rtol=0, atol=1e-12 * np.abs(res["plain"][1]).max())
