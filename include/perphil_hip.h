@@ -299,8 +299,8 @@ int pph_get_timers(pph_ctx* ctx, double* out, int n);
  *                        their grids are capped so that together they write at most "part_cap" [4096, the area's size;
  *                        tests lower it] partial sums
  *   "sell_dict" [1]      row dictionaries for the symmetric stencil-ELL operators of at least "sell_dict_min_rows" [1e6]
- *                        rows: after an assembly the distinct rows (all 27 / 9 coefficients a product would load for a row,
- *                        bit patterns) are stored once and every row gets a 2-byte class; every assembly checks every row
+ *                        rows: after an assembly the distinct rows (all 27 / 15 / 9 / 7 coefficients a product would load for a row,
+ *                        bit patterns; all four cell kinds) are stored once and every row gets a 2-byte class; every assembly checks every row
  *                        against its class bit for bit; products then read the class instead of the stored values and are
  *                        bit-identical.  More than "sell_dict_cap" [256] distinct rows (graded meshes, node spacing not
  *                        exact in binary) or a failed check: stored values as before.  "sell_dict_walk" [1]: whole-operator

@@ -533,7 +533,7 @@ __device__ __forceinline__ void sell_ld2(const double* p, double& a, double& b) 
 int sell_alloc(pph_ctx* ctx, const MeshData& mesh, DevBuf<double>& buf, Sell* out, int sym);
 // operator bytes a product streams per row: the stored values, or the 2-byte class with a usable row dictionary
 static inline double sell_stream_bytes(const pph_ctx* ctx, const Sell& E) {
-  const bool dict = ctx->sell_rpt != 1 && E.sym && E.dict && E.dict->on && (E.kind == PPH_CELL_HEX || E.kind == PPH_CELL_QUAD);
+  const bool dict = ctx->sell_rpt != 1 && E.sym && E.dict && E.dict->on;
   return dict ? 2.0 : 8.0 * sell_stored(E.kind, E.sym);
 }
 // (re)builds the row dictionary of E after its values were (re)written; sets / clears E->dict

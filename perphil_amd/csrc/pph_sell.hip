@@ -570,7 +570,7 @@ static void sell_launch_mode(pph_ctx* ctx, int mode, int grid, const Sell& E, co
 #define PPH_SELL_GO(MM)                                                                                              \
   hipLaunchKernelGGL((k_spmv_sell<KIND, MM, RPT>), dim3(grid), dim3(256), 0, ctx->stream, E.val, E.ld, x, b, dinv, w, \
                      y, aux, z0, n, E.px, pxy, halo, nchunks, chunk0, group, zwalk, ctx->sell_xmap, part, dlo, dhi, ctx->sell_flags, nod)
-  if constexpr (RPT == 2 && (KIND == PPH_CELL_HEX || KIND == PPH_CELL_QUAD)) {
+  if constexpr (RPT == 2) {
     if (E.sym && E.dict && E.dict->on) {
       // row dictionary: 2 B per row instead of the value streams; the table of distinct rows goes to LDS
       const SellDict& D = *E.dict;
@@ -650,7 +650,7 @@ int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x,
     if (g > 0) return g;
   }
 #endif
-  const bool dict = rpt == 2 && E.sym && E.dict && E.dict->on && (E.kind == PPH_CELL_HEX || E.kind == PPH_CELL_QUAD);
+  const bool dict = rpt == 2 && E.sym && E.dict && E.dict->on;
   if (dict && cend < 0) {
     const int g = sell_launch_dict_walk(ctx, mode, E, x, b, dinv, w, y, aux, z0, n, part, dlo, dhi);
     if (g > 0) return g;
@@ -854,7 +854,7 @@ __global__ __launch_bounds__(256) void k_dict_verify_sym(const double* __restric
 static void dict_launch_verify(pph_ctx* ctx, const Sell& E, SellDict& D, int64_t n, const uint16_t* map, int lds_classes) {
   const int64_t pxy = (int64_t)E.px * E.py;
   const size_t lds = (size_t)lds_classes * sell_slots(E.kind) * sizeof(double);
-  if (E.kind == PPH_CELL_HEX) {
+  if (E.kind == PPH_CELL_HEX || E.kind == PPH_CELL_TET) {
     const int walk = (E.pz >= 8 && n == pxy * E.pz) ? 8 : 0;
     int grid = sell_grid(n);
     if (walk) {   // a few workgroups per CU, a multiple of 8, no more than there are (slab, chunk) items
@@ -863,18 +863,24 @@ static void dict_launch_verify(pph_ctx* ctx, const Sell& E, SellDict& D, int64_t
       if (g > items) g = items;
       grid = (int)(((g + 7) / 8) * 8);
     }
-    hipLaunchKernelGGL(k_dict_verify_sym<PPH_CELL_HEX>, dim3(grid), dim3(256), lds, ctx->stream, E.val, E.ld, E.px, pxy, n, map,
-                       D.cls.p, D.tab.p, D.state.p, lds_classes, walk);
-  } else {
+    if (E.kind == PPH_CELL_HEX)
+      hipLaunchKernelGGL(k_dict_verify_sym<PPH_CELL_HEX>, dim3(grid), dim3(256), lds, ctx->stream, E.val, E.ld, E.px, pxy, n, map,
+                         D.cls.p, D.tab.p, D.state.p, lds_classes, walk);
+    else
+      hipLaunchKernelGGL(k_dict_verify_sym<PPH_CELL_TET>, dim3(grid), dim3(256), lds, ctx->stream, E.val, E.ld, E.px, pxy, n, map,
+                         D.cls.p, D.tab.p, D.state.p, lds_classes, walk);
+  } else if (E.kind == PPH_CELL_QUAD) {
     hipLaunchKernelGGL(k_dict_verify_sym<PPH_CELL_QUAD>, dim3(sell_grid(n)), dim3(256), lds, ctx->stream, E.val, E.ld, E.px, pxy, n,
+                       map, D.cls.p, D.tab.p, D.state.p, lds_classes, 0);
+  } else {
+    hipLaunchKernelGGL(k_dict_verify_sym<PPH_CELL_TRI>, dim3(sell_grid(n)), dim3(256), lds, ctx->stream, E.val, E.ld, E.px, pxy, n,
                        map, D.cls.p, D.tab.p, D.state.p, lds_classes, 0);
   }
 }
 
 int sell_dict_update(pph_ctx* ctx, Sell* E, SellDict& D, int64_t n) {
   E->dict = nullptr;
-  const bool want = ctx->sell_dict && E->val && E->sym && n >= ctx->sell_dict_min_rows && ctx->sell_rpt != 1 &&
-                    (E->kind == PPH_CELL_HEX || E->kind == PPH_CELL_QUAD);
+  const bool want = ctx->sell_dict && E->val && E->sym && n >= ctx->sell_dict_min_rows && ctx->sell_rpt != 1;
   if (!want) { D.on = false; return PPH_OK; }
   const bool same = D.val == E->val && D.n == n && D.px == E->px && D.py == E->py && D.bc_epoch == ctx->bc_epoch &&
                     D.cap == ctx->sell_dict_cap;

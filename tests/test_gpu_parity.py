@@ -1623,3 +1623,50 @@ def test_row_dictionary_on_quadrilateral_blocks(gpu_ctx_factory, nx, ny):
         np.testing.assert_array_equal(ya, yb)
     assert res["plain"][2] == res["dict"][2]
     np.testing.assert_allclose(res["dict"][1], res["plain"][1], rtol=0, atol=1e-12 * np.abs(res["plain"][1]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,dims", [("tet", (32, 16, 16)), ("tet", (24, 20, 12)), ("tri", (64, 32))])
+def test_row_dictionary_on_simplex_blocks(gpu_ctx_factory, kind, dims):
+    """P1 blocks (15-point rows on Kuhn tetrahedra, 7-point rows on triangles; k_spmv_sell<kind, mode, 2, sym, DICT>): products of
+    the three blocks bit-identical to the stored-value kernel, a Picard solve with the same sweeps / iterations."""
+    f = _ffi()
+    import perphil_amd.fd as fdm
+
+    if kind == "tet":
+        mesh = fdm.UnitCubeMesh(*dims)
+        dim, ck, PP = 3, f.CELL_TET, P
+    else:
+        mesh = fdm.UnitSquareMesh(*dims)
+        dim, ck, PP = 2, f.CELL_TRI, o.Params()
+    b = mesh.boundary_nodes()
+    g1, g2 = o.exact_pressures(mesh.node_coordinates(b), PP)
+    cfg = _cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_MG, inner_rtol=1e-10, inner_reduction=1e-1, inner_norm=1,
+               mg_smooth=1, picard_rtol=1e-8)
+    rng = np.random.default_rng(9)
+    x = None
+    res = {}
+    exact = all(v & (v - 1) == 0 for v in dims)
+    for name in ("plain", "dict"):
+        ctx = gpu_ctx_factory()
+        ctx.set_option("sell_dict", 1 if name == "dict" else 0)
+        ctx.set_option("sell_dict_min_rows", 1)
+        ctx.mesh_build(dim, ck, *(dims if dim == 3 else dims + (0,)))
+        ctx.set_dirichlet(0, b, g1)
+        ctx.set_dirichlet(1, b, g2)
+        ctx.assemble(PP.k1, PP.k2, PP.beta, PP.mu, monolithic=False)
+        ctx.assemble(PP.k1, PP.k2, PP.beta, PP.mu, monolithic=False)
+        t = ctx.timers()
+        if name == "dict" and exact:
+            assert t["dict_operators"] >= 3 and t["dict_status"] == 1 and 4 <= t["dict_classes"] <= 128, t
+        if x is None:
+            x = rng.uniform(-1, 1, ctx.n)
+        ys = [ctx.spmv(w, x) for w in (f.MAT_A11, f.MAT_A22, f.MAT_A12)]
+        xs, info, hist = ctx.solve(cfg, hist_cap=64)
+        assert info.converged
+        res[name] = (ys, xs, (info.iterations, info.inner_iterations))
+        ctx.close()
+    for ya, yb in zip(res["plain"][0], res["dict"][0]):
+        np.testing.assert_array_equal(ya, yb)
+    assert res["plain"][2] == res["dict"][2]
+    np.testing.assert_allclose(res["dict"][1], res["plain"][1], rtol=0, atol=1e-12 * np.abs(res["plain"][1]).max())
