@@ -535,6 +535,8 @@ static int sell_launch_dict_walk(pph_ctx* ctx, int mode, const Sell& E, const do
   const int64_t items = ((pxy + 511) / 512) * E.pz;
   int64_t g = ctx->sell_dict_blocks >= 8 ? ctx->sell_dict_blocks : 1024;
   if ((mode == 2 || mode >= 4) && g > ctx->part_cap) g = ctx->part_cap;
+  // (ranges of at least 12 steps, or the straight-line loop of the kernel hardly runs: level 1 of a 256^3 hierarchy has 4 257 steps)
+  if (g * 12 > items) g = items / 12 > ctx->num_cus ? items / 12 : ctx->num_cus;
   if (g > items) g = items;
   const int grid = (int)g;
 #define PPH_DW_GO(MM)                                                                                                       \
