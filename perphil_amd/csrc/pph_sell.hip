@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     // step z + 1 are issued before step z waits for its own).  Planes 0, planes - 1 and beyond reach outside [0, n):
     // clamped loads, kept out of the 4-step loop.
     double A[3][4], B[3][4], C[3][4], D[3][4];
-    DwOps O0, O1;
+    DwOps O0 = {}, O1 = {};   // (O1 is copied before its first request when a range is one step long)
 #define PPH_DW_LOADC(W, ZZ)                                                                                     \
     do {                                                                                                          \
       const int zz_ = (ZZ);                                                                                       \
