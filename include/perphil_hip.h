@@ -194,7 +194,8 @@ int pph_error_norms_mms(pph_ctx* ctx, int field, const double* nodal_host, doubl
  * (same rule and point order as pph_error_norms_mms); the caller evaluates its field (and gradient) there and
  * pph_error_norms_sampled returns the SQUARED partial norms over those cells: exact_q_host[(cell - cell_begin) npts + q],
  * grad_q_host[((cell - cell_begin) npts + q) dim + d]; either may be NULL (zero field / zero gradient), so the norms of
- * a finite-element function itself come from the same call.  Chunking the cell range bounds the host arrays. */
+ * a finite-element function itself come from the same call.  Chunking the cell range bounds the host arrays; nodal_host may
+ * be NULL from the second chunk on: the nodal field uploaded by the previous call on this context is used again. */
 int pph_quadrature_points(pph_ctx* ctx, int nq, int64_t cell_begin, int64_t cell_count, double* xq_host);
 int pph_error_norms_sampled(pph_ctx* ctx, const double* nodal_host, int nq, int64_t cell_begin, int64_t cell_count,
                             const double* exact_q_host, const double* grad_q_host, double* l2sq_out, double* h1sq_out);

@@ -376,6 +376,9 @@ class Context:
             raise ValueError("nodal array must have one value per mesh vertex")
         l2, h1 = 0.0, 0.0
         a, b = C.c_double(), C.c_double()
+        if exact is None:
+            chunk_cells = self.ncell      # no host samples: one call over all cells
+        first = True
         for c0 in range(0, self.ncell, chunk_cells):
             cnt = min(chunk_cells, self.ncell - c0)
             se = sg = None
@@ -393,8 +396,10 @@ class Context:
                         sg[:, d] = (np.asarray(exact(X + E), dtype=np.float64).reshape(-1)
                                     - np.asarray(exact(X - E), dtype=np.float64).reshape(-1)) / (2 * h)
                     sg = np.ascontiguousarray(sg)
-            self._check(lib.pph_error_norms_sampled(self._h, _ptr(nodal), int(nq), int(c0), int(cnt), _ptr(se), _ptr(sg),
-                                                    C.byref(a), C.byref(b)))
+            # the nodal field travels with the first chunk only (NULL afterwards = the field of the previous call)
+            self._check(lib.pph_error_norms_sampled(self._h, _ptr(nodal) if first else None, int(nq), int(c0), int(cnt),
+                                                    _ptr(se), _ptr(sg), C.byref(a), C.byref(b)))
+            first = False
             l2 += a.value
             h1 += b.value
         return float(np.sqrt(l2)), float(np.sqrt(h1))

@@ -40,6 +40,9 @@ def _set_bcs(ctx, space, bcs: List[fd.DirichletBC]) -> None:
 
 def get_matrix_data_from_form(form, boundary_conditions: List[fd.DirichletBC], symmetry_tolerance: float = 1e-8) -> MatrixData:
     """Assemble `form` (monolithic DPP form or one Picard block) with the BCs and export it as SciPy CSR."""
+    if form.space.mesh().distributed:
+        raise NotImplementedError("matrix export is an analysis path on the whole matrix: build the mesh with "
+                                  "comm=fd.COMM_SELF under torch.distributed")
     if isinstance(form, DPPBilinearForm):
         mesh = form.space.mesh()
         ctx = mesh.context()

@@ -159,6 +159,7 @@ int pph_ctx_destroy(pph_ctx* ctx) {
   for (int f = 0; f < 2; ++f) { ctx->bcmask[f].release(); ctx->g[f].release(); }
   ctx->rownear.release();
   ctx->sell_tmp.release();
+  ctx->post_u.release();
   ctx->dinv0[0].release(); ctx->dinv0[1].release(); ctx->lam0.release();
   comm_release(ctx);
   for (auto& w : ctx->work) w.release();
@@ -211,6 +212,7 @@ int pph_mesh_build(pph_ctx* ctx, int dim, int cell_kind, int nx, int ny, int nz,
   ctx->mesh.release_all();
   ctx->mesh.km_valid = false;
   ctx->mesh_ok = false;
+  ctx->post_u_valid = false;
   PPH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   MeshData& m = ctx->mesh;
   m.dim = dim; m.kind = cell_kind; m.nx = nx; m.ny = ny; m.nz = nz; m.z0 = z_cell_begin; m.nzl = z_cell_count;

@@ -408,6 +408,8 @@ struct pph_ctx {
   int sell_dict_cap = PPH_DICT_CAP;     // classes accepted (tests lower it to force the plain path)
   int sell_rpt = 2, sell_blocks = 0, sell_group = 0;   // SELL SpMV tuning: rows per thread, grid cap, XCD chunk group
   DevBuf<double> sell_tmp;              // SELL copy of the matrix last selected by pph_spmv / pph_spmv_bench
+  DevBuf<double> post_u;                // nodal field of the last pph_error_norms_sampled call (chunked callers upload it once)
+  bool post_u_valid = false;
 };
 
 // lanes per row of the CSR-vector SpMV for a matrix with the given mean row length

@@ -433,14 +433,23 @@ extern "C" int pph_error_norms_sampled(pph_ctx* ctx, const double* nodal_host, i
   PPH_REQUIRE(ctx, ctx->mesh_ok, "pph_error_norms_sampled before pph_mesh_build");
   PPH_REQUIRE(ctx, ctx->world == 1, "error norms are implemented for single-context meshes");
   const MeshData& m = ctx->mesh;
-  PPH_REQUIRE(ctx, nq >= 1 && nq <= 8 && nodal_host && l2sq_out && h1sq_out, "bad arguments");
+  PPH_REQUIRE(ctx, nq >= 1 && nq <= 8 && l2sq_out && h1sq_out, "bad arguments");
   PPH_REQUIRE(ctx, cell_begin >= 0 && cell_count >= 1 && cell_begin + cell_count <= m.ncell, "cell range outside the mesh");
+  // nodal_host == NULL: the field uploaded by the previous call on this context (a caller that walks the cells in chunks
+  // ships the nodal vector once, not once per chunk)
+  PPH_REQUIRE(ctx, nodal_host || (ctx->post_u.p && ctx->post_u.n == (size_t)m.n && ctx->post_u_valid),
+              "pph_error_norms_sampled: no nodal field (NULL means: the one of the previous call)");
   PPH_HIP(ctx, hipSetDevice(ctx->device));
   const int64_t npts = (m.dim == 2) ? nq * nq : nq * nq * nq;
-  DevBuf<double> u, part, se, sg;
-  PPH_TRY(u.alloc(ctx, (size_t)m.n));
+  DevBuf<double> part, se, sg;
+  DevBuf<double>& u = ctx->post_u;
   PPH_TRY(part.alloc(ctx, 2 * 2048 + 2));
-  PPH_HIP(ctx, hipMemcpyAsync(u.p, nodal_host, sizeof(double) * (size_t)m.n, hipMemcpyHostToDevice, ctx->stream));
+  if (nodal_host) {
+    ctx->post_u_valid = false;
+    PPH_TRY(u.alloc(ctx, (size_t)m.n));
+    PPH_HIP(ctx, hipMemcpyAsync(u.p, nodal_host, sizeof(double) * (size_t)m.n, hipMemcpyHostToDevice, ctx->stream));
+    ctx->post_u_valid = true;
+  }
   if (exact_q_host) {
     PPH_TRY(se.alloc(ctx, (size_t)(cell_count * npts)));
     PPH_HIP(ctx, hipMemcpyAsync(se.p, exact_q_host, sizeof(double) * (size_t)(cell_count * npts), hipMemcpyHostToDevice, ctx->stream));
@@ -463,7 +472,7 @@ extern "C" int pph_error_norms_sampled(pph_ctx* ctx, const double* nodal_host, i
   PPH_HIP(ctx, hipGetLastError());
   *l2sq_out = r[0];
   *h1sq_out = r[1];
-  u.release(); part.release(); se.release(); sg.release();
+  part.release(); se.release(); sg.release();
   return PPH_OK;
 }
 

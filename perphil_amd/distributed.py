@@ -173,59 +173,131 @@ class Communicator:
         ctx._comm = self  # keep the callbacks alive as long as the context
 
 
+def default_device() -> int:
+    """Device of this rank: torch's current device when torch already selected one, else LOCAL_RANK modulo the device
+    count (ranks of a gloo rehearsal share devices)."""
+    import os
+    import torch
+
+    ndev = max(torch.cuda.device_count(), 1)
+    if "LOCAL_RANK" in os.environ:
+        return int(os.environ["LOCAL_RANK"]) % ndev
+    return 0
+
+
+def process_group():
+    """(rank, world) of the default torch.distributed group when one is initialised with more than one rank, else
+    None.  torch is not imported for the question: a process that never imported it is not distributed."""
+    import sys
+
+    if "torch" not in sys.modules:
+        return None
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() <= 1:
+        return None
+    return dist.get_rank(), dist.get_world_size()
+
+
+class Transport:
+    """What carries a slab context's halo planes and reductions, and how it got there."""
+
+    def __init__(self):
+        self.kind = "none"            # "rccl" | "torch" | "none"
+        self.backend = ""             # torch.distributed backend of the group
+        self.ranks_seen = 1
+        self.rccl_error = None        # message of a failed RCCL start-up when the callbacks took over
+        self.comm: Optional[Communicator] = None
+
+    @property
+    def label(self) -> str:
+        """ "rccl" (library-issued ncclSend/Recv/AllReduce on the solver stream), "torch-nccl" / "torch-gloo" (callbacks
+        into torch.distributed, one host synchronisation per exchange), "none" (single rank)."""
+        if self.kind == "rccl":
+            return "rccl"
+        return f"torch-{self.backend}" if self.kind == "torch" else "none"
+
+
+def strict_rccl() -> bool:
+    import os
+
+    return os.environ.get("PERPHIL_STRICT_RCCL", "0") not in ("", "0")
+
+
+def attach_transport(ctx: _ffi.Context, group=None, transport: str = "auto", strict: Optional[bool] = None,
+                     inject_rccl_failure: bool = False) -> Transport:
+    """Give a slab context its communication.  "auto": the library's own RCCL transport with the nccl backend, the
+    torch.distributed callbacks otherwise (gloo rehearsals).  When the RCCL transport fails to start (library missing,
+    ncclCommInitRank or the neighbour self-test failing on ANY rank) all ranks move to the callback transport
+    together - still RCCL on the device with the nccl backend, but one host synchronisation per exchange - and the
+    Transport says so (`label` "torch-nccl", `rccl_error` the message); `strict` (default: PERPHIL_STRICT_RCCL=1)
+    raises instead.  `inject_rccl_failure` (tests): behave as if the RCCL start-up had failed."""
+    import torch.distributed as dist
+
+    t = Transport()
+    t.backend = dist.get_backend(group)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if strict is None:
+        strict = strict_rccl()
+    if transport == "auto":
+        transport = "rccl" if t.backend == "nccl" else "torch"
+    t.kind = transport
+    if transport == "rccl":
+        try:
+            if inject_rccl_failure:
+                raise RuntimeError("injected RCCL start-up failure (test)")
+            t.ranks_seen = init_rccl(ctx, group)   # raises on EVERY rank when any rank failed
+        except RuntimeError as e:
+            if strict:
+                raise RuntimeError(f"RCCL transport unavailable ({e}); without PERPHIL_STRICT_RCCL / --strict the run "
+                                   f"continues on the torch.distributed callbacks and says so") from e
+            if rank == 0:
+                print(f"[perphil_amd.distributed] {e}: continuing on the torch.distributed callbacks on all ranks",
+                      flush=True)
+            t.kind, t.rccl_error = "torch", str(e)
+    if t.kind == "torch":
+        t.comm = Communicator(group)
+        t.comm.attach(ctx)
+        one = np.ones(1)   # the callback transport's own check: one all-reduce of 1 over the group
+        t.comm._allreduce(None, one.ctypes.data_as(C.c_void_p), 1)
+        t.ranks_seen = int(one[0])
+    if t.ranks_seen != world:
+        raise RuntimeError(f"transport {t.label} sees {t.ranks_seen} ranks of {world}")
+    return t
+
+
 class SlabSolver:
-    """The DPP unit-cube problem on `world` slabs: assemble + block-Picard solve with multigrid-CG
-    block solves, manufactured Dirichlet data; same algorithm and iteration counts as one GPU."""
+    """The benchmark's driver of a slab-decomposed unit cube: the reference's objects (fd.UnitCubeMesh under an
+    initialised torch.distributed group -> this rank's slab context with its transport, DirichletBC with the
+    manufactured pressures -> the slab's boundary nodes) and a solver configuration stepped WITHOUT fetching the
+    solution (bench.py times assemble + solve with the result left on the device; callers of the public API use
+    solve_dpp / solve_dpp_nonlinear on the same mesh objects and get the same context)."""
 
     def __init__(self, n_cells: int, world: int, rank: int, device: int, k1: float, k2: float, beta: float, mu: float,
                  inner_rtol: float = 1e-10, smooth: int = 2, kind: int = _ffi.CELL_HEX, group=None,
                  inner_pc: int = _ffi.PC_MG, transport: str = "auto", inner_reduction: float = 0.0,
-                 inner_norm: int = 0, allow_fallback: bool = False):
+                 inner_norm: int = 0, strict: Optional[bool] = None, inject_rccl_failure: bool = False):
         from .manufactured_solutions import exact_expressions_3d
         from .parameters import DPPParameters
+        from .solver import _apply_bcs
         from . import fd
 
         self.params = (k1, k2, beta, mu)
-        self.slab: Slab = make_slab(n_cells, n_cells, n_cells, world, rank)
-        self.comm = Communicator(group)
-        assert self.comm.world == world and self.comm.rank == rank
-        self.ctx = _ffi.Context(device)
-        s = self.slab
-        self.ctx.mesh_build(3, kind, s.nx, s.ny, s.nz, s.z_begin, s.z_count, s.ghost_lo, s.ghost_hi)
-        # transport: "rccl" = ncclSend/Recv/AllReduce issued by the library on its own stream (default with
-        # the nccl backend), "torch" = callbacks into torch.distributed (needed for gloo rehearsals)
-        if transport == "auto":
-            transport = "rccl" if self.comm.backend == "nccl" else "torch"
-        self.transport_requested = transport
-        self.transport = transport
-        self.ranks_seen = world if world == 1 else 0
-        if transport == "rccl":
-            try:
-                self.ranks_seen = init_rccl(self.ctx, group)   # raises on EVERY rank when any rank failed
-            except RuntimeError as e:
-                # no silent downgrade: the callback transport synchronises the host on every exchange, so a scaling
-                # figure taken on it must say so (bench.py records config.transport) and has to be asked for
-                if not allow_fallback:
-                    raise RuntimeError(f"RCCL transport unavailable ({e}); pass allow_fallback=True (bench.py "
-                                       f"--allow-fallback) to run on the torch.distributed callbacks instead") from e
-                if rank == 0:
-                    print(f"[perphil_amd.distributed] {e}: falling back to torch.distributed callbacks on all ranks",
-                          flush=True)
-                self.transport = "torch"
-        if self.transport == "torch":
-            self.comm.attach(self.ctx)
-            if world > 1:
-                # the callback transport's own check: one all-reduce of 1 over the group
-                one = np.ones(1)
-                self.comm._allreduce(None, one.ctypes.data_as(C.c_void_p), 1)
-                self.ranks_seen = int(one[0])
-        mesh = fd.UnitCubeMesh(n_cells, n_cells, n_cells, hexahedral=(kind == _ffi.CELL_HEX))
-        loc, glob = s.boundary_local()
-        X = mesh.node_coordinates(glob)
-        _, p1, _, p2 = exact_expressions_3d(mesh, DPPParameters(k1=k1, k2=k2, beta=beta, mu=mu))
-        self.ctx.set_dirichlet(0, loc, p1(X))
-        self.ctx.set_dirichlet(1, loc, p2(X))
-        self.global_dofs = 2 * (n_cells + 1) ** 3
+        self.mesh = fd.UnitCubeMesh(n_cells, n_cells, n_cells, hexahedral=(kind == _ffi.CELL_HEX))
+        self.mesh.distribute(group=group, device=device, transport=transport, strict=strict,
+                             inject_rccl_failure=inject_rccl_failure)
+        self.slab: Slab = self.mesh.slab
+        assert self.slab is not None and (self.slab.world, self.slab.rank) == (world, rank)
+        self.ctx = self.mesh.context()
+        self.transport_info: Transport = self.mesh.transport
+        self.comm = self.transport_info.comm
+        self.ranks_seen = self.transport_info.ranks_seen
+        V = fd.FunctionSpace(self.mesh, "CG", 1)
+        self.W = V * V
+        _, p1, _, p2 = exact_expressions_3d(self.mesh, DPPParameters(k1=k1, k2=k2, beta=beta, mu=mu))
+        self.bcs = [fd.DirichletBC(self.W.sub(0), p1, "on_boundary"), fd.DirichletBC(self.W.sub(1), p2, "on_boundary")]
+        _apply_bcs(self.ctx, self.W, self.bcs)
+        self.global_dofs = self.W.dim()
         cfg = _ffi.SolverCfg()
         cfg.ksp_type, cfg.pc_type, cfg.restart, cfg.max_it = _ffi.KSP_GMRES, _ffi.PC_FIELDSPLIT, 30, 50000
         cfg.rtol, cfg.atol = 1e-8, 1e-12
@@ -248,25 +320,30 @@ class SlabSolver:
 
     @property
     def transport_label(self) -> str:
-        """What carries the halo planes and reductions: "rccl" (library-issued ncclSend/Recv/AllReduce on the solver
-        stream), "torch-nccl" / "torch-gloo" (callbacks into torch.distributed, one host synchronisation per
-        exchange)."""
-        return "rccl" if self.transport == "rccl" else f"torch-{self.comm.backend}"
+        return self.transport_info.label
 
     def gather_solution(self) -> Optional[np.ndarray]:
-        """Global field-major solution on rank 0 (tests / small runs only)."""
-        torch, dist = self.comm.torch, self.comm.dist
-        s = self.slab
-        x = self.ctx.solution()
-        nl, ng = s.n_local, s.plane * (s.nz + 1)
-        full = np.zeros(2 * ng)
-        for f in (0, 1):
-            full[f * ng:(f + 1) * ng][s.owned_global] = x[f * nl:(f + 1) * nl][s.owned_local]
-        t = torch.from_numpy(full)
-        if self.comm.on_device:
-            d = t.cuda()
-            dist.all_reduce(d, group=self.comm.group)
-            full = d.cpu().numpy()
-        else:
-            dist.all_reduce(t, group=self.comm.group)
-        return full
+        """Global field-major solution on every rank (tests / small runs only)."""
+        return gather_field_major(self.slab, self.ctx.solution())
+
+
+def gather_field_major(slab: Slab, x_local: np.ndarray, group=None) -> np.ndarray:
+    """Global field-major vector from every rank's local one (owned entries; ghost planes dropped): zero-padded
+    all-reduce over the group - small runs, tests and post-processing, not the hot path."""
+    import torch
+    import torch.distributed as dist
+
+    s = slab
+    nl, ng = s.n_local, s.plane * (s.nz + 1)
+    nf = x_local.size // nl
+    full = np.zeros(nf * ng)
+    for f in range(nf):
+        full[f * ng:(f + 1) * ng][s.owned_global] = x_local[f * nl:(f + 1) * nl][s.owned_local]
+    t = torch.from_numpy(full)
+    if dist.get_backend(group) == "nccl":
+        d = t.cuda()
+        dist.all_reduce(d, group=group)
+        full = d.cpu().numpy()
+    else:
+        dist.all_reduce(t, group=group)
+    return full

@@ -61,16 +61,82 @@ def sqrt(x):
     return Constant(math.sqrt(float(x))) if isinstance(x, Constant) else math.sqrt(x)
 
 
-class Mesh:
-    """Structured unit square / unit cube; lexicographic vertex numbering."""
+COMM_WORLD, COMM_SELF = "world", "self"
 
-    def __init__(self, dim: int, kind: int, nx: int, ny: int, nz: int = 0):
+
+class Mesh:
+    """Structured unit square / unit cube; lexicographic vertex numbering.
+
+    Under an initialised ``torch.distributed`` group of G > 1 ranks (one process per GPU) a 3D mesh with
+    ``comm=COMM_WORLD`` (the default, like Firedrake's) is DISTRIBUTED: rank r holds the cell slab
+    ``partition.make_slab(nx, ny, nz, G, r)`` - its owned node planes plus one ghost plane per neighbour - and
+    ``context()`` is that slab's device context with its transport attached (RCCL over xGMI with the nccl backend).
+    Local node ids are lexicographic inside the slab's box: global id = local id + z_begin * (nx+1)(ny+1).
+    2D meshes, meshes with fewer than two cell layers per rank and ``comm=COMM_SELF`` meshes are REPLICATED: every
+    rank holds (and solves on) the whole mesh, nothing is communicated.  The decision is taken at first use and kept."""
+
+    def __init__(self, dim: int, kind: int, nx: int, ny: int, nz: int = 0, comm=COMM_WORLD):
         if dim not in (2, 3):
             raise ValueError("dim must be 2 or 3")
         if min(nx, ny) < 1 or (dim == 3 and nz < 1):
             raise ValueError("need at least one cell per direction")
         self.dim, self.kind, self.nx, self.ny, self.nz = dim, kind, int(nx), int(ny), int(nz)
+        self.comm = comm
         self._ctx = None  # device context, created on first solve
+        self._slab = None          # partition.Slab of this rank once distributed
+        self._decided = False      # distribution decided (first use)
+        self._dist_args = {}       # distribute(...) keywords: group, device, transport, strict
+        self.transport = None      # distributed.Transport once the slab context exists
+        self.replicated_because = None
+
+    # -- distribution ---------------------------------------------------------------------------
+    def distribute(self, group=None, device=None, transport: str = "auto", strict=None, inject_rccl_failure: bool = False):
+        """Optional, before first use: the process group (default: torch.distributed's default group), the device and
+        the transport of the slab context.  Without it the defaults apply when the mesh is first used."""
+        if self._decided:
+            raise RuntimeError("the mesh is already in use: call distribute() right after creating it")
+        self._dist_args = dict(group=group, device=device, transport=transport, strict=strict,
+                               inject_rccl_failure=inject_rccl_failure)
+        return self
+
+    def _decide(self) -> None:
+        if self._decided:
+            return
+        self._decided = True
+        if self.comm == COMM_SELF:
+            return
+        from .distributed import process_group
+
+        pg = process_group()
+        if pg is None:
+            return
+        group = self._dist_args.get("group")
+        if group is not None:
+            import torch.distributed as dist
+
+            pg = (dist.get_rank(group), dist.get_world_size(group))
+            if pg[1] <= 1:
+                return
+        rank, world = pg
+        if self.dim != 3:
+            self.replicated_because = "2D meshes are replicated on every rank"
+            return
+        if self.nz // world < 2:
+            self.replicated_because = f"nz = {self.nz} gives fewer than 2 cell layers per rank on {world} ranks"
+            return
+        from .partition import make_slab
+
+        self._slab = make_slab(self.nx, self.ny, self.nz, world, rank)
+
+    @property
+    def slab(self):
+        """This rank's ``partition.Slab`` when the mesh is distributed, else None."""
+        self._decide()
+        return self._slab
+
+    @property
+    def distributed(self) -> bool:
+        return self.slab is not None
 
     # -- sizes ----------------------------------------------------------------------------------
     @property
@@ -78,8 +144,14 @@ class Mesh:
         return self.nx + 1, self.ny + 1, (self.nz + 1 if self.dim == 3 else 1)
 
     def num_vertices(self) -> int:
+        """Global vertex count (like Firedrake's under MPI)."""
         px, py, pz = self.node_dims
         return px * py * pz
+
+    def num_local_vertices(self) -> int:
+        """Vertices of this rank's box (owned + ghost planes); = num_vertices() when not distributed."""
+        s = self.slab
+        return self.num_vertices() if s is None else s.n_local
 
     def num_cells(self) -> int:
         boxes = self.nx * self.ny * (self.nz if self.dim == 3 else 1)
@@ -88,8 +160,14 @@ class Mesh:
     def geometric_dimension(self) -> int:
         return self.dim
 
+    def local_to_global(self, nodes: np.ndarray) -> np.ndarray:
+        s = self.slab
+        nodes = np.asarray(nodes, dtype=np.int64)
+        return nodes if s is None else nodes + s.z_begin * s.plane
+
     # -- geometry (host side, closed form; only boundary coordinates are needed by the hot path) --
     def node_coordinates(self, nodes: Optional[np.ndarray] = None) -> np.ndarray:
+        """Coordinates of GLOBAL vertex ids (all vertices if None)."""
         px, py, _ = self.node_dims
         ids = np.arange(self.num_vertices(), dtype=np.int64) if nodes is None else np.asarray(nodes, dtype=np.int64)
         i, j = ids % px, (ids // px) % py
@@ -98,8 +176,14 @@ class Mesh:
             cols.append((ids // (px * py)) / self.nz)
         return np.stack(cols, axis=1).astype(np.float64)
 
+    def local_node_coordinates(self, nodes: Optional[np.ndarray] = None) -> np.ndarray:
+        """Coordinates of LOCAL vertex ids (all local vertices if None)."""
+        if nodes is None:
+            nodes = np.arange(self.num_local_vertices(), dtype=np.int64)
+        return self.node_coordinates(self.local_to_global(nodes))
+
     def boundary_nodes(self) -> np.ndarray:
-        """Sorted vertex ids with the "on_boundary" marker."""
+        """Sorted GLOBAL vertex ids with the "on_boundary" marker."""
         px, py, pz = self.node_dims
         if self.dim == 2:
             m = np.zeros((py, px), dtype=bool)
@@ -112,25 +196,61 @@ class Mesh:
             m[:, :, 0] = m[:, :, -1] = True
         return np.nonzero(m.ravel())[0].astype(np.int64)
 
-    def context(self, device: int = 0):
-        """Device context holding this mesh (cell->dof map, CSR pattern, K and M are cached there)."""
+    def local_boundary_nodes(self) -> np.ndarray:
+        """Sorted LOCAL vertex ids on the boundary of the unit square / cube (ghost planes included: their Dirichlet
+        values enter the lifting of the owned rows next to them)."""
+        s = self.slab
+        return self.boundary_nodes() if s is None else s.boundary_local()[0]
+
+    def context(self, device: Optional[int] = None):
+        """Device context holding this mesh - this rank's slab with its transport when the mesh is distributed
+        (cell->dof map, operators and the multigrid hierarchy are cached there)."""
         from . import _ffi
 
+        s = self.slab
+        if device is None:
+            device = self._dist_args.get("device")
+        if device is None:
+            if self._ctx is not None:
+                return self._ctx
+            if s is not None:
+                from .distributed import default_device
+
+                device = default_device()
+            else:
+                device = 0
         if self._ctx is None or self._ctx.device != device:
             ctx = _ffi.Context(device)
-            ctx.mesh_build(self.dim, self.kind, self.nx, self.ny, self.nz)
+            if s is None:
+                ctx.mesh_build(self.dim, self.kind, self.nx, self.ny, self.nz)
+            else:
+                from .distributed import attach_transport
+
+                ctx.mesh_build(3, self.kind, s.nx, s.ny, s.nz, s.z_begin, s.z_count, s.ghost_lo, s.ghost_hi)
+                a = self._dist_args
+                self.transport = attach_transport(ctx, a.get("group"), a.get("transport", "auto"), a.get("strict"),
+                                                  a.get("inject_rccl_failure", False))
             self._ctx = ctx
         return self._ctx
 
+    def serial_twin(self) -> "Mesh":
+        """The same mesh held whole by this process (COMM_SELF): where gathered functions live."""
+        if not self.distributed:
+            return self
+        if getattr(self, "_twin", None) is None:
+            self._twin = Mesh(self.dim, self.kind, self.nx, self.ny, self.nz, comm=COMM_SELF)
+        return self._twin
 
-def UnitSquareMesh(nx: int, ny: int, quadrilateral: bool = False, **_ignored) -> Mesh:
+
+def UnitSquareMesh(nx: int, ny: int, quadrilateral: bool = False, comm=COMM_WORLD, **_ignored) -> Mesh:
     """``fd.UnitSquareMesh``: quads, or triangles with the "left" diagonal (Firedrake's default)."""
-    return Mesh(2, CELL_QUAD if quadrilateral else CELL_TRI, nx, ny)
+    return Mesh(2, CELL_QUAD if quadrilateral else CELL_TRI, nx, ny, comm=comm)
 
 
-def UnitCubeMesh(nx: int, ny: int, nz: int, hexahedral: bool = False, **_ignored) -> Mesh:
-    """``fd.UnitCubeMesh``: hexes, or six Kuhn tetrahedra per cube."""
-    return Mesh(3, CELL_HEX if hexahedral else CELL_TET, nx, ny, nz)
+def UnitCubeMesh(nx: int, ny: int, nz: int, hexahedral: bool = False, comm=COMM_WORLD, **_ignored) -> Mesh:
+    """``fd.UnitCubeMesh``: hexes, or six Kuhn tetrahedra per cube; distributed by cell slabs along z under an
+    initialised torch.distributed group (class Mesh)."""
+    return Mesh(3, CELL_HEX if hexahedral else CELL_TET, nx, ny, nz, comm=comm)
 
 
 class FunctionSpace:
@@ -147,7 +267,12 @@ class FunctionSpace:
         return self._mesh
 
     def dim(self) -> int:
+        """Global dof count (what Firedrake's ``V.dim()`` reports under MPI as well)."""
         return self._mesh.num_vertices()
+
+    def local_dim(self) -> int:
+        """Dofs this rank stores (owned + ghost planes of its slab); = dim() when the mesh is not distributed."""
+        return self._mesh.num_local_vertices()
 
     def num_sub_spaces(self) -> int:
         return 1
@@ -165,6 +290,9 @@ class VectorFunctionSpace(FunctionSpace):
 
     def dim(self) -> int:
         return self._mesh.num_vertices() * self.value_size
+
+    def local_dim(self) -> int:
+        return self._mesh.num_local_vertices() * self.value_size
 
 
 class _IndexedSubSpace(FunctionSpace):
@@ -200,6 +328,9 @@ class MixedFunctionSpace:
     def dim(self) -> int:
         return sum(s.dim() for s in self._subs)
 
+    def local_dim(self) -> int:
+        return sum(s.local_dim() for s in self._subs)
+
 
 class _Dat:
     def __init__(self, arr: np.ndarray):
@@ -211,17 +342,21 @@ class _Dat:
 
 
 class Function:
-    """Nodal coefficient vector on a (mixed) space; ``sub(i)`` / ``subfunctions`` are views."""
+    """Nodal coefficient vector on a (mixed) space; ``sub(i)`` / ``subfunctions`` are views.
+
+    On a distributed mesh the vector is this rank's LOCAL one (field-major over the slab's box, ghost planes
+    included, as the device holds it); ``owned()`` drops the ghost planes, ``gather()`` returns the whole function on
+    the mesh's serial twin on every rank (``dat.data_ro`` is the owned part, as in Firedrake under MPI)."""
 
     def __init__(self, space, val: Optional[np.ndarray] = None, name: Optional[str] = None):
         self._space, self.name = space, name
-        n = space.dim()
+        n = space.local_dim()
         if val is None:
             val = np.zeros(n, dtype=np.float64)
         if val.shape != (n,):
             raise ValueError(f"expected {n} coefficients, got {val.shape}")
         self._val = val
-        self.dat = _Dat(self._val)
+        self.dat = _Dat(self._val if not space.mesh().distributed else self.owned())
 
     def function_space(self):
         return self._space
@@ -229,12 +364,39 @@ class Function:
     def vector(self) -> np.ndarray:
         return self._val
 
+    def _fields(self):
+        sp = self._space
+        return [sp.sub(i) for i in range(sp.num_sub_spaces())] if isinstance(sp, MixedFunctionSpace) else [sp]
+
+    def owned(self) -> np.ndarray:
+        """Owned entries, field-major (a copy when the mesh is distributed, the vector itself otherwise)."""
+        s = self._space.mesh().slab
+        if s is None:
+            return self._val
+        nl, nf = s.n_local, len(self._fields())
+        return np.concatenate([self._val[f * nl:(f + 1) * nl][s.owned_local] for f in range(nf)])
+
+    def gather(self) -> "Function":
+        """The whole function on the mesh's serial twin, on every rank (collective; small runs, tests and
+        post-processing - error norms, ``at``, slices - not the hot path)."""
+        mesh = self._space.mesh()
+        if not mesh.distributed:
+            return self
+        from .distributed import gather_field_major
+
+        full = gather_field_major(mesh.slab, self._val, mesh._dist_args.get("group"))
+        twin = mesh.serial_twin()
+        fields = self._fields()
+        V = FunctionSpace(twin, "CG", 1)
+        space = MixedFunctionSpace([V] * len(fields)) if isinstance(self._space, MixedFunctionSpace) else V
+        return Function(space, full, name=self.name)
+
     def sub(self, i: int) -> "Function":
         if not isinstance(self._space, MixedFunctionSpace):
             raise IndexError("not a mixed function")
-        off = sum(self._space.sub(k).dim() for k in range(i))
+        off = sum(self._space.sub(k).local_dim() for k in range(i))
         V = self._space.sub(i)
-        return Function(V, self._val[off:off + V.dim()], name=f"{self.name or 'w'}[{i}]")
+        return Function(V, self._val[off:off + V.local_dim()], name=f"{self.name or 'w'}[{i}]")
 
     @property
     def subfunctions(self) -> Tuple["Function", ...]:
@@ -254,6 +416,8 @@ class Function:
     def at(self, point: Sequence[float]) -> float:
         """Value at a point that coincides with a mesh vertex (what ``slice_along_x`` needs)."""
         mesh = self._space.mesh()
+        if mesh.distributed:
+            return self.gather().at(point)
         dims = (mesh.nx, mesh.ny, mesh.nz)[: mesh.dim]
         idx = []
         for c, nc in zip(point, dims):
@@ -270,18 +434,26 @@ Expr = Union[float, Constant, np.ndarray, Callable[[np.ndarray], np.ndarray], Fu
 
 
 def evaluate(expr: Expr, mesh: Mesh, nodes: Optional[np.ndarray]) -> np.ndarray:
-    """Values of a boundary/initial datum at mesh vertices ``nodes`` (all vertices if None)."""
-    count = mesh.num_vertices() if nodes is None else len(nodes)
+    """Values of a boundary/initial datum at the LOCAL mesh vertices ``nodes`` (all local vertices if None; local =
+    global on a mesh that is not distributed).  Callables see global coordinates; nodal arrays may be global (one value
+    per mesh vertex) or local; Functions are read where they live."""
+    nloc = mesh.num_local_vertices()
+    count = nloc if nodes is None else len(nodes)
     if isinstance(expr, Function):
-        return expr.vector() if nodes is None else expr.vector()[nodes]
+        expr = expr.vector()
+        if expr.shape != (nloc,):
+            raise ValueError("boundary Function must live on a scalar CG-1 space of the same mesh")
     if isinstance(expr, (int, float, Constant)):
         return np.full(count, float(expr))
     if isinstance(expr, np.ndarray):
-        if expr.shape != (mesh.num_vertices(),):
-            raise ValueError("nodal array must have one value per mesh vertex")
-        return expr if nodes is None else expr[nodes]
+        if expr.shape == (nloc,):
+            return expr if nodes is None else expr[nodes]
+        if expr.shape == (mesh.num_vertices(),):
+            g = mesh.local_to_global(np.arange(nloc, dtype=np.int64) if nodes is None else nodes)
+            return expr[g]
+        raise ValueError("nodal array must have one value per mesh vertex")
     if callable(expr):
-        vals = np.asarray(expr(mesh.node_coordinates(nodes)), dtype=np.float64)
+        vals = np.asarray(expr(mesh.local_node_coordinates(nodes)), dtype=np.float64)
         if vals.shape != (count,):
             raise ValueError("expression must return one value per point")
         return vals
@@ -304,14 +476,22 @@ class DirichletBC:
         return 0 if self._V.index is None else int(self._V.index)
 
     def nodes_and_values(self) -> Tuple[np.ndarray, np.ndarray]:
-        """Boundary nodes and their values.  A callable datum (the manufactured pressures) is evaluated once per
-        condition object: every solve with the same conditions used to re-evaluate exp / sin at 394 k boundary nodes
-        (256^3: ~20 ms per field and call).  Constants, arrays and Functions are read afresh (they can be reassigned)."""
+        """LOCAL boundary nodes (this rank's slab when the mesh is distributed, ghost planes included) and their
+        values.  A callable datum is evaluated once per (condition, mesh, datum version): every solve with the same
+        conditions used to re-evaluate exp / sin at 394 k boundary nodes (256^3: ~20 ms per field and call).  The cache
+        key holds the callable's ``version`` / ``params`` attributes when it has them (MMSPressure: its parameters), so
+        a datum whose captured parameters change is evaluated again; ``invalidate()`` drops the cache for callables
+        that change without saying so.  Constants, arrays and Functions are read afresh (they can be reassigned)."""
         mesh = self._V.mesh()
+        nodes = mesh.local_boundary_nodes()
         if callable(self.value) and not isinstance(self.value, (Function, Constant)):
-            if getattr(self, "_cache", None) is None:
-                nodes = mesh.boundary_nodes()
-                self._cache = (nodes, evaluate(self.value, mesh, nodes))
-            return self._cache
-        nodes = mesh.boundary_nodes()
+            key = (id(mesh), id(self.value), getattr(self.value, "version", None), getattr(self.value, "params", None))
+            cached = getattr(self, "_cache", None)
+            if cached is None or cached[0] != key:
+                self._cache = (key, nodes, evaluate(self.value, mesh, nodes))
+            return self._cache[1], self._cache[2]
         return nodes, evaluate(self.value, mesh, nodes)
+
+    def invalidate(self) -> None:
+        """Forget the evaluated datum (a callable whose captured state changed)."""
+        self._cache = None

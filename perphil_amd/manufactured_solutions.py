@@ -25,6 +25,11 @@ class MMSPressure:
         self._fn, self.field, self.dim = fn, field, dim
         self.k1, self.k2, self.beta, self.mu = k1, k2, beta, mu
 
+    @property
+    def params(self):
+        """What the values depend on (fd.DirichletBC keys its cache of evaluated boundary data on it)."""
+        return (self.field, self.dim, self.k1, self.k2, self.beta, self.mu)
+
     def __call__(self, X: np.ndarray) -> np.ndarray:
         return self._fn(X)
 
@@ -87,6 +92,6 @@ def interpolate_exact(mesh: fd.Mesh, velocity_space, pressure_space, dpp_params:
     returned as ``[n, dim]`` arrays, pressures as ``Function``s."""
     ex = exact_expressions if mesh.dim == 2 else exact_expressions_3d
     u1, p1, u2, p2 = ex(mesh, dpp_params)
-    X = mesh.node_coordinates()
+    X = mesh.local_node_coordinates()
     return (u1(X), fd.Function(pressure_space, p1(X), name="p1_exact"),
             u2(X), fd.Function(pressure_space, p2(X), name="p2_exact"))

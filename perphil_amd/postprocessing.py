@@ -35,6 +35,9 @@ def calculate_darcy_velocity_from_pressure(pressure_field: fd.Function, conducti
     Coefficients are node-major: ``u.vector().reshape(-1, dim)[node]`` is the velocity at a vertex.
     """
     mesh = pressure_field.function_space().mesh()
+    if mesh.distributed:
+        pressure_field = pressure_field.gather()      # (collective) the projection runs on the serial twin of the mesh
+        mesh, velocity_space = pressure_field.function_space().mesh(), None
     if velocity_space is None:
         velocity_space = fd.VectorFunctionSpace(mesh, "CG", degree)
     if velocity_space.degree != 1 or velocity_space.mesh() is not mesh:
@@ -61,6 +64,12 @@ def _norms(numerical: fd.Function, exact_expr, quadrature_points: int):
     `.grad(X) -> [m, dim]` attribute; central differences otherwise), a CG-1 `Function` on the same mesh, or a
     `Constant` / number."""
     mesh = numerical.function_space().mesh()
+    if mesh.distributed:
+        # post-processing is not on the sharded path: the whole function on the serial twin of the mesh (collective)
+        numerical = numerical.gather()
+        if isinstance(exact_expr, fd.Function):
+            exact_expr = exact_expr.gather()
+        mesh = numerical.function_space().mesh()
     ctx = mesh.context()
     if isinstance(exact_expr, MMSPressure):
         if exact_expr.dim != mesh.dim:

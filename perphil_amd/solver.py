@@ -27,7 +27,7 @@ snes_type ngs | nrichardson             block Picard (fixed-stress) sweeps per d
 from __future__ import annotations
 
 import warnings
-from typing import Dict, List, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import attr
 import numpy as np
@@ -41,11 +41,18 @@ _DIRECT_RTOL = 1e-13
 
 @attr.define(frozen=True)
 class Solution:
-    """Result of a solve (reference solver.py:14-27) + ``info`` with what actually ran."""
+    """Result of a solve (reference solver.py:14-27) + ``info`` with what actually ran.  On a distributed mesh
+    ``solution`` holds this rank's slab (``solution.owned()``: its owned rows); ``gather()`` returns the same result
+    with the whole function on every rank."""
     solution: fd.Function | Tuple[fd.Function, fd.Function]
     iteration_number: int
     residual_error: float | np.float64
     info: dict = attr.field(factory=dict, eq=False)
+
+    def gather(self) -> "Solution":
+        sol = self.solution
+        g = tuple(f.gather() for f in sol) if isinstance(sol, tuple) else sol.gather()
+        return Solution(g, self.iteration_number, self.residual_error, self.info)
 
 
 def _sub_options(params: Dict, idx: int) -> Dict:
@@ -186,10 +193,32 @@ def _apply_bcs(ctx: _ffi.Context, W, bcs: List[fd.DirichletBC]) -> None:
             ctx.set_dirichlet(f, nodes, vals)
 
 
-def _run(W, model_params: DPPParameters, bcs, solver_parameters: Dict, nonlinear: bool, device: int = 0) -> Solution:
+_warned_direct = False
+
+
+def _run(W, model_params: DPPParameters, bcs, solver_parameters: Dict, nonlinear: bool,
+         device: Optional[int] = None) -> Solution:
+    global _warned_direct
     cfg, info = translate_options(solver_parameters, nonlinear=nonlinear)
     mesh = W.mesh()
+    # this rank's slab + its transport when the mesh is distributed (fd.Mesh); the solver loops are the same
     ctx = mesh.context(device)
+    if mesh.distributed:
+        if cfg.pc_type == _ffi.PC_ILU or (cfg.inner_pc_type == _ffi.PC_ILU and cfg.pc_type == _ffi.PC_FIELDSPLIT):
+            raise NotImplementedError("pc_type ilu is a sequential-elimination preconditioner: not available on a "
+                                      "distributed mesh (use fd.UnitCubeMesh(..., comm=fd.COMM_SELF) or another pc_type)")
+        tr = mesh.transport
+        info["distributed"] = {"rank": mesh.slab.rank, "world": mesh.slab.world, "transport": tr.label,
+                               "rccl_error": tr.rccl_error, "owned_planes": [mesh.slab.owned_planes.start,
+                                                                             mesh.slab.owned_planes.stop]}
+    elif mesh.replicated_because:
+        info["replicated"] = mesh.replicated_because
+    if info.get("direct_equivalent") and not _warned_direct:
+        # an unsupported algorithm never SILENTLY becomes another one - once per process, audibly
+        _warned_direct = True
+        warnings.warn("ksp_type preonly + pc_type lu (MUMPS) runs as a direct-EQUIVALENT solve on the GPU: field-split GMRES "
+                      "with multigrid-CG block solves to 1e-13; iteration_number 1 / residual 0.0 are reported as PETSc's "
+                      "preonly does (see Solution.info['notes'])", stacklevel=3)
     _apply_bcs(ctx, W, bcs)
     need_mono = not cfg.picard
     ctx.assemble(float(model_params.k1), float(model_params.k2), float(model_params.beta), float(model_params.mu),

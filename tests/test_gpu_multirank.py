@@ -46,6 +46,58 @@ def test_slab_runs_match_single_context(world, cells, kind, pc, solver):
     assert line and "max rel diff" in line[0]
 
 
+def _run_api_check(world, extra, timeout=280):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "tools", "api_slab_check.py"), "--backend", "gloo"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    line = [l for l in r.stdout.splitlines() if l.startswith("world=")]
+    assert r.returncode == 0 and line and "api parity: ok" in line[0], (line, r.stdout[-3000:], r.stderr[-3000:])
+    return r.stdout
+
+
+@pytest.mark.parametrize("world,cells,kind,params,nonlinear", [
+    # the slabs BEHIND solve_dpp / solve_dpp_nonlinear - hexahedra and tetrahedra, three and more option
+    # dictionaries, boxes with nx != ny != nz and slabs of unequal thickness
+    (2, (16, 16, 16), "hex", "PICARD_MG_SOLVER_PARAMS", True),
+    (4, (16, 16, 16), "hex", "PICARD_MG_INEXACT_SOLVER_PARAMS", True),
+    (2, (16, 16, 16), "tet", "PICARD_MG_SOLVER_PARAMS", True),
+    (4, (12, 10, 18), "tet", "PICARD_MG_INEXACT_SOLVER_PARAMS", True),
+    (2, (16, 16, 16), "hex", "FIELDSPLIT_MG_PARAMS", False),
+    (4, (16, 16, 16), "tet", "FIELDSPLIT_MG_PARAMS", False),
+    (2, (12, 16, 20), "hex", "FIELDSPLIT_LU_PARAMS", False),       # the reference's dictionary: GMRES + field-split, LU blocks
+    (2, (8, 8, 8), "hex", "CG_BLOCK_JACOBI_PARAMS", False),
+    (4, (8, 8, 8), "tet", "GMRES_JACOBI_PARAMS", False),
+    (2, (8, 8, 8), "hex", "LINEAR_SOLVER_PARAMS", False),          # preonly + lu: the direct-equivalent solve
+    (3, (10, 9, 20), "hex", "PICARD_JACOBI_SOLVER_PARAMS", True),
+    (2, (16, 16, 0), "quad", "FIELDSPLIT_LU_PARAMS", False),       # 2D: replicated on every rank
+])
+def test_public_api_on_slabs_matches_single_context(world, cells, kind, params, nonlinear):
+    """solve_dpp / solve_dpp_nonlinear called on every rank of a process group exactly as a single process calls them
+    (reference src/perphil/solvers/solver.py:30-76): equal to the COMM_SELF solve of the same objects."""
+    extra = ["--cells"] + [str(c) for c in cells] + ["--kind", kind, "--params", params] + (["--nonlinear"] if nonlinear else [])
+    _run_api_check(world, extra)
+
+
+def test_public_api_on_slabs_with_plain_boundary_data():
+    """Constant and global nodal-array Dirichlet data (no manufactured solution) through the slab path."""
+    _run_api_check(2, ["--cells", "10", "12", "16", "--kind", "hex", "--params", "PICARD_MG_SOLVER_PARAMS", "--nonlinear",
+                       "--constant-bc"])
+
+
+def test_rccl_start_up_failure_continues_on_labelled_callbacks():
+    """a failing RCCL start-up (injected) moves every rank to the torch.distributed callbacks, the
+    result is right and says which transport carried it; PERPHIL_STRICT_RCCL=1 keeps the old behaviour (raise)."""
+    out = _run_api_check(2, ["--cells", "16", "16", "16", "--params", "PICARD_MG_INEXACT_SOLVER_PARAMS", "--nonlinear",
+                             "--inject-rccl-failure"])
+    assert "continuing on the torch.distributed callbacks" in out
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "api_slab_check.py"), "--backend", "gloo",
+           "--params", "PICARD_MG_INEXACT_SOLVER_PARAMS", "--nonlinear", "--inject-rccl-failure"]
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, PERPHIL_STRICT_RCCL="1"), capture_output=True, text=True, timeout=280)
+    assert r.returncode != 0 and "RCCL transport unavailable" in (r.stdout + r.stderr)
+
+
 def test_split_products_stay_inside_one_partial_sum_area():
     """a product launched as interior + two boundary row ranges lays its per-workgroup partial sums
     back to back in ONE reduction slot's area; more of them than the area holds would alias the next slot (mode 7 keeps

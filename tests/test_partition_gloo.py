@@ -150,3 +150,88 @@ def test_partition_invariants():
         assert planes == list(range(nz + 1))   # every node plane owned exactly once
     with pytest.raises(ValueError):
         make_slab(4, 4, 7, 4, 0)     # fewer than 2 cell layers per rank
+
+
+def _api_worker(rank, world, port, out):
+    """Host side of the rank-aware public API (no GPU): under an initialised group fd.UnitCubeMesh is this rank's slab,
+    DirichletBC data are evaluated on the slab's boundary nodes, Functions hold local vectors and gather() restores the
+    global one; 2D and COMM_SELF meshes stay whole."""
+    sys.path.insert(0, ROOT)
+    import torch  # noqa: F401
+    import torch.distributed as dist
+
+    import perphil_amd as pa
+    from perphil_amd import fd
+    from perphil_amd.partition import make_slab
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    ok = True
+    nx, ny, nz = 5, 4, 9
+    mesh = fd.UnitCubeMesh(nx, ny, nz, hexahedral=True)
+    s = make_slab(nx, ny, nz, world, rank)
+    ok &= mesh.distributed and mesh.slab == s and mesh.num_local_vertices() == s.n_local
+    ok &= mesh.num_vertices() == (nx + 1) * (ny + 1) * (nz + 1)
+    V = fd.FunctionSpace(mesh, "CG", 1)
+    W = V * V
+    ok &= W.dim() == 2 * mesh.num_vertices() and W.local_dim() == 2 * s.n_local
+    params = pa.DPPParameters()
+    _, p1, _, p2 = pa.exact_expressions_3d(mesh, params)
+    whole = fd.UnitCubeMesh(nx, ny, nz, hexahedral=True, comm=fd.COMM_SELF)
+    ok &= (not whole.distributed) and whole.num_local_vertices() == whole.num_vertices()
+    gb = whole.boundary_nodes()
+    gv = p1(whole.node_coordinates(gb))
+    nodes, vals = fd.DirichletBC(W.sub(0), p1, "on_boundary").nodes_and_values()
+    gl = mesh.local_to_global(nodes)
+    lookup = dict(zip(gb.tolist(), gv.tolist()))
+    ok &= all(g in lookup for g in gl.tolist()) and np.array_equal(vals, np.array([lookup[g] for g in gl.tolist()]))
+    # every global boundary node inside this rank's box is among the local ones (ghost planes included)
+    lo, hi = s.z_begin * s.plane, (s.z_begin + s.local_planes) * s.plane
+    ok &= np.array_equal(np.sort(gl), gb[(gb >= lo) & (gb < hi)])
+    # a global nodal array and a Constant as data
+    arr = np.arange(mesh.num_vertices(), dtype=np.float64)
+    n2, v2 = fd.DirichletBC(W.sub(1), arr, "on_boundary").nodes_and_values()
+    ok &= np.array_equal(v2, arr[mesh.local_to_global(n2)])
+    _, v3 = fd.DirichletBC(W.sub(1), fd.Constant(3.0), "on_boundary").nodes_and_values()
+    ok &= bool(np.all(v3 == 3.0))
+    # a Function interpolated locally gathers to the globally interpolated one
+    f = fd.Function(W)
+    f.sub(0).interpolate(p1)
+    f.sub(1).interpolate(lambda X: X[:, 0] + 10.0 * X[:, 2])
+    g = f.gather()
+    Xg = whole.node_coordinates()
+    ok &= g.function_space().mesh() is mesh.serial_twin() and not g.function_space().mesh().distributed
+    ok &= np.array_equal(g.sub(0).vector(), p1(Xg)) and np.array_equal(g.sub(1).vector(), Xg[:, 0] + 10.0 * Xg[:, 2])
+    ok &= f.owned().shape == (2 * len(s.owned_planes) * s.plane,)
+    ok &= abs(f.sub(1).at((0.2, 0.5, 1.0)) - (0.2 + 10.0)) < 1e-14
+    # the cache of evaluated boundary data follows the datum's parameters (ADVICE r3)
+    bc = fd.DirichletBC(W.sub(0), p1, "on_boundary")
+    a = bc.nodes_and_values()[1]
+    ok &= bc.nodes_and_values()[1] is a
+    _, q1, _, _ = pa.exact_expressions_3d(mesh, pa.DPPParameters(k1=2.0))
+    bc.value = q1
+    ok &= not np.array_equal(bc.nodes_and_values()[1], a)
+    # 2D meshes and meshes with too few layers are replicated
+    m2 = fd.UnitSquareMesh(8, 8, quadrilateral=True)
+    ok &= (not m2.distributed) and m2.replicated_because is not None
+    m3 = fd.UnitCubeMesh(4, 4, 2 * world - 1)
+    ok &= (not m3.distributed) and "fewer than 2" in m3.replicated_because
+    out.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_public_api_objects_on_a_distributed_mesh(world):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_api_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(res)
