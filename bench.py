@@ -72,21 +72,22 @@ def _mms_boundary_np(N, k1, k2, beta, mu):
     return idx[on], g1, g2
 
 
-def _cpu_port_run(N, threads, k1, k2, beta, mu, smooth, reduction, inner_rtol, inner_norm, keep=None):
+def _cpu_port_run(N, threads, k1, k2, beta, mu, smooth, reduction, inner_rtol, inner_norm, keep=None, kind=2, steps=2,
+                  rtol=1e-8):
     """One step (assemble + multigrid setup + inexact Picard) of the C/OpenMP restatement; seconds, sweeps, its."""
     from oracle import dpp_cpu as cpu
 
     cpu.set_threads(threads)
-    S = cpu.CpuSystem(3, 2, N, N, N)          # mesh + pattern: outside the timed region, as on the GPU
+    S = cpu.CpuSystem(3, kind, N, N, N)       # mesh + pattern: outside the timed region, as on the GPU
     b, g1, g2 = _mms_boundary_np(N, k1, k2, beta, mu)
     S.set_dirichlet(0, b, g1)
     S.set_dirichlet(1, b, g2)
     # two steps, the second one timed: like the GPU's warm-up step, the first pays for allocation and first touch
-    for _ in range(2):
+    for _ in range(steps):
         t0 = time.perf_counter()
         S.assemble(k1, k2, beta, mu)
         S.mg_setup()
-        x, sweeps, inner, res = S.picard(pc=cpu.PC_MG, inner_rtol=inner_rtol, reduction=reduction, smooth=smooth, rtol=1e-8,
+        x, sweeps, inner, res = S.picard(pc=cpu.PC_MG, inner_rtol=inner_rtol, reduction=reduction, smooth=smooth, rtol=rtol,
                                          atol=1e-12, max_it=100, inner_norm=inner_norm)
         t = time.perf_counter() - t0
     if keep is not None:      # what main() compares the GPU step with (parity_vs_port)
@@ -235,6 +236,146 @@ def api_wall(N, k1, k2, beta, mu):
     return out
 
 
+def bench_configs(_ffi, device, with_cpu, cores):
+    """Driver-timed numbers for the BASELINE.json configurations that fit one GPU besides the headline (VERDICT r3 item
+    6): config 1 (2D 16^2 Q1, LINEAR_SOLVER_PARAMS, through the public API - plumbing), 2 (64^3 Q1 monolithic CSR CG + 2x2
+    block Jacobi), 3 (128^3 Q1 Picard-split, the headline's algorithm), 5 (256^3 P1 Kuhn tets, k1/k2 = 1e4, GMRES + field
+    split with multigrid-CG block solves).  Each entry: workload, ms per assemble + solve step (one warm-up step, then the
+    mean of `reps`), iterations, and parity against the oracle / the C port solving the same problem (rank 0, 1 GPU)."""
+    import perphil_amd as pa
+    from perphil_amd import fd, solver_parameters as spar
+    from perphil_amd.manufactured_solutions import exact_expressions
+
+    out = []
+
+    def timed(ctx, step, reps):
+        step()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            info = step()
+        ctx.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / reps, info
+
+    # ---- config 1: plumbing case through the public API -------------------------------------------------------------
+    params = pa.DPPParameters(k1=1.0, k2=1e-2, beta=1.0, mu=1.0)
+    mesh = pa.create_mesh(16, 16, quadrilateral=True)
+    _, V = pa.create_function_spaces(mesh)
+    W = fd.MixedFunctionSpace((V, V))
+    _, p1, _, p2 = exact_expressions(mesh, params)
+    bcs = [fd.DirichletBC(W.sub(0), p1, "on_boundary"), fd.DirichletBC(W.sub(1), p2, "on_boundary")]
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pa.solve_dpp(W, params, bcs, solver_parameters=spar.LINEAR_SOLVER_PARAMS)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            sol = pa.solve_dpp(W, params, bcs, solver_parameters=spar.LINEAR_SOLVER_PARAMS)
+        ms = 1e3 * (time.perf_counter() - t0) / 5
+    e = {"config": 1, "workload": "2D UnitSquare 16x16 Q1, monolithic linear DPP, manufactured BCs, LINEAR_SOLVER_PARAMS "
+                                  "through solve_dpp (direct-equivalent solve; wall clock of the call, result on the host)",
+         "dofs": int(W.dim()), "ms": round(ms, 3), "iterations": int(sol.iteration_number), "parity": None}
+    if with_cpu:
+        from oracle import dpp_oracle as o
+
+        om = o.build_mesh(2, o.CELL_QUAD, 16, 16, 0)
+        ud = o.solve_direct(o.build_system(om, o.Params(k1=1.0, k2=1e-2, beta=1.0, mu=1.0)))
+        err = float(np.abs(sol.solution.vector() - ud).max() / np.abs(ud).max())
+        e.update(parity=bool(err <= 1e-9), parity_vs="NumPy oracle, sparse direct solve", max_rel_diff=err)
+    mesh.context().close()
+    out.append(e)
+
+    # ---- configs 2, 3, 5 through the C ABI (results stay on the device, like the headline) ---------------------------
+    def cube(N, kind, k2):
+        ctx = _ffi.Context(device)
+        ctx.mesh_build(3, kind, N, N, N)
+        m = fd.UnitCubeMesh(N, N, N, hexahedral=(kind == _ffi.CELL_HEX), comm=fd.COMM_SELF)
+        b = m.boundary_nodes()
+        X = m.node_coordinates(b)
+        _, q1, _, q2 = pa.exact_expressions_3d(m, pa.DPPParameters(k1=1.0, k2=k2, beta=1.0, mu=1.0))
+        ctx.set_dirichlet(0, b, q1(X))
+        ctx.set_dirichlet(1, b, q2(X))
+        return ctx
+
+    def stepper(ctx, cfg, k2, mono):
+        def step():
+            ctx.set_option("invalidate_KM", 1)
+            ctx.assemble(1.0, k2, 1.0, 1.0, monolithic=mono)
+            _, info, _ = ctx.solve(cfg, fetch=False)
+            return info
+        return step
+
+    # config 2
+    ctx = cube(64, _ffi.CELL_HEX, 1e-2)
+    cfg = _ffi.SolverCfg()
+    cfg.ksp_type, cfg.pc_type, cfg.restart, cfg.max_it, cfg.rtol, cfg.atol = _ffi.KSP_CG, _ffi.PC_BLOCK2, 30, 50000, 1e-8, 1e-12
+    cfg.inner_ksp_type, cfg.inner_pc_type, cfg.inner_max_it, cfg.inner_rtol, cfg.inner_atol = _ffi.KSP_CG, _ffi.PC_MG, 500, 1e-10, 1e-300
+    cfg.picard, cfg.mg_smooth = 0, 2
+    ms, info = timed(ctx, stepper(ctx, cfg, 1e-2, True), 3)
+    e = {"config": 2, "workload": "3D UnitCube 64^3 Q1, monolithic linear DPP on the field-major CSR (aij), CG + 2x2 node-block "
+                                  "Jacobi to ksp_rtol 1e-8, assemble + solve",
+         "dofs": int(2 * ctx.n), "ms": round(ms, 3), "iterations": int(info.iterations), "converged": bool(info.converged),
+         "dofs_per_s": round(2 * ctx.n / ms * 1e3, 0), "parity": None}
+    if with_cpu:
+        keep = {}
+        _cpu_port_run(64, cores, 1.0, 1e-2, 1.0, 1.0, 2, 0.0, 1e-12, 0, keep, steps=1, rtol=1e-11)
+        x = ctx.solution()
+        err = float(np.abs(x - keep["x"]).max() / np.abs(keep["x"]).max())
+        e.update(parity=bool(info.converged and err <= 1e-6), parity_vs="C/OpenMP port, block Picard run to 1e-11 (same fixed point)",
+                 max_rel_diff=err)
+    ctx.close()
+    out.append(e)
+
+    # config 3
+    ctx = cube(128, _ffi.CELL_HEX, 1e-2)
+    cfg = picard_cfg(_ffi, 1e-10, 1, 1e-1, 1)
+    ms, info = timed(ctx, stepper(ctx, cfg, 1e-2, False), 3)
+    e = {"config": 3, "workload": "3D UnitCube 128^3 Q1, Picard-split (fixed-stress) solve, the headline's algorithm (inexact sweeps, "
+                                  "CG + multigrid V(1,1) block solves), assemble + solve",
+         "dofs": int(2 * ctx.n), "ms": round(ms, 3), "iterations": int(info.iterations), "inner_cg_iterations": int(info.inner_iterations),
+         "converged": bool(info.converged), "dofs_per_s": round(2 * ctx.n / ms * 1e3, 0), "parity": None}
+    if with_cpu:
+        keep = {}
+        _cpu_port_run(128, cores, 1.0, 1e-2, 1.0, 1.0, 1, 1e-1, 1e-10, 1, keep, steps=1)
+        pv = parity_vs_port(ctx.solution(), info, keep)
+        e.update(parity=bool(pv["ok"]), parity_vs="C/OpenMP port, same algorithm: sweeps / iterations equal, solution 1e-9",
+                 max_rel_diff=pv["solution_max_abs_diff_over_max_abs"], sweeps=pv["sweeps"], inner=pv["inner_cg_iterations"])
+    ctx.close()
+    out.append(e)
+
+    # config 5
+    ctx = cube(256, _ffi.CELL_TET, 1e-4)
+    cfg = config5_cfg(_ffi)
+    ms, info = timed(ctx, stepper(ctx, cfg, 1e-4, True), 2)
+    e = {"config": 5, "workload": "3D UnitCube 256^3 P1 Kuhn tetrahedra (100.7 M cells), k1/k2 = 1e4, GMRES(30) + multiplicative "
+                                  "field-split to ksp_rtol 1e-8, block solves CG + multigrid V(1,1) to 1e-10, assemble + solve",
+         "dofs": int(2 * ctx.n), "ms": round(ms, 3), "iterations": int(info.iterations), "inner_cg_iterations": int(info.inner_iterations),
+         "converged": bool(info.converged), "dofs_per_s": round(2 * ctx.n / ms * 1e3, 0), "parity": None}
+    if with_cpu:
+        keep = {}
+        tp = _cpu_port_run(256, cores, 1.0, 1e-4, 1.0, 1.0, 1, 1e-1, 1e-10, 1, keep, kind=3, steps=1, rtol=1e-10)[0]
+        x = ctx.solution()
+        err = float(np.abs(x - keep["x"]).max() / np.abs(keep["x"]).max())
+        e.update(parity=bool(info.converged and int(info.iterations) == 4 and err <= 1e-6),
+                 parity_vs="C/OpenMP port on the same tetrahedral problem, block Picard to 1e-10 (same fixed point); 4 outer "
+                           "iterations = the reference's count at every size (petsc_perf_breakdown_3d.csv, Scale-Splitting GMRES)",
+                 max_rel_diff=err, port_seconds=round(tp, 2))
+    ctx.close()
+    out.append(e)
+    return out
+
+
+def config5_cfg(_ffi):
+    """BASELINE config 5: GMRES(30) + multiplicative field-split (reference src/perphil/solvers/parameters.py:30-37 with
+    GMRES_PARAMS, experiments/petsc_profiling_3d.py:31 for the tetrahedra); block LU -> CG + multigrid to 1e-10."""
+    cfg = _ffi.SolverCfg()
+    cfg.ksp_type, cfg.pc_type, cfg.restart, cfg.max_it, cfg.rtol, cfg.atol = _ffi.KSP_GMRES, _ffi.PC_FIELDSPLIT, 30, 200, 1e-8, 1e-12
+    cfg.inner_ksp_type, cfg.inner_pc_type, cfg.inner_max_it, cfg.inner_rtol, cfg.inner_atol = _ffi.KSP_CG, _ffi.PC_MG, 500, 1e-10, 1e-300
+    cfg.picard, cfg.picard_rtol, cfg.picard_atol, cfg.picard_max_it, cfg.mg_smooth = 0, 1e-8, 1e-12, 100, 1
+    cfg.inner_reduction, cfg.inner_norm = 0.0, 0
+    return cfg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -257,13 +398,20 @@ def main():
                     help="extra pph_set_option settings for A/B runs (e.g. spmv_kernel=8)")
     ap.add_argument("--skip-fine-bench", action="store_true", help="omit the isolated fine-level SpMV loop (PMC passes)")
     ap.add_argument("--skip-csr", action="store_true", help="omit the extra untimed step on the CSR operator format")
-    ap.add_argument("--halo-overlap", type=int, default=0, choices=(0, 1, 2),
+    ap.add_argument("--halo-overlap", type=int, default=1, choices=(0, 1, 2),
                     help="N > 1: products of large levels as interior + boundary launches with the halo exchange of the "
-                         "operand on a second stream behind the interior rows (1), or the same launches serially (2); "
-                         "default 0: exchange, then one launch (the RCCL neighbour exchange has not run on hardware yet)")
-    ap.add_argument("--allow-fallback", action="store_true",
-                    help="N > 1: continue on the torch.distributed callback transport when the RCCL transport fails its "
-                         "self-test (default: exit non-zero - no silent downgrade of a scaling run)")
+                         "operand on a second stream behind the interior rows (1, default: bit-identical to 2 in the gloo "
+                         "tests), the same launches serially (2), or exchange, then one launch (0)")
+    ap.add_argument("--strict", action="store_true",
+                    help="N > 1: exit non-zero when the library's RCCL transport fails to start (default: continue on the "
+                         "torch.distributed callbacks - still RCCL on the device with the nccl backend - and say so in the "
+                         "line: config.transport 'torch-nccl', config.rccl_native_error)")
+    ap.add_argument("--allow-fallback", action="store_true", help="(the default since round 4; kept for old command lines)")
+    ap.add_argument("--config", type=int, default=4, choices=(4, 5),
+                    help="BASELINE.json configuration: 4 (default; = 3 at --cells 128) Q1 hexahedra, Picard-split - the headline "
+                         "metric; 5: P1 Kuhn tetrahedra, k1/k2 = 1e4, GMRES + field-split - on --gpus N slabs either way")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="omit the timed runs of the other single-GPU BASELINE configurations (1, 2, 3, 5; 'configs' in the line)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -295,7 +443,10 @@ def main():
         else:
             dist.init_process_group(backend=backend)
     N = args.cells
-    k1, k2, beta, mu = 1.0, 1e-2, 1.0, 1.0
+    c5 = args.config == 5
+    k1, k2, beta, mu = 1.0, (1e-4 if c5 else 1e-2), 1.0, 1.0
+    kind = _ffi.CELL_TET if c5 else _ffi.CELL_HEX
+    rccl_error = None
 
     transport, ranks_seen = "none", 1
     # HIP runtime start-up (the first HIP call of the process) + context: a per-process cost, reported apart from the
@@ -309,11 +460,16 @@ def main():
     if world > 1:
         from perphil_amd.distributed import SlabSolver
 
-        # raises (non-zero exit) when the RCCL transport was asked for and failed, unless --allow-fallback
+        # the reference's objects under the process group: fd.UnitCubeMesh = this rank's slab + its transport.  A failing
+        # RCCL start-up continues on the torch.distributed callbacks and is labelled (--strict: exit non-zero instead)
         solver = SlabSolver(N, world, rank, device, k1, k2, beta, mu, inner_rtol=args.inner_rtol, smooth=args.smooth,
-                            inner_reduction=args.inner_reduction, inner_norm=args.inner_norm,
-                            allow_fallback=args.allow_fallback)
+                            inner_reduction=args.inner_reduction, inner_norm=args.inner_norm, kind=kind,
+                            strict=True if args.strict else None)
         transport, ranks_seen = solver.transport_label, solver.ranks_seen
+        rccl_error = solver.transport_info.rccl_error
+        if c5:
+            solver.cfg = config5_cfg(_ffi)
+            solver.monolithic = True
         solver.ctx.set_option("asm_kernel", args.asm_kernel)
         solver.ctx.set_option("halo_overlap", args.halo_overlap)
         for kv in args.set:
@@ -323,11 +479,12 @@ def main():
         ctx = solver.ctx
     else:
         ctx = _ffi.Context(device)
-        ctx.mesh_build(3, _ffi.CELL_HEX, N, N, N)
+        ctx.mesh_build(3, kind, N, N, N)
         b, g1, g2 = mms_boundary(N, k1, k2, beta, mu)
         ctx.set_dirichlet(0, b, g1)
         ctx.set_dirichlet(1, b, g2)
-        cfg = picard_cfg(_ffi, args.inner_rtol, args.smooth, args.inner_reduction, args.inner_norm, args.inner_max_it)
+        cfg = (config5_cfg(_ffi) if c5 else
+               picard_cfg(_ffi, args.inner_rtol, args.smooth, args.inner_reduction, args.inner_norm, args.inner_max_it))
         ctx.set_option("asm_kernel", args.asm_kernel)
         for kv in args.set:
             ctx.set_option(kv.split("=")[0], float(kv.split("=")[1]))
@@ -336,7 +493,7 @@ def main():
 
         def step():
             ctx.set_option("invalidate_KM", 1)          # integrate K and M again: assembly is part of the step
-            ctx.assemble(k1, k2, beta, mu, monolithic=False)
+            ctx.assemble(k1, k2, beta, mu, monolithic=c5)
             _, info, _ = ctx.solve(cfg, fetch=False)
             last["info"] = info
             return info
@@ -406,7 +563,9 @@ def main():
     tr, launches, ms, byts = instrumented_step()
     achieved = (byts / 1e9) / (ms / 1e3) if ms > 0 else 0.0
     sym = bool(ctx.timers().get("symmetric_storage", False))   # what the last assembly actually stored
-    S = 14 if sym else 27        # stored slots per row: diagonal + upper half of the 27-point stencil, or all of it
+    SF = 15 if c5 else 27        # stencil: 27-point (Q1 hexahedra) / 15-point (P1 Kuhn tetrahedra)
+    S = SF // 2 + 1 if sym else SF   # stored slots per row: diagonal + upper half of the stencil, or all of it
+    extra_records = not args.skip_csr and not c5   # the stored-value / full-storage / CSR records belong to the headline config
     # row dictionaries (option sell_dict, default): the products of the fine blocks stream a 2-byte class per row
     # instead of the S stored values (pph_get_timers: operators on a dictionary, distinct rows of A11)
     dict_ops, dict_classes = int(tr.get("dict_operators", 0)), int(tr.get("dict_classes", 0))
@@ -423,7 +582,7 @@ def main():
     # file is stamped with the kernel and the launch count it was taken on: anything else reports null.
     traffic = None
     pmc_file = os.path.join(ROOT, "profiles", "r03_pmc_spmv_dict_bench256.json" if dicton else "r03_pmc_spmv_bench256.json")
-    if os.path.exists(pmc_file) and N == 256 and world == 1 and sell:
+    if os.path.exists(pmc_file) and N == 256 and world == 1 and sell and not c5:
         try:
             with open(pmc_file) as f:
                 pmc = json.load(f)
@@ -435,7 +594,10 @@ def main():
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-        "kernel": ((f"k_spmv_dict_walk<mode> (stencil-ELL SpMV on row dictionaries: {dict_classes} distinct rows of A11 in LDS, a "
+        "kernel": ((f"k_spmv_sell<tet,mode,2,sym,DICT> (15-point stencil-ELL SpMV on row dictionaries: {dict_classes} distinct rows of "
+                    "A11 in LDS, a 2-byte class per row instead of the 8 stored values; field-split block solves; the monolithic "
+                    "GMRES products run k_spmv_wide on the field-major CSR and are not in this figure)") if (dicton and c5) else
+                   (f"k_spmv_dict_walk<mode> (stencil-ELL SpMV on row dictionaries: {dict_classes} distinct rows of A11 in LDS, a "
                     "2-byte class per row instead of the 14 stored values, x window of three planes in registers; operators "
                     "below 1 M rows - the coarse multigrid levels - k_spmv_sell on their stored values; all multigrid "
                     "levels of one step)")
@@ -451,7 +613,7 @@ def main():
         "fine_level": fine_block(sell_bytes if sell else csr_bytes),
         "fine_level_in_solver": in_solver(tr),
     }
-    if dicton and not args.skip_csr:
+    if dicton and extra_records:
         # the same step with the products on the STORED values (symmetric stencil-ELL, the dominant kernel of rounds 2-3
         # and the path of every mesh whose rows do not repeat): untimed, for the record
         ctx.set_option("sell_dict", 0)
@@ -469,7 +631,7 @@ def main():
                                      "fine_level": fine_block(stored_bytes), "fine_level_in_solver": in_solver(tv)}
         ctx.set_option("sell_dict", 1)
         step()                                   # (the dictionaries are rebuilt by the next assembly)
-    if sell and sym and not args.skip_csr:
+    if sell and sym and extra_records:
         # the same step on full (27-slot) stencil-ELL storage: untimed, for the record
         ctx.set_option("sell_sym", 0)
         step()
@@ -479,13 +641,13 @@ def main():
         ctx.synchronize()
         full_ms = 1e3 * (time.perf_counter() - t0f)
         af = (bf / 1e9) / (msf / 1e3) if msf > 0 else 0.0
-        full_bytes = 8.0 * 27 * ctx.n + 16.0 * ctx.n
+        full_bytes = 8.0 * SF * ctx.n + 16.0 * ctx.n
         roofline["full_storage"] = {"kernel": "k_spmv_sell<kind,mode,2,full> (all 27 slot arrays)", "achieved": round(af, 1),
                                     "frac": round(af / HBM_PEAK_GBS, 4), "launches_per_step": int(lf),
                                     "algorithmic_bytes_per_launch": round(bf / max(lf, 1), 0), "ms_per_step": round(full_ms, 3),
                                     "fine_level": fine_block(full_bytes), "fine_level_in_solver": in_solver(tf)}
         ctx.set_option("sell_sym", 1)
-    if sell and not args.skip_csr:
+    if sell and extra_records:
         # the same step on the CSR operator format (the north-star's "CSR SpMV inner loop"): untimed, for the record
         ctx.set_option("op_format", 0)
         step()                                   # re-assembles into CSR arrays, rebuilds the level operators
@@ -501,9 +663,37 @@ def main():
                            "fine_level": fine_block(csr_bytes), "fine_level_in_solver": in_solver(tc)}
         ctx.set_option("op_format", 1)
     cs = ctx.comm_stats()
+    # communication split of one more (untimed) step: every halo exchange / all-reduce bracketed by an event pair on the
+    # stream it runs on (RCCL transport; callback transports: host clock inside the callback), so that a measured scaling
+    # curve can be read: comm_ms (exchange, all-reduce) beside the step's wall time taken the same way
+    comm = None
+    if world > 1:
+        ctx.set_option("time_comm", 1)
+        fence()
+        tq = time.perf_counter()
+        step()
+        ctx.synchronize()
+        step_ms_timed = 1e3 * (time.perf_counter() - tq)
+        ct = ctx.comm_times()
+        ctx.set_option("time_comm", 0)
+        vals = [ct["halo_ms"], ct["allreduce_ms"], step_ms_timed]
+        tv = torch.tensor(vals, dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tv, op=dist.ReduceOp.MAX)
+        halo_ms, ar_ms, step_ms_timed = (float(v) for v in tv.tolist())
+        overlapped = args.halo_overlap == 1 and transport == "rccl"
+        comm = {"halo_ms": round(halo_ms, 3), "allreduce_ms": round(ar_ms, 3),
+                "halo_exchanges_timed": ct["halo_timed"], "allreduces_timed": ct["allreduce_timed"],
+                "step_ms_with_comm_timers": round(step_ms_timed, 3),
+                "kernel_ms": round(step_ms_timed - ar_ms - (0.0 if overlapped else halo_ms), 3),
+                "what": "max over ranks, one extra untimed step; rccl transport: device time between HIP events around each "
+                        "grouped ncclSend/ncclRecv and each ncclAllReduce (an exchange overlapped with interior rows counts "
+                        "its full duration on the communication stream and is NOT subtracted in kernel_ms); callback "
+                        "transports: host time inside the callback; kernel_ms = the step's wall time minus the serial "
+                        "communication = kernels + launch gaps + host round trips"}
 
     out = {
-        "metric": "DoF/s (assemble+solve), 3D UnitCube Q1 DPP, Picard-split",
+        "metric": ("DoF/s (assemble+solve), 3D UnitCube P1 (Kuhn tetrahedra) DPP, k1/k2 = 1e4, GMRES + field-split" if c5 else
+                   "DoF/s (assemble+solve), 3D UnitCube Q1 DPP, Picard-split"),
         "value": dofs_global * args.steps / elapsed,
         "unit": "DoF/s",
         "n_gpus": world,
@@ -516,7 +706,11 @@ def main():
         "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": f"3D UnitCube {N}^3 Q1, two-pressure DPP (k1=1, k2=1e-2, beta=mu=1), manufactured Dirichlet data, "
+            "workload": (f"BASELINE config 5: 3D UnitCube {N}^3 P1 Kuhn tetrahedra ({6 * N ** 3} cells), two-pressure DPP, k1/k2 = 1e4 "
+                         f"(k1=1, k2=1e-4, beta=mu=1), manufactured Dirichlet data, assemble + GMRES(30) with the multiplicative "
+                         f"field-split preconditioner to ksp_rtol 1e-8, block solves = CG + geometric multigrid V(1,1) to 1e-10 "
+                         f"on stencil-ELL scalar blocks, monolithic products on the field-major CSR") if c5 else
+                        f"3D UnitCube {N}^3 Q1, two-pressure DPP (k1=1, k2=1e-2, beta=mu=1), manufactured Dirichlet data, "
                         f"assemble + block Picard (fixed-stress) to snes_rtol 1e-8 (true residual), warm-started block solves = "
                         f"CG + geometric multigrid (Chebyshev-Jacobi V({args.smooth},{args.smooth})) on {'stencil-ELL' if sell else 'CSR'} "
                         f"scalar blocks, each "
@@ -524,29 +718,39 @@ def main():
                            if args.inner_norm == 2 else
                            f"to a reduction of the {'unpreconditioned' if args.inner_norm else 'preconditioned'} residual by "
                            f"{args.inner_reduction:g} (or rtol {args.inner_rtol:g})"),
+            "baseline_config": args.config if (c5 or N == 256) else (3 if N == 128 else None),
             "preallocation": "outside the timed step: HIP runtime start-up + first context of the process (context_ms), mesh "
-                             "+ host-side boundary data + its upload (setup_ms; the CSR pattern is built only on demand) and "
-                             "the first step's buffer / multigrid-hierarchy allocation (cold_step_ms = that first step)",
+                             "+ host-side boundary data + its upload (setup_ms; the CSR pattern is built only on demand) and, "
+                             "inside the first (cold) step (cold_step_ms), the buffer / multigrid-hierarchy allocation and the "
+                             "FIRST BUILD of the row dictionaries (hash build + table + first bitwise check + read-back of the "
+                             "verdict per operator: dict_build_ms for dict_builds operators - a symbolic phase, paid again only "
+                             "when the mesh or a Dirichlet SET changes; the per-step check of every row stays in the timed step)",
+            "dict_build_ms": round(float(tm.get("dict_build_ms", 0.0)), 3), "dict_builds": int(tm.get("dict_builds", 0)),
             "setup_ms": round(setup_ms, 2), "cold_step_ms": None if cold_ms is None else round(cold_ms, 2),
             "context_ms": round(context_ms, 2),
             "operator_format": ((("row dictionary (%d distinct rows) over " % dict_classes) if dicton else "")
                                 + ("stencil-ELL, symmetric storage" if sym else "stencil-ELL")) if sell else "CSR",
-            "transport": transport, "ranks_seen": int(ranks_seen),
+            "transport": transport, "ranks_seen": int(ranks_seen), "rccl_native_error": rccl_error,
+            "comm": comm,
             "allreduces_per_step": int(cs["allreduces"]),
             "halo_overlap": int(args.halo_overlap), "split_products_per_step": int(tm.get("split_products", 0)),
-            "cells": N ** 3, "dofs": int(dofs_global), "parallelism": f"slab{world}" if world > 1 else "single",
-            "picard_sweeps": int(info.iterations), "inner_cg_iterations": int(info.inner_iterations),
-            "picard_ms_per_sweep": round(tm["solve_ms"] / max(int(info.iterations), 1), 3),
+            "cells": (6 if c5 else 1) * N ** 3, "dofs": int(dofs_global), "parallelism": f"slab{world}" if world > 1 else "single",
+            ("gmres_iterations" if c5 else "picard_sweeps"): int(info.iterations), "inner_cg_iterations": int(info.inner_iterations),
+            ("ms_per_outer_iteration" if c5 else "picard_ms_per_sweep"): round(tm["solve_ms"] / max(int(info.iterations), 1), 3),
             "assemble_ms": round(tm["assemble_ms"] + tm["bc_blocks_ms"], 3), "solve_ms": round(tm["solve_ms"], 3),
             "final_residual": float(info.resnorm), "rhs_norm": float(info.rhs_norm),
             "halo_exchanges_per_step": int(cs["halo_exchanges"]),
         },
         "roofline": roofline,
     }
-    if rank == 0 and world == 1 and not args.no_api_wall:
+    if rank == 0 and world == 1 and not args.no_api_wall and not c5:
         out["config"]["api"] = api_wall(N, k1, k2, beta, mu)
     parity_failed = False
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
+    if c5:
+        if rank == 0:
+            out["cpu_baseline"] = None
+            out["parity_vs_port"] = None
+    elif rank == 0 and not args.no_cpu_baseline and world == 1:
         keep = {}
         out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample_n, N), k1, k2, beta, mu, args.smooth, args.inner_reduction,
                                            args.inner_rtol, args.cpu_threads, args.inner_norm, keep)
@@ -564,10 +768,16 @@ def main():
             pv = parity_vs_port(x_gpu, info_timed, keep)
             out["parity_vs_port"] = pv["ok"]
             out["parity"] = pv
-            parity_failed = not pv["ok"]
+            parity_failed = parity_failed or not pv["ok"]
     elif rank == 0:
         out["cpu_baseline"] = None
         out["parity_vs_port"] = None
+    if rank == 0 and world == 1 and not args.no_configs and not c5 and N == 256:
+        # the other BASELINE configurations that fit one GPU, each timed and checked (after the headline: own contexts)
+        ctx.close()
+        cfgs = bench_configs(_ffi, device, not args.no_cpu_baseline, args.cpu_threads if args.cpu_threads > 0 else host_cores())
+        out["configs"] = cfgs
+        parity_failed = parity_failed or any(c.get("parity") is False for c in cfgs)
     if dist is not None:
         dist.barrier()
         ctx.close()  # destroys the library's RCCL communicator before the process group goes away
@@ -575,7 +785,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if parity_failed:
-        raise SystemExit("bench.py: the GPU step and the CPU port disagree (see \"parity\" in the line above)")
+        raise SystemExit("bench.py: the GPU step and the CPU port / oracle disagree (see \"parity\" / \"configs\" in the line above)")
 
 
 if __name__ == "__main__":

@@ -238,6 +238,11 @@ int pph_comm_selftest2(pph_ctx* ctx, int* ranks_seen);
 /* halo exchanges and all-reduces of the last solve, and the sticky communication status: after the first failed
  * exchange / reduction on a context every solve returns PPH_ERR_COMM until the transport is set up again */
 int pph_comm_stats(pph_ctx* ctx, int64_t* halo_exchanges, int64_t* allreduces, int* status);
+/* with option "time_comm" on: summed durations (ms) of the last solve's halo exchanges (out4[0]) and all-reduces (out4[1])
+ * and how many of each were timed (out4[2], out4[3]).  RCCL transport: device time between two HIP events on the issuing
+ * stream (an exchange overlapped with interior rows counts its full duration on the communication stream); callback
+ * transport: host time inside the callback.  Lets a measured scaling curve be split into communication and the rest. */
+int pph_comm_times(pph_ctx* ctx, double* out4);
 
 /* ---- stats ---------------------------------------------------------------------------------
  * replaces: PETSc -log_view event times scraped by reference src/perphil/experiments/petsc_profiling.py:302-447.
@@ -256,7 +261,10 @@ int pph_comm_stats(pph_ctx* ctx, int64_t* halo_exchanges, int64_t* allreduces, i
  * out[17] stencil-ELL operators (fine blocks + multigrid levels) whose products run on a row dictionary (option
  * "sell_dict": distinct rows stored once + a 2-byte class per row; their launches count (2 + 16 + e) nrows bytes),
  * out[18] distinct rows of A11 found by the last build (0: not tried), out[19] its status on the device (1 in use,
- * 0 not built, -1 more distinct rows than the cap, -2 a row failed the bitwise check: plain storage is used). */
+ * 0 not built, -1 more distinct rows than the cap, -2 a row failed the bitwise check: plain storage is used);
+ * out[20] ms spent so far in FIRST builds of row dictionaries (hash build + table + first bitwise check + the read-back of
+ * the verdict; once per operator, mesh and Dirichlet-set pair - a symbolic-phase cost like the pattern of a CSR matrix),
+ * out[21] how many such builds. */
 int pph_get_timers(pph_ctx* ctx, double* out, int n);
 /* tuning / profiling switches (no reference counterpart; defaults in brackets):
  *   "op_format" [1]      operator format of the scalar blocks inside block solves / Picard sweeps: 1 stencil-ELL
@@ -286,6 +294,10 @@ int pph_get_timers(pph_ctx* ctx, double* out, int n);
  *   "coarse_max_it" [500] iteration limit of the coarsest-level Jacobi-CG (reported through inner_failed)
  *   "mg_fp32" [0], "mg_replicate_below" [40000 nodes], "coarse_on_device" [1]   multigrid: fp32 copies of the V-cycle
  *                        operators (CSR only), replication threshold of coarse levels on slabs, coarsest solve on the device
+ *   "mg_replicate_rows_per_rank" [40000], "mg_replicate_cap" [1e6]   slabs: a level is also replicated when its share per
+ *                        rank is at most this many nodes (its kernels are shorter than one halo exchange) and the whole
+ *                        level has at most mg_replicate_cap nodes; 0 restores the global threshold alone
+ *   "time_comm" [0]      1: every halo exchange / all-reduce of a solve is timed (pph_comm_times)
  *   "fetch_spin" [1]     reduction results reach the host through a mapped mirror the host polls; 0: D2H copy + sync
  *   "merge_allreduce" [1] slabs, CG block solves on stencil-ELL operators: the product also sums r.Ap and Ap.Ap, and
  *                        { p.Ap, r.Ap, Ap.Ap, r.r of the previous update } travel in ONE all-reduce; the host forms the next
@@ -293,7 +305,7 @@ int pph_get_timers(pph_ctx* ctx, double* out, int n);
  *   "use_graphs" [1]     launch sequences replayed from captured hipGraphs: ILU(0) sweeps, the launch-only Picard sweeps of
  *                        inner_norm 2, and CG iteration bodies on systems of up to "graph_cg_max_rows" [0] rows (2: always)
  *   "device_scalars" [0] 1: the device-scalar CG branch also over the callback transport (tests)
- *   "halo_overlap" [0]   slabs: products on levels of at least "halo_overlap_min_rows" [200000] rows are launched as
+ *   "halo_overlap" [1]   slabs: products on levels of at least "halo_overlap_min_rows" [200000] rows are launched as
  *                        interior rows + boundary rows; 1: the exchange of the operand's ghost planes runs on a second
  *                        stream while the interior rows are computed, 2: the same launches, exchange first (the two
  *                        give bit-identical results).  The three launches share one reduction slot's partial-sum area:

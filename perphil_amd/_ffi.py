@@ -35,7 +35,7 @@ EXPORTS = [
     "pph_csr_sizes", "pph_get_csr", "pph_get_rhs", "pph_spmv", "pph_spmv_bench",
     "pph_get_timers", "pph_set_option", "pph_comm_set_callbacks",
     "pph_rccl_available", "pph_rccl_unique_id", "pph_comm_init_rccl", "pph_comm_selftest", "pph_comm_selftest2",
-    "pph_comm_stats", "pph_error_norms_mms", "pph_quadrature_points", "pph_error_norms_sampled", "pph_bw_probe",
+    "pph_comm_stats", "pph_comm_times", "pph_error_norms_mms", "pph_quadrature_points", "pph_error_norms_sampled", "pph_bw_probe",
     "pph_darcy_velocity",
 ]
 
@@ -157,6 +157,7 @@ def _load() -> C.CDLL:
         "pph_comm_selftest": ([p], C.c_int),
         "pph_comm_selftest2": ([p, C.POINTER(C.c_int)], C.c_int),
         "pph_comm_stats": ([p, i64p, i64p, C.POINTER(C.c_int)], C.c_int),
+        "pph_comm_times": ([p, f64p], C.c_int),
         "pph_rccl_available": ([C.c_char_p], C.c_int),
         "pph_bw_probe": ([p, C.c_int64, C.c_int, C.c_int, f64p], C.c_int),
         "pph_error_norms_mms": ([p, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, f64p,
@@ -418,9 +419,15 @@ class Context:
         self._check(lib.pph_comm_stats(self._h, C.byref(h), C.byref(a), C.byref(st)))
         return {"halo_exchanges": h.value, "allreduces": a.value, "status": st.value}
 
+    def comm_times(self) -> dict:
+        """Summed durations of the last solve's exchanges / reductions (option time_comm)."""
+        t = (C.c_double * 4)()
+        self._check(lib.pph_comm_times(self._h, t))
+        return {"halo_ms": t[0], "allreduce_ms": t[1], "halo_timed": int(t[2]), "allreduce_timed": int(t[3])}
+
     def timers(self) -> dict:
-        t = np.zeros(20, dtype=np.float64)
-        self._check(lib.pph_get_timers(self._h, _ptr(t), 20))
+        t = np.zeros(22, dtype=np.float64)
+        self._check(lib.pph_get_timers(self._h, _ptr(t), 22))
         return {"mesh_ms": t[0], "assemble_ms": t[1], "bc_blocks_ms": t[2], "solve_ms": t[3],
                 "spmv_ms": t[4], "spmv_launches": int(t[5]), "spmv_bytes": t[6],
                 "spmv_dot_ms": t[7], "spmv_dot_launches": int(t[8]), "spmv_dot_bytes": t[9],
@@ -428,4 +435,5 @@ class Context:
                 "spmv_fine_ms": t[11], "spmv_fine_launches": int(t[12]), "spmv_fine_bytes": t[13],
                 "split_products": int(t[14]), "symmetric_storage": bool(t[15]),
                 "max_split_partials": int(t[16]),
-                "dict_operators": int(t[17]), "dict_classes": int(t[18]), "dict_status": int(t[19])}
+                "dict_operators": int(t[17]), "dict_classes": int(t[18]), "dict_status": int(t[19]),
+                "dict_build_ms": t[20], "dict_builds": int(t[21])}

@@ -112,7 +112,9 @@ int pph_ctx_create(int device, pph_ctx** out) {
   if ((e = hipHostGetDevicePointer((void**)&ctx->h_scal_dev, ctx->h_scal, 0)) != hipSuccess)
     return fail("hipHostGetDevicePointer", e);
   ctx->h_seq = reinterpret_cast<unsigned long long*>(ctx->h_scal + PPH_MAX_SCAL);
+  ctx->dict_alarm = reinterpret_cast<int*>(ctx->h_scal + PPH_MAX_SCAL + 4);   // (the mirror has 8 spare words behind the slots)
   ctx->h_seq_dev = reinterpret_cast<unsigned long long*>(ctx->h_scal_dev + PPH_MAX_SCAL);
+  ctx->dict_alarm_dev = reinterpret_cast<int*>(ctx->h_scal_dev + PPH_MAX_SCAL + 4);
   // reduction results + partial sums (32 slots x 4096 workgroups)
   if (ctx->scal.alloc(ctx, (size_t)PPH_MAX_SCAL + 32 * 4096) < 0) {
     g_last_error = ctx->err;
@@ -563,6 +565,16 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
     mg_release(ctx);
     return PPH_OK;
   }
+  if (!strcmp(name, "mg_replicate_rows_per_rank")) {
+    ctx->mg_replicate_rows_per_rank = (int64_t)value;
+    mg_release(ctx);
+    return PPH_OK;
+  }
+  if (!strcmp(name, "mg_replicate_cap")) {
+    ctx->mg_replicate_cap = (int64_t)value;
+    mg_release(ctx);
+    return PPH_OK;
+  }
   if (!strcmp(name, "mg_fp32")) {
     ctx->mg_fp32 = value != 0.0 ? 1 : 0;
     ctx->mg_ok = false;
@@ -646,6 +658,7 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
     for (SellDict* D : {&ctx->D11, &ctx->D22, &ctx->D12})
       if (D->state.p) PPH_HIP(ctx, hipMemcpyAsync(D->state.p + 1, &bad, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
     PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (value == 2.0 && ctx->dict_alarm) *ctx->dict_alarm = 1;   // ... and raise the word the check kernels raise (sell_dict_poll)
     return PPH_OK;
   }
   if (!strcmp(name, "asm_tile")) { ctx->asm_tile = (value == 2.0) ? 2 : (value != 0.0 ? 1 : 0); return PPH_OK; }
@@ -664,6 +677,7 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
   if (!strcmp(name, "coarse_on_device")) { ctx->coarse_on_device = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "spmv_bench_mode")) { ctx->spmv_bench_mode = (int)value; return PPH_OK; }
   if (!strcmp(name, "time_spmv")) { ctx->time_spmv = value != 0.0; return PPH_OK; }
+  if (!strcmp(name, "time_comm")) { ctx->time_comm = value != 0.0; return PPH_OK; }
   if (!strcmp(name, "invalidate_KM")) {
     // forget the integrated K and M (all multigrid levels) so that the next assemble + solve integrates
     // again (benchmarks); the buffers are kept
@@ -731,13 +745,14 @@ int pph_get_timers(pph_ctx* ctx, double* out, int n) {
     (void)hipMemcpyAsync(dst, ctx->D11.state.p, sizeof(dst), hipMemcpyDeviceToHost, ctx->stream);
     (void)hipStreamSynchronize(ctx->stream);
   }
-  const double v[20] = {ctx->t_mesh, ctx->t_asm, ctx->t_bc, ctx->t_solve,
+  const double v[22] = {ctx->t_mesh, ctx->t_asm, ctx->t_bc, ctx->t_solve,
                         ctx->t_spmv[0], (double)ctx->n_spmv[0], ctx->spmv_bytes[0],
                         ctx->t_spmv[1], (double)ctx->n_spmv[1], ctx->spmv_bytes[1], (double)ctx->n_halo,
                         ctx->t_spmv_fine, (double)ctx->n_spmv_fine, ctx->spmv_bytes_fine, (double)ctx->n_split,
                         (ctx->ell_ok && ctx->S11.sym) ? 1.0 : 0.0, (double)ctx->max_split_partials,
-                        (double)dn, (double)(ctx->D11.tried ? ctx->D11.ncls : 0), (double)(ctx->D11.on ? dst[1] : ctx->D11.status)};
-  for (int i = 0; i < n && i < 20; ++i) out[i] = v[i];
+                        (double)dn, (double)(ctx->D11.tried ? ctx->D11.ncls : 0), (double)(ctx->D11.on ? dst[1] : ctx->D11.status),
+                        ctx->t_dict_build, (double)ctx->n_dict_build};
+  for (int i = 0; i < n && i < 22; ++i) out[i] = v[i];
   return PPH_OK;
 }
 

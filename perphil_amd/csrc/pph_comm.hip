@@ -131,6 +131,34 @@ static int comm_fail(pph_ctx* ctx, const char* what, const char* detail) {
 
 static const char* rccl_errstr(int r) { return g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?"; }
 
+// option "time_comm": an event pair around every exchange / reduction on the stream it is issued on (harvested with
+// the SpMV pairs by la_harvest_spmv_times: variant 2 = halo exchange, 3 = all-reduce); the callback transport is
+// timed with the host clock around the callback (its stream is idle then)
+#include <chrono>
+static pph_ctx::EvPair* comm_ev_begin(pph_ctx* ctx, int variant, hipStream_t on) {
+  if (!ctx->time_comm) return nullptr;
+  if (ctx->ev_used == ctx->ev_pool.size()) {
+    pph_ctx::EvPair p;
+    p.variant = 0; p.fine = false;
+    if (hipEventCreate(&p.e0) == hipSuccess && hipEventCreate(&p.e1) == hipSuccess) ctx->ev_pool.push_back(p);
+  }
+  if (ctx->ev_used >= ctx->ev_pool.size()) return nullptr;
+  pph_ctx::EvPair* ev = &ctx->ev_pool[ctx->ev_used++];
+  ev->variant = variant; ev->fine = false;
+  (void)hipEventRecord(ev->e0, on);
+  return ev;
+}
+static void comm_ev_end(pph_ctx::EvPair* ev, hipStream_t on) { if (ev) (void)hipEventRecord(ev->e1, on); }
+struct HostClock {
+  pph_ctx* ctx; int which; std::chrono::steady_clock::time_point t0;
+  HostClock(pph_ctx* c, int w) : ctx(c), which(w), t0(std::chrono::steady_clock::now()) {}
+  ~HostClock() {
+    if (!ctx->time_comm) return;
+    ctx->t_comm[which] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    ctx->n_comm_timed[which]++;
+  }
+};
+
 // `on` (default: the context's stream): stream the RCCL exchange is issued on.  `x_ready` (callback transport): the
 // event after which v holds the planes to send - waited for instead of the whole stream, which may already carry
 // the interior rows of the product that consumes v (halo_overlap, pph_la.hip)
@@ -142,6 +170,7 @@ int la_halo(pph_ctx* ctx, const MeshData& g, double* v, hipStream_t on, hipEvent
   const int64_t send_lo = g.glo ? pl : -1, recv_lo = g.glo ? 0 : -1;
   const int64_t send_hi = g.ghi ? g.n - 2 * pl : -1, recv_hi = g.ghi ? g.n - pl : -1;
   if (ctx->nccl_comm) {
+    pph_ctx::EvPair* ev = comm_ev_begin(ctx, 2, on);
     // every call of the group is issued and the group is always closed, also after a failed call
     int bad = g_rccl.GroupStart();
     if (g.glo) {
@@ -158,6 +187,7 @@ int la_halo(pph_ctx* ctx, const MeshData& g, double* v, hipStream_t on, hipEvent
     }
     const int re = g_rccl.GroupEnd();
     bad = bad ? bad : re;
+    comm_ev_end(ev, on);
     if (bad) return comm_fail(ctx, "RCCL halo exchange", rccl_errstr(bad));
     ctx->n_halo++;
     return PPH_OK;
@@ -165,6 +195,7 @@ int la_halo(pph_ctx* ctx, const MeshData& g, double* v, hipStream_t on, hipEvent
   if (!ctx->halo_cb) return PPH_OK;
   if ((x_ready ? hipEventSynchronize(x_ready) : hipStreamSynchronize(ctx->stream)) != hipSuccess)
     return comm_fail(ctx, "halo exchange", "synchronisation before the callback");
+  HostClock hc(ctx, 0);
   if (ctx->halo_cb(ctx->comm_user, v, pl, send_lo, recv_lo, send_hi, recv_hi) != 0)
     return comm_fail(ctx, "halo exchange", "callback returned an error");
   ctx->n_halo++;
@@ -177,12 +208,16 @@ int comm_allreduce_device(pph_ctx* ctx, double* dev, int64_t count) {
   if (ctx->comm_status != PPH_OK) return ctx->comm_status;
   ctx->n_allreduce++;
   if (ctx->nccl_comm) {
+    pph_ctx::EvPair* ev = comm_ev_begin(ctx, 3, ctx->stream);
     const int r = g_rccl.AllReduce(dev, dev, (size_t)count, RCCL_DOUBLE, RCCL_SUM, ctx->nccl_comm, ctx->stream);
+    comm_ev_end(ev, ctx->stream);
     if (r) return comm_fail(ctx, "RCCL all-reduce", rccl_errstr(r));
     return PPH_OK;
   }
   if (!ctx->allreduce_cb) return PPH_OK;
   ctx->h_stage.resize((size_t)count);
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return comm_fail(ctx, "all-reduce", "synchronisation before the callback");
+  HostClock hc(ctx, 1);
   if (hipMemcpyAsync(ctx->h_stage.data(), dev, sizeof(double) * (size_t)count, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
       hipStreamSynchronize(ctx->stream) != hipSuccess)
     return comm_fail(ctx, "all-reduce", "device-to-host copy");
@@ -211,6 +246,7 @@ int comm_allreduce_host(pph_ctx* ctx, double* vals, int64_t count) {
   }
   if (!ctx->allreduce_cb) return PPH_OK;
   ctx->n_allreduce++;
+  HostClock hc(ctx, 1);
   if (ctx->allreduce_cb(ctx->comm_user, vals, count) != 0) return comm_fail(ctx, "all-reduce", "callback returned an error");
   return PPH_OK;
 }
@@ -298,6 +334,18 @@ extern "C" int pph_comm_selftest(pph_ctx* ctx) { return pph_comm_selftest2(ctx, 
 
 // communication counters of the last solve (bench.py: config.halo_exchanges_per_step / allreduces_per_step) and the
 // sticky status
+// option "time_comm": summed durations of the last solve's exchanges and reductions (ms) and how many were timed;
+// out[0] halo ms, [1] all-reduce ms, [2] halo exchanges timed, [3] all-reduces timed.  RCCL transport: device time between
+// two events on the issuing stream (an overlapped exchange counts its full duration on the communication stream);
+// callback transport: host time inside the callback (+ staging copies of the reductions)
+extern "C" int pph_comm_times(pph_ctx* ctx, double* out4) {
+  if (!ctx || !out4) return PPH_ERR_INVALID;
+  la_harvest_spmv_times(ctx);
+  out4[0] = ctx->t_comm[0]; out4[1] = ctx->t_comm[1];
+  out4[2] = (double)ctx->n_comm_timed[0]; out4[3] = (double)ctx->n_comm_timed[1];
+  return PPH_OK;
+}
+
 extern "C" int pph_comm_stats(pph_ctx* ctx, int64_t* halo, int64_t* allreduce, int* status) {
   if (!ctx) return PPH_ERR_INVALID;
   if (halo) *halo = ctx->n_halo;

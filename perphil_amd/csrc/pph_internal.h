@@ -270,7 +270,7 @@ struct pph_ctx {
   // are computed; 0 off (one launch after the exchange), 1 overlapped, 2 the same three launches without overlap
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_x = nullptr, ev_h = nullptr;
-  int halo_overlap = 0;
+  int halo_overlap = 1;
   int64_t halo_overlap_min_rows = 200000;
   int64_t n_split = 0;                  // products launched split (statistics)
   int max_split_partials = 0;           // largest total a split product wrote so far (statistics)
@@ -370,6 +370,9 @@ struct pph_ctx {
   double spmv_bytes[2] = {0, 0};
   int64_t n_spmv[2] = {0, 0};
   bool time_spmv = false;
+  bool time_comm = false;               // option "time_comm": every halo exchange / all-reduce bracketed by an event pair on the stream it runs on (callback transport: host clock around the callback)
+  double t_comm[2] = {0, 0};            // [0] halo exchanges, [1] all-reduces: summed durations in ms of the last solve
+  int64_t n_comm_timed[2] = {0, 0};
   struct EvPair { hipEvent_t e0, e1; int variant; bool fine; };
   double t_spmv_fine = 0, spmv_bytes_fine = 0;   // the fine-level launches among t_spmv / spmv_bytes
   int64_t n_spmv_fine = 0;
@@ -388,6 +391,8 @@ struct pph_ctx {
   int coarse_on_device = 1;             // coarsest multigrid level (<= 4096 rows): CG inside one workgroup, no host round trips
   int spmv_bench_mode = 0;              // pph_spmv_bench protocol: 0 back-to-back, 1-3 interleaved (see pph_api.hip)
   int64_t mg_replicate_below = 40000;   // slabs: multigrid levels with at most this many global nodes are replicated
+  int64_t mg_replicate_rows_per_rank = 40000;   // ... and levels with at most this many nodes PER RANK (and at most mg_replicate_cap global nodes): their slab kernels are shorter than one exchange
+  int64_t mg_replicate_cap = 1000000;
   int mg_fp32 = 0;                      // 1: V-cycle SpMVs read fp32 copies of the operator values (8 instead of 12 B per non-zero)
   int asm_kernel = 2;                   // multilinear cells: 2 two-pass (element rows + node gather, default), 1 one-pass node gather, 0 cell-centred atomic scatter-add
   int spmv_kernel = 3;                  // 3: aligned-wide CSR-vector (default); 0,1,2,4..8,10: variants kept for A/B runs
@@ -407,6 +412,10 @@ struct pph_ctx {
   int sell_dict_walk = 1;               // whole-operator dictionary products of hexahedral blocks: x window in registers (k_spmv_dict_walk)
   int sell_dict_cap = PPH_DICT_CAP;     // classes accepted (tests lower it to force the plain path)
   int sell_rpt = 2, sell_blocks = 0, sell_group = 0;   // SELL SpMV tuning: rows per thread, grid cap, XCD chunk group
+  int* dict_alarm = nullptr;            // mapped host word the per-assembly dictionary checks raise on a refusal (sell_dict_poll)
+  int* dict_alarm_dev = nullptr;
+  double t_dict_build = 0;              // ms spent in first builds of row dictionaries (k_dict_build + table + first check + read-back)
+  int n_dict_build = 0;
   DevBuf<double> sell_tmp;              // SELL copy of the matrix last selected by pph_spmv / pph_spmv_bench
   DevBuf<double> post_u;                // nodal field of the last pph_error_norms_sampled call (chunked callers upload it once)
   bool post_u_valid = false;
@@ -540,6 +549,7 @@ static inline double sell_stream_bytes(const pph_ctx* ctx, const Sell& E) {
 }
 // (re)builds the row dictionary of E after its values were (re)written; sets / clears E->dict
 int sell_dict_update(pph_ctx* ctx, Sell* E, SellDict& D, int64_t n);
+int sell_dict_poll(pph_ctx* ctx);   // retires dictionaries a per-assembly check refused on the device (end of a solve)
 int sell_from_csr(pph_ctx* ctx, const MeshData& mesh, const double* csr_val, DevBuf<double>& buf, Sell* out, int sym);
 // symmetric storage is used for operators that are symmetric on the local box: single context (a slab's ghost rows
 // are empty, which breaks the symmetry of the local matrix) and option sell_sym on

@@ -350,10 +350,13 @@ static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const doub
 void la_harvest_spmv_times(pph_ctx* ctx) {
   if (ctx->ev_used == 0) return;
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->comm_stream) (void)hipStreamSynchronize(ctx->comm_stream);
   for (size_t i = 0; i < ctx->ev_used; ++i) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ctx->ev_pool[i].e0, ctx->ev_pool[i].e1) == hipSuccess) {
-      ctx->t_spmv[ctx->ev_pool[i].variant] += ms;
+      const int v = ctx->ev_pool[i].variant;
+      if (v >= 2) { ctx->t_comm[v - 2] += ms; ctx->n_comm_timed[v - 2]++; continue; }   // halo exchange / all-reduce (pph_comm.hip)
+      ctx->t_spmv[v] += ms;
       if (ctx->ev_pool[i].fine) ctx->t_spmv_fine += ms;
     }
   }
@@ -364,6 +367,7 @@ void la_reset_spmv_stats(pph_ctx* ctx) {
   la_harvest_spmv_times(ctx);
   for (int v = 0; v < 2; ++v) { ctx->t_spmv[v] = 0; ctx->spmv_bytes[v] = 0; ctx->n_spmv[v] = 0; }
   ctx->t_spmv_fine = 0; ctx->spmv_bytes_fine = 0; ctx->n_spmv_fine = 0;
+  ctx->t_comm[0] = ctx->t_comm[1] = 0; ctx->n_comm_timed[0] = ctx->n_comm_timed[1] = 0;
 }
 
 

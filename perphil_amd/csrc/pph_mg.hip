@@ -498,11 +498,15 @@ int mg_setup(pph_ctx* ctx) {
     int l = 0;
     while (l + 1 < nlev && (c0 % (2 << l)) == 0 && (c1 % (2 << l)) == 0 && ((c1 - c0) >> (l + 1)) >= 2) ++l;
     // small levels are latency-bound: below `mg_replicate_below` global nodes a level is replicated (one
-    // all-reduce of its right-hand side per cycle) instead of distributed (five halo exchanges per cycle)
+    // all-reduce of its right-hand side per cycle) instead of distributed (five halo exchanges per cycle) - and so is
+    // a level whose share PER RANK is at most `mg_replicate_rows_per_rank` nodes (its slab kernels are shorter than one
+    // exchange: 256^3 on 8 ranks, level 2 = 65^3 = 34 k nodes per rank) while the whole level stays small enough to be
+    // cheap on every rank (`mg_replicate_cap` global nodes)
     int lr = l + 1;
     for (int q = 1; q <= l; ++q) {
       const int64_t gn = (int64_t)((fm.nx >> q) + 1) * ((fm.ny >> q) + 1) * ((fm.nz >> q) + 1);
-      if (gn <= ctx->mg_replicate_below) { lr = q; break; }
+      const bool small_share = gn / ctx->world <= ctx->mg_replicate_rows_per_rank && gn <= ctx->mg_replicate_cap;
+      if (gn <= ctx->mg_replicate_below || small_share) { lr = q; break; }
     }
     PPH_TRY(comm_min_int(ctx, lr, &ndist));
   }

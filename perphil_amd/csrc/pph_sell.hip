@@ -11,6 +11,7 @@
 // Algorithmic bytes per product: 8 S nrows (values, S = stencil size, pad zeros on the box boundary included)
 // + 16 nrows (x read once, y written once).
 #include "pph_internal.h"
+#include <chrono>
 
 __device__ inline double sell_wave_sum(double v) {
 #pragma unroll
@@ -793,7 +794,7 @@ template <int KIND>
 __global__ __launch_bounds__(256) void k_dict_verify_sym(const double* __restrict__ val, int64_t ld, int px, int64_t pxy,
                                                          int64_t n, const uint16_t* __restrict__ map,
                                                          uint16_t* __restrict__ cls, const double* __restrict__ tab,
-                                                         int* state, int lds_classes, int walk) {
+                                                         int* state, int lds_classes, int walk, int* alarm) {
   using ST = SellSt<KIND>;
   constexpr int S = ST::S, C0 = S / 2;
   extern __shared__ double vtab[];
@@ -850,7 +851,12 @@ __global__ __launch_bounds__(256) void k_dict_verify_sym(const double* __restric
       }
     }
   }
-  if (bad) atomicExch(state + 1, -2);
+  if (bad) {
+    atomicExch(state + 1, -2);
+    // the host learns of a refusal on the device without a read-back per operator: one word in mapped host memory, looked
+    // at when a solve ends (sell_dict_poll)
+    if (alarm) __hip_atomic_store(alarm, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 static void dict_launch_verify(pph_ctx* ctx, const Sell& E, SellDict& D, int64_t n, const uint16_t* map, int lds_classes) {
@@ -867,16 +873,16 @@ static void dict_launch_verify(pph_ctx* ctx, const Sell& E, SellDict& D, int64_t
     }
     if (E.kind == PPH_CELL_HEX)
       hipLaunchKernelGGL(k_dict_verify_sym<PPH_CELL_HEX>, dim3(grid), dim3(256), lds, ctx->stream, E.val, E.ld, E.px, pxy, n, map,
-                         D.cls.p, D.tab.p, D.state.p, lds_classes, walk);
+                         D.cls.p, D.tab.p, D.state.p, lds_classes, walk, ctx->dict_alarm_dev);
     else
       hipLaunchKernelGGL(k_dict_verify_sym<PPH_CELL_TET>, dim3(grid), dim3(256), lds, ctx->stream, E.val, E.ld, E.px, pxy, n, map,
-                         D.cls.p, D.tab.p, D.state.p, lds_classes, walk);
+                         D.cls.p, D.tab.p, D.state.p, lds_classes, walk, ctx->dict_alarm_dev);
   } else if (E.kind == PPH_CELL_QUAD) {
     hipLaunchKernelGGL(k_dict_verify_sym<PPH_CELL_QUAD>, dim3(sell_grid(n)), dim3(256), lds, ctx->stream, E.val, E.ld, E.px, pxy, n,
-                       map, D.cls.p, D.tab.p, D.state.p, lds_classes, 0);
+                       map, D.cls.p, D.tab.p, D.state.p, lds_classes, 0, ctx->dict_alarm_dev);
   } else {
     hipLaunchKernelGGL(k_dict_verify_sym<PPH_CELL_TRI>, dim3(sell_grid(n)), dim3(256), lds, ctx->stream, E.val, E.ld, E.px, pxy, n,
-                       map, D.cls.p, D.tab.p, D.state.p, lds_classes, 0);
+                       map, D.cls.p, D.tab.p, D.state.p, lds_classes, 0, ctx->dict_alarm_dev);
   }
 }
 
@@ -886,7 +892,9 @@ int sell_dict_update(pph_ctx* ctx, Sell* E, SellDict& D, int64_t n) {
   if (!want) { D.on = false; return PPH_OK; }
   const bool same = D.val == E->val && D.n == n && D.px == E->px && D.py == E->py && D.bc_epoch == ctx->bc_epoch &&
                     D.cap == ctx->sell_dict_cap;
-  if (same && D.tried && !D.on) return PPH_OK;   // refused for this mesh and these Dirichlet sets: not tried again
+  // refused for this mesh and these Dirichlet sets (too many distinct rows / a failed check): not tried again.  A dictionary
+  // that was only switched OFF (option sell_dict 0, sell_sym 0 or sell_rpt 1 at an assembly in between) is rebuilt.
+  if (same && D.tried && !D.on && D.status < 0) return PPH_OK;
   const Stencil st = make_stencil(E->kind);
   const int64_t pxy = (int64_t)E->px * E->py;
   const int grid = sell_grid(n);
@@ -902,6 +910,8 @@ int sell_dict_update(pph_ctx* ctx, Sell* E, SellDict& D, int64_t n) {
   }
   const bool was_on = D.on;
   const int was_ncls = D.ncls;
+  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));   // (first build only: its cost is reported apart, pph_get_timers out[20])
+  const auto t_build0 = std::chrono::steady_clock::now();
   PPH_TRY(D.cls.alloc(ctx, (size_t)E->ld));
   PPH_TRY(D.keys.alloc(ctx, (size_t)PPH_DICT_HASH));
   PPH_TRY(D.rep.alloc(ctx, (size_t)(PPH_DICT_HASH + PPH_DICT_CAP)));
@@ -920,6 +930,8 @@ int sell_dict_update(pph_ctx* ctx, Sell* E, SellDict& D, int64_t n) {
   int h[2] = {0, 0};
   PPH_HIP(ctx, hipMemcpyAsync(h, D.state.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
   PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->t_dict_build += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
+  ctx->n_dict_build++;
   D.ncls = h[0];
   D.on = h[1] == 1;
   D.status = h[1];
@@ -927,6 +939,39 @@ int sell_dict_update(pph_ctx* ctx, Sell* E, SellDict& D, int64_t n) {
   D.val = E->val; D.n = n; D.px = E->px; D.py = E->py; D.bc_epoch = ctx->bc_epoch; D.cap = ctx->sell_dict_cap;
   if (D.on != was_on || D.ncls != was_ncls) la_release_graphs(ctx);   // captured launches carry the old class count
   if (D.on) E->dict = &D;
+  return PPH_OK;
+}
+
+// A per-assembly check that refused a dictionary ON THE DEVICE (state[1] = -2) makes every product launch take its
+// one-row-at-a-time fallback - correct, but far slower than the plain kernel the refusal is meant to fall back to, and the
+// byte accounting keeps counting 2 B per row.  The check kernels raise one word in mapped host memory; a solve looks at it
+// when it ends (it has synchronised by then) and, if raised, reads the status words back and retires the refused
+// dictionaries on the host as well.
+int sell_dict_poll(pph_ctx* ctx) {
+  if (!ctx->dict_alarm || !*ctx->dict_alarm) return PPH_OK;
+  *ctx->dict_alarm = 0;
+  auto retire = [&](Sell& E, SellDict& D) -> int {
+    if (!D.on || !D.state.p) return PPH_OK;
+    int h[2] = {0, 0};
+    PPH_HIP(ctx, hipMemcpyAsync(h, D.state.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h[1] == 1) return PPH_OK;
+    D.on = false; D.status = h[1];
+    if (E.dict == &D) E.dict = nullptr;
+    return 1;
+  };
+  int n = 0, r;
+  if ((r = retire(ctx->S11, ctx->D11)) < 0) return r; n += r;
+  if ((r = retire(ctx->S22, ctx->D22)) < 0) return r; n += r;
+  if ((r = retire(ctx->S12, ctx->D12)) < 0) return r; n += r;
+  if (ctx->S21.dict && !ctx->D12.on) ctx->S21.dict = nullptr;
+  for (size_t l = 0; l < ctx->mg.size(); ++l)
+    for (int f = 0; f < 2; ++f) {
+      MgLevel& L = ctx->mg[l];
+      if (l == 0) { if (L.ell[f].dict && !L.ell[f].dict->on) L.ell[f].dict = nullptr; continue; }   // level 0 aliases S11 / S22
+      if ((r = retire(L.ell[f], L.dict[f])) < 0) return r; n += r;
+    }
+  if (n) la_release_graphs(ctx);   // captured launches carry the dictionary kernels
   return PPH_OK;
 }
 

@@ -936,6 +936,7 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
   PPH_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
   ctx->t_solve = ms;
   la_harvest_spmv_times(ctx);
+  PPH_TRY(sell_dict_poll(ctx));   // a dictionary refused by its per-assembly check on the device is retired on the host too
   PPH_HIP(ctx, hipGetLastError());
   if (info) *info = inf;
   if (ctx->comm_status != PPH_OK) { ctx->err = ctx->comm_error; return ctx->comm_status; }

@@ -150,18 +150,30 @@ def test_rccl_plumbing_single_rank():
     assert r.returncode == 0 and "rccl selftest ok" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])
 
 
-def test_bench_gpus_2_starts_its_own_ranks():
+@pytest.mark.parametrize("config", [4, 5])
+def test_bench_gpus_2_starts_its_own_ranks(config):
     """`python bench.py --gpus 2` exactly as the driver starts the 1-GPU run (no launcher): bench.py spawns
-    torch.distributed.run itself; gloo rehearsal, both ranks on the one GPU."""
+    torch.distributed.run itself; gloo rehearsal, both ranks on the one GPU.  Both BASELINE multi-GPU configurations have a
+    launcher (4: hexahedra, Picard-split; 5: Kuhn tetrahedra, k1/k2 = 1e4, GMRES + field-split) and the line carries what
+    a measured curve needs to be read: transport, communication counts and event-timed communication beside the step."""
     import json
 
     env = dict(os.environ, PERPHIL_DIST_BACKEND="gloo")
     env.pop("WORLD_SIZE", None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cells", "16", "--steps", "1",
-                        "--warmup", "1", "--no-cpu-baseline", "--skip-fine-bench", "--skip-csr"],
+                        "--warmup", "1", "--no-cpu-baseline", "--skip-fine-bench", "--skip-csr", "--config", str(config)],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=280)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout[-2000:], r.stderr[-2000:])
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["config"]["transport"] == "torch-gloo" and out["config"]["ranks_seen"] == 2
-    assert out["config"]["halo_exchanges_per_step"] > 0 and out["value"] > 0
+    c = out["config"]
+    assert out["n_gpus"] == 2 and c["transport"] == "torch-gloo" and c["ranks_seen"] == 2 and c["rccl_native_error"] is None
+    assert c["halo_exchanges_per_step"] > 0 and c["allreduces_per_step"] > 0 and out["value"] > 0
+    assert c["halo_overlap"] == 1
+    cm = c["comm"]
+    assert cm["halo_ms"] > 0 and cm["allreduce_ms"] > 0 and cm["halo_exchanges_timed"] == c["halo_exchanges_per_step"]
+    assert 0 < cm["kernel_ms"] < cm["step_ms_with_comm_timers"]
+    if config == 5:
+        assert "tetrahedra" in c["workload"] and c["gmres_iterations"] == 4 and c["cells"] == 6 * 16 ** 3
+    else:
+        assert c["picard_sweeps"] > 0

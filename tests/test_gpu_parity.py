@@ -1545,6 +1545,52 @@ def test_row_dictionary_products_are_bitwise_the_stored_ones(gpu_ctx_factory, nx
 
 
 @pytest.mark.gpu
+def test_row_dictionary_comes_back_after_being_switched_off_and_retires_after_a_device_refusal(gpu_ctx_factory):
+    """(medium) sell_dict 1 -> assemble -> 0 -> assemble -> 1 -> assemble must rebuild the dictionaries - only a
+    real refusal (too many distinct rows, a failed check) is remembered per mesh and Dirichlet set; (low) a refusal that
+    happens ON THE DEVICE in a re-assembly check reaches the host at the end of the next solve (one word in mapped host
+    memory), which then retires the dictionary instead of running every product through the dictionary kernel's one-row
+    fallback and counting 2 B per row."""
+    f = _ffi()
+    import perphil_amd.fd as fdm
+
+    N = 16
+    mesh = fdm.UnitCubeMesh(N, N, N, hexahedral=True)
+    b = mesh.boundary_nodes()
+    g1, g2 = o.exact_pressures(mesh.node_coordinates(b), P)
+    ctx = gpu_ctx_factory()
+    ctx.set_option("sell_dict_min_rows", 1)
+    ctx.mesh_build(3, f.CELL_HEX, N, N, N)
+    ctx.set_dirichlet(0, b, g1)
+    ctx.set_dirichlet(1, b, g2)
+    asm = lambda: ctx.assemble(P.k1, P.k2, P.beta, P.mu, monolithic=False)
+    asm()
+    builds = ctx.timers()["dict_builds"]
+    assert ctx.timers()["dict_operators"] >= 3 and builds >= 3 and ctx.timers()["dict_build_ms"] > 0
+    ctx.set_option("sell_dict", 0)
+    asm()
+    assert ctx.timers()["dict_operators"] == 0
+    ctx.set_option("sell_dict", 1)
+    asm()
+    assert ctx.timers()["dict_operators"] >= 3 and ctx.timers()["dict_builds"] >= builds + 3
+    nb = ctx.timers()["dict_builds"]
+    asm()                                                  # an ordinary re-assembly builds nothing
+    assert ctx.timers()["dict_builds"] == nb
+    cfg = _cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_MG, inner_rtol=1e-10, inner_reduction=1e-1, inner_norm=1,
+               mg_smooth=1, picard_rtol=1e-8)
+    x0, info0, _ = ctx.solve(cfg)
+    before = ctx.timers()["dict_operators"]
+    assert info0.converged and before >= 3
+    ctx.set_option("sell_dict_poison", 2)                  # refusal on the device + the alarm word a check kernel raises
+    x1, info1, _ = ctx.solve(cfg)                          # this solve's launches take the stored values by themselves ...
+    assert info1.converged and np.array_equal(x1, x0)
+    t = ctx.timers()                                       # ... and at its end the host retired the fine blocks' dictionaries
+    assert t["dict_status"] == -2 and t["dict_operators"] == before - 3, t
+    x2, info2, _ = ctx.solve(cfg)                          # plain kernels now
+    assert info2.converged and np.array_equal(x2, x0)
+
+
+@pytest.mark.gpu
 def test_large_results_come_back_in_pinned_arrays_that_are_safe_to_keep(gpu_ctx_factory):
     """Context.solution() / solve(fetch=True) hand large results out in page-locked arrays from a pool of three per context
     (pph_host_alloc): an array somebody still refers to - directly or through a view - is never written again, one that
