@@ -2221,6 +2221,439 @@ __global__ __launch_bounds__(256, WPS) void k_asm_node(const double* __restrict_
   fuse_lam_max(best1, best2, fa.lam);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Node kernel, round 4 (k_asm_node2; default): the same integrals, organised so that a node-wave needs ~3 x fewer
+// instructions.  What the round-3 kernel spent its 10 k instructions per node-wave on (ISA): 1 400 fp64 operations, 1 370
+// v_readlane / v_writelane (scalar registers spilled into vector lanes: the ~150 64-bit literals of the reference tables
+// G[a][b][ef] + the saved exec masks of 35 predicated regions), 760 selects, ~1 500 exec-mask / branch instructions, 81
+// coordinate loads with clamped indices.  Three changes:
+//
+//  1. Edges instead of neighbourhoods.  Every cell has equal parallel edges (MeshData::all_affine: the exact test at
+//     mesh build), so the Jacobian of the cell with the node as corner a is made of the node's OWN edges
+//     E(d, +) = x(node + e_d) - x(node) (a_d = 0) or E(d, -) = x(node) - x(node - e_d) (a_d = 1) - bitwise the edges the
+//     tile kernel reads off the cell's corner 0.  7 vertices (21 loads) instead of 27 (81).
+//  2. Sums over cells BEFORE the reference integrals.  With b = a + o the reference integrals of trilinear functions on
+//     a constant-Jacobian cell factor into one-dimensional ones ( int n_i n_j = 2/3 | 1/3, int n_i' n_j' = +-1/2,
+//     int n_i' n_j = s_i / 2 ):
+//        G[a][b][ee] = sigma_e(o) / 2 * prod_{d != e} mm_d(o)                       sigma = +1 (o_d = 0) | -1,  mm = 2/3 | 1/3
+//        G[a][b][ef] = s_e(a) s_f(a) (sigma_e + sigma_f) / 4 * mm_h(o)  (e < f)     s_d(a) = +1 (a_d = 1) | -1
+//        M[a][b]     = prod_d mm_d(o)
+//     i.e. a coefficient that depends on the SLOT o only, times a sign that depends on the cell only.  Hence
+//        K(node, node + o) = sum_ef c_ef(o) * [ sum over the cells c that hold both nodes of  s_e s_f D^c_ef ]
+//     and the inner sums over the 2 x 2 x 2 cells around the node are box sums along the axes with o_d = 0: 19
+//     additions per component give all 27 slots.  9 distinct literals instead of ~150; 480 (factors) + 133 (box sums)
+//     + 153 (combination) fp64 operations instead of 1 400; the cell loop has no corner loop and no predicated region
+//     (a cell outside the box gets the weight |det J| = 0, its edge replaced by the opposite one).
+//  3. A wave whose 64 nodes are all interior and far from constrained dofs (~70 % of the waves of a 256^3 level) runs a
+//     straight-line body: no masks, no existence tests, right-hand side 0.  Storage variants (full / symmetric,
+//     coupling block symmetric or not, with or without A21 / right-hand side) are template parameters, not tables in
+//     scalar registers.
+// Entries agree with the tile kernel's to 1e-15 of the largest entry (closed-form reference integrals instead of
+// Gauss sums evaluated at compile time, other association of the sums); same sweeps / iterations
+// (test_node_assembly_kernel_equals_tile_kernel).  Rows of a uniform box repeat bit for bit as before: every node of a
+// class runs the same arithmetic on the same edge vectors (row dictionaries, pph_sell.hip).
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ constexpr double n2_mm(int od) { return od == 0 ? 0.66666666666666663 : 0.33333333333333331; }
+template <int DIM> __host__ __device__ constexpr int n2_o(int q, int d) { return d == 0 ? q % 3 - 1 : (d == 1 ? (q / 3) % 3 - 1 : (DIM == 3 ? q / 9 - 1 : 0)); }
+// coefficient of the packed component k = (e, f) of D (order of tile_factor: 3D 00 01 02 11 12 22, 2D 00 01 11) in slot q
+template <int DIM>
+__host__ __device__ constexpr double n2_coef(int q, int e, int f) {
+  const int oe = n2_o<DIM>(q, e), of = n2_o<DIM>(q, f);
+  if (e == f) {
+    double v = (oe == 0) ? 0.5 : -0.5;
+    for (int d = 0; d < DIM; ++d) if (d != e) v *= n2_mm(n2_o<DIM>(q, d));
+    return v;
+  }
+  if ((oe == 0) != (of == 0)) return 0.0;
+  double v = (oe == 0) ? 0.5 : -0.5;
+  for (int d = 0; d < DIM; ++d) if (d != e && d != f) v *= n2_mm(n2_o<DIM>(q, d));
+  return v;
+}
+template <int DIM>
+__host__ __device__ constexpr double n2_cmass(int q) {
+  double v = 1.0;
+  for (int d = 0; d < DIM; ++d) v *= n2_mm(n2_o<DIM>(q, d));
+  return v;
+}
+// box sums of the 2^DIM cell values Q[a] (a_d = 1: the cell lies on the low side of the node along d): out[q] = sum of
+// Q[a] over the cells that hold both the node and node + o(q)  (o_d = +1: a_d = 0, o_d = -1: a_d = 1, o_d = 0: both)
+template <int DIM>
+__device__ __forceinline__ void n2_box(const double (&Q)[1 << DIM], double (&out)[DIM == 3 ? 27 : 9]) {
+  if constexpr (DIM == 2) {
+    double X[3][2];
+#pragma unroll
+    for (int ay = 0; ay < 2; ++ay) { X[0][ay] = Q[1 + 2 * ay]; X[2][ay] = Q[2 * ay]; X[1][ay] = Q[2 * ay] + Q[1 + 2 * ay]; }
+#pragma unroll
+    for (int ox = 0; ox < 3; ++ox) { out[ox] = X[ox][1]; out[6 + ox] = X[ox][0]; out[3 + ox] = X[ox][0] + X[ox][1]; }
+  } else {
+    double X[3][2][2];
+#pragma unroll
+    for (int az = 0; az < 2; ++az)
+#pragma unroll
+      for (int ay = 0; ay < 2; ++ay) {
+        const double q0 = Q[2 * ay + 4 * az], q1 = Q[1 + 2 * ay + 4 * az];
+        X[0][ay][az] = q1; X[2][ay][az] = q0; X[1][ay][az] = q0 + q1;
+      }
+    double Y[3][3][2];
+#pragma unroll
+    for (int az = 0; az < 2; ++az)
+#pragma unroll
+      for (int ox = 0; ox < 3; ++ox) { Y[ox][0][az] = X[ox][1][az]; Y[ox][2][az] = X[ox][0][az]; Y[ox][1][az] = X[ox][0][az] + X[ox][1][az]; }
+#pragma unroll
+    for (int oy = 0; oy < 3; ++oy)
+#pragma unroll
+      for (int ox = 0; ox < 3; ++ox) {
+        out[ox + 3 * oy] = Y[ox][oy][1]; out[18 + ox + 3 * oy] = Y[ox][oy][0]; out[9 + ox + 3 * oy] = Y[ox][oy][0] + Y[ox][oy][1];
+      }
+  }
+}
+
+// coordinates a node's row needs: the node and its two neighbours along every axis (indices clamped to the node itself
+// where the box ends), and the `near` byte
+template <int DIM>
+struct N2Pre {
+  double X0[DIM], XP[DIM][DIM], XM[DIM][DIM];   // XP[d] = x(node + e_d), XM[d] = x(node - e_d)
+  uint8_t near;
+};
+template <int DIM>
+__device__ __forceinline__ void n2_fetch(const double* __restrict__ cx, const double* __restrict__ cy, const double* __restrict__ cz,
+                                         int px, int py, int pz, const uint8_t* __restrict__ nearp, uint32_t node, int gi, int gj,
+                                         int gk, int probe, N2Pre<DIM>& P) {
+  const uint32_t stride[3] = {1u, (uint32_t)px, (uint32_t)px * (uint32_t)py};
+  const int g[3] = {gi, gj, gk};
+  const int pd[3] = {px, py, pz};
+  const double* cc[3] = {cx, cy, cz};
+  P.near = nearp[node];
+#pragma unroll
+  for (int c = 0; c < DIM; ++c) P.X0[c] = cc[c][node];
+#pragma unroll
+  for (int d = 0; d < DIM; ++d) {
+    const bool hp = g[d] < pd[d] - 1, hm = g[d] > 0;
+    const uint32_t np = hp ? node + stride[d] : node, nm = hm ? node - stride[d] : node;
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) {
+      P.XP[d][c] = cc[c][np];
+      P.XM[d][c] = cc[c][nm];
+    }
+  }
+}
+
+// K and M of the row of one node, slot by slot.  FAST: every cell around the node exists (no selects).
+// CELLMAJOR (default): the 2^d cells one after the other, each adding its 2^d x (components + weight) terms to the slots it
+// touches - only kv, mv and ONE cell's factor are live (3 waves per SIMD instead of 2).  The slot coefficients are a
+// leading literal per component class (2/9 | 1/3 | 8/27 in 3D) times 1, 1/2, 1/4, 1/8: the literal is multiplied into the
+// cell's factor once and the powers of two are exact, so every term is one add / multiply-add with an inline constant
+// and equals c(o) * D bit for bit.  !CELLMAJOR: box sums over the cells first (19 additions per component give all
+// slots; fewer operations, 56 factor values live).
+template <int DIM> __host__ __device__ constexpr double n2_lead(int e, int f) {   // largest |coefficient| of component (e, f): o = 0
+  return n2_coef<DIM>((DIM == 3) ? 13 : 4, e, f);
+}
+template <int DIM, bool FAST, bool CELLMAJOR = true>
+__device__ __forceinline__ void n2_row(const N2Pre<DIM>& P, const bool (&has)[DIM][2], double (&kv)[DIM == 3 ? 27 : 9],
+                                       double (&mv)[DIM == 3 ? 27 : 9]) {
+  constexpr int NB = 1 << DIM;
+  constexpr int NSLOT = (DIM == 3) ? 27 : 9;
+  constexpr int NC = DIM * (DIM + 1) / 2;     // components of D
+  // the node's edges: E[d][0] towards +d, E[d][1] from -d (a_d = 1); a missing one is replaced by the opposite one
+  double E[DIM][2][DIM];
+#pragma unroll
+  for (int d = 0; d < DIM; ++d)
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) {
+      const double ep = P.XP[d][c] - P.X0[c], em = P.X0[c] - P.XM[d][c];
+      E[d][0][c] = (FAST || has[d][0]) ? ep : em;
+      E[d][1][c] = (FAST || has[d][1]) ? em : ep;
+    }
+  if constexpr (CELLMAJOR) {
+#pragma unroll
+    for (int q = 0; q < NSLOT; ++q) { kv[q] = 0.0; mv[q] = 0.0; }
+#pragma unroll
+    for (int a = 0; a < NB; ++a) {
+      double J[DIM][DIM];
+      bool in = true;
+#pragma unroll
+      for (int e = 0; e < DIM; ++e) {
+        const int ae = (a >> e) & 1;
+        in = in && has[e][ae];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) J[e][d] = 0.5 * E[e][ae][d];
+      }
+      double D[NC + 1];
+      tile_factor<DIM>(J, D);
+      // leading coefficient (and the cell's sign s_e s_f, and 0 for a cell outside the box) folded into the factor
+      double U[NC + 1];
+      int k = 0;
+#pragma unroll
+      for (int e = 0; e < DIM; ++e)
+#pragma unroll
+        for (int f = e; f < DIM; ++f) {
+          const bool neg = (e != f) && (((a >> e) & 1) != ((a >> f) & 1));     // s_e s_f = -1
+          const double u = (neg ? -n2_lead<DIM>(e, f) : n2_lead<DIM>(e, f)) * D[k];
+          U[k] = (FAST || in) ? u : 0.0;
+          ++k;
+        }
+      {
+        const double u = n2_cmass<DIM>((DIM == 3) ? 13 : 4) * D[NC];
+        U[NC] = (FAST || in) ? u : 0.0;
+      }
+      // the 2^d slots this cell touches: o_d = 0 or towards the cell (a_d = 0: +1, a_d = 1: -1)
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        int q = 0, mul = 1;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) {
+          const int od = ((t >> d) & 1) ? (((a >> d) & 1) ? -1 : 1) : 0;
+          q += (od + 1) * mul;
+          mul *= 3;
+        }
+        k = 0;
+#pragma unroll
+        for (int e = 0; e < DIM; ++e)
+#pragma unroll
+          for (int f = e; f < DIM; ++f) {
+            constexpr double zero = 0.0;
+            const double r = n2_coef<DIM>(q, e, f) / n2_lead<DIM>(e, f);     // +- 1, 1/2, 1/4 (exact) or 0
+            if (r != zero) kv[q] += r * U[k];
+            ++k;
+          }
+        mv[q] += (n2_cmass<DIM>(q) / n2_cmass<DIM>((DIM == 3) ? 13 : 4)) * U[NC];
+      }
+    }
+    return;
+  }
+  // geometry factors of the 2^d cells: Dc[k][a], k < NC the packed symmetric D (signed: s_e s_f), k = NC the weight
+  double Dc[NC + 1][NB];
+#pragma unroll
+  for (int a = 0; a < NB; ++a) {
+    double J[DIM][DIM];
+    bool in = true;
+#pragma unroll
+    for (int e = 0; e < DIM; ++e) {
+      const int ae = (a >> e) & 1;
+      in = in && has[e][ae];
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) J[e][d] = 0.5 * E[e][ae][d];
+    }
+    double D[NC + 1];
+    tile_factor<DIM>(J, D);
+    int k = 0;
+#pragma unroll
+    for (int e = 0; e < DIM; ++e)
+#pragma unroll
+      for (int f = e; f < DIM; ++f) {
+        const bool neg = (e != f) && (((a >> e) & 1) != ((a >> f) & 1));     // s_e s_f = -1
+        const double v = neg ? -D[k] : D[k];
+        Dc[k][a] = (FAST || in) ? v : 0.0;
+        ++k;
+      }
+    Dc[NC][a] = (FAST || in) ? D[NC] : 0.0;
+  }
+  double bs[NSLOT];
+  int k = 0;
+#pragma unroll
+  for (int e = 0; e < DIM; ++e)
+#pragma unroll
+    for (int f = e; f < DIM; ++f) {
+      n2_box<DIM>(Dc[k], bs);
+#pragma unroll
+      for (int q = 0; q < NSLOT; ++q) {
+        constexpr double zero = 0.0;
+        const double c = n2_coef<DIM>(q, e, f);
+        if (k == 0) kv[q] = c * bs[q];
+        else if (c != zero) kv[q] += c * bs[q];
+      }
+      ++k;
+    }
+  n2_box<DIM>(Dc[NC], bs);
+#pragma unroll
+  for (int q = 0; q < NSLOT; ++q) mv[q] = n2_cmass<DIM>(q) * bs[q];
+}
+
+// Two output streams, ONE 16-byte store per lane: lanes 2i and 2i + 1 hold the entries of the consecutive rows 2i, 2i + 1 for
+// stream A (va) and stream B (vb); they swap one value (DPP quad_perm [1,0,3,2]) so that the even lane writes rows (2i, 2i + 1)
+// of stream A and the odd lane rows (2i, 2i + 1) of stream B.  A wave-instruction then covers two contiguous, aligned 512-byte
+// runs instead of one, and a row's 42 operator entries leave in 21 store instructions instead of 42: the kernel's stores
+// are issue-bound, not bandwidth-bound (timing probes).  pa / pb: this lane's stream base (already
+// selected by parity), offp = 8 * (row & ~1).
+__device__ __forceinline__ double n2_swap1(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), 0xB1, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), 0xB1, 0xF, 0xF, true);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ void n2_store_pair(char* base, uint32_t offp, bool odd, double va, double vb) {
+  const double got = n2_swap1(odd ? va : vb);     // the even lane needs its partner's va, the odd lane its partner's vb
+  pph_d2 v;
+  v.x = odd ? got : va;
+  v.y = odd ? vb : got;
+  *reinterpret_cast<pph_d2*>(base + offp) = v;
+}
+
+// fused epilogue (Dirichlet elimination, A11 / A22 / A12 (/ A21), lifting, u0, 1 / a_ii, spectral bound) - no predicated
+// region in either form: the general form loads the masks / boundary values of every neighbour (index clamped to the node
+// itself where there is none; the entry is then an exact 0 and is stored as the pad's +0) and selects.  All predicates are
+// 0 / 1 integers combined with & | ^ (C++'s && would come back as exec-mask regions with the loads sunk into them).
+// SAME: both fields carry one Dirichlet set (m1 == m2): one predicate per entry position instead of four.
+template <int DIM, bool FAST, bool SAME, bool SYM, bool SYMC, bool HAS12, bool HAS21, bool HASRHS>
+__device__ __forceinline__ void n2_epilogue(const double (&kv)[DIM == 3 ? 27 : 9], const double (&mv)[DIM == 3 ? 27 : 9],
+                                            const unsigned (&hasb)[DIM][2], int px, int py, int64_t n, const FuseArgs& fa,
+                                            uint32_t node, uint32_t nodeS, unsigned liveb, unsigned nearb, double& best1,
+                                            double& best2) {
+  // node: the row for loads (0 for a lane beyond n); nodeS: the lane's own row index for the operator stores (a lane beyond
+  // n, always inside the leading dimension, writes the zeros of its padding row); liveb: 1 for a row of the mesh
+  constexpr int NSLOT = (DIM == 3) ? 27 : 9;
+  const uint32_t upxy = (uint32_t)px * (uint32_t)py;
+  unsigned r1 = 0, r2 = 0;
+  if (!FAST) {
+    const unsigned nm = 0u - nearb;
+    r1 = (unsigned)fa.m1[node] & nm;
+    r2 = SAME ? r1 : ((unsigned)fa.m2[node] & nm);
+  }
+  const unsigned free1 = (r1 & 1u) ^ 1u, free2 = (r2 & 1u) ^ 1u, own1 = ((r1 >> 1) & 1u) ^ 1u, own2 = ((r2 >> 1) & 1u) ^ 1u;
+  const unsigned symg = fa.symg ? 1u : 0u;
+  double t11 = 0.0, t22 = 0.0, d11 = 0.0, d22 = 0.0, tK1 = 0.0, tK2 = 0.0, tM = 0.0;
+  const uint32_t offp = (nodeS & ~1u) * 8u;                     // (launcher: n < 2^29)
+  const bool odd = (nodeS & 1u) != 0;
+  const int64_t ldb = fa.ld * 8;
+  // this lane's stream bases: diagonal blocks - even lanes A11, odd lanes A22 of the same slot; coupling blocks - A12 and
+  // A21 of the same slot when A21 is stored, else two consecutive slots of A12 (even lane the first)
+  char* const pD = reinterpret_cast<char*>(odd ? fa.A22 : fa.A11);
+  char* const pC = HAS21 ? reinterpret_cast<char*>(odd ? fa.A21 : fa.A12) : reinterpret_cast<char*>(fa.A12) + (odd ? ldb : 0);
+  double held12 = 0.0;
+#pragma unroll
+  for (int q = 0; q < NSLOT; ++q) {
+    const int ox = n2_o<DIM>(q, 0), oy = n2_o<DIM>(q, 1), oz = n2_o<DIM>(q, 2);
+    const double kvs = kv[q], mvs = mv[q];
+    const bool diag = (q == NSLOT / 2);
+    double o11 = fa.a * kvs + fa.b * mvs, o22 = fa.c * kvs + fa.b * mvs, o12 = -fa.b * mvs, o21 = o12;
+    if (!FAST) {
+      unsigned ex = liveb;
+      if (ox != 0) ex &= hasb[0][ox > 0 ? 0 : 1];
+      if (oy != 0) ex &= hasb[1][oy > 0 ? 0 : 1];
+      if (DIM == 3 && oz != 0) ex &= hasb[DIM - 1][oz > 0 ? 0 : 1];
+      const uint32_t j = node + ((uint32_t)(ox + oy * px) + (uint32_t)oz * upxy) * ex;     // (the node itself where there is no neighbour)
+      const unsigned um = 0u - (ex & nearb);
+      const unsigned cm1 = (unsigned)fa.m1[j] & um;
+      const unsigned cm2 = SAME ? cm1 : ((unsigned)fa.m2[j] & um);
+      if (HASRHS) {
+        const double v1 = fa.g1[j], v2 = fa.g2[j];
+        tK1 += kvs * v1; tK2 += kvs * v2; tM += mvs * (v1 - v2);     // (kvs = mvs = 0 where there is no neighbour)
+      }
+      // fuse_elim_diag / fuse_elim_coupling: an entry survives in a free row towards a free column; the ghost row of a slab
+      // keeps it only in symmetric storage and towards an owned column; a constrained (non-ghost) row keeps a unit diagonal
+      const unsigned cf1 = (cm1 & 1u) ^ 1u, cf2 = (cm2 & 1u) ^ 1u, co1 = ((cm1 >> 1) & 1u) ^ 1u, co2 = ((cm2 >> 1) & 1u) ^ 1u;
+      const unsigned k11 = ex & free1 & cf1 & (own1 | (symg & co1));
+      const unsigned k22 = SAME ? k11 : (ex & free2 & cf2 & (own2 | (symg & co2)));
+      const unsigned k12 = SAME ? k11 : (ex & free1 & cf2 & (own1 | (symg & co2)));
+      const unsigned k21 = SAME ? k11 : (ex & free2 & cf1 & (own2 | (symg & co1)));
+      const double u1 = (diag && ((free1 ^ 1u) & own1)) ? 1.0 : 0.0, u2 = (diag && ((free2 ^ 1u) & own2)) ? 1.0 : 0.0;
+      o11 = k11 ? o11 : u1;
+      o22 = k22 ? o22 : u2;
+      o12 = k12 ? o12 : 0.0;
+      o21 = k21 ? o21 : 0.0;
+    }
+    const int so = SYM ? q - NSLOT / 2 : q, sc = SYMC ? q - NSLOT / 2 : q;   // stored slot (< 0: lower half, not stored)
+    constexpr int NSC = SYMC ? NSLOT / 2 + 1 : NSLOT;                         // stored coupling slots
+    if (so >= 0) n2_store_pair(pD + so * ldb, offp, odd, o11, o22);
+    if (sc >= 0 && HAS12) {
+      if (HAS21) {
+        n2_store_pair(pC + sc * ldb, offp, odd, o12, o21);
+      } else if ((sc & 1) == 0 && sc + 1 < NSC) {
+        held12 = o12;                                                        // first of a pair of slots
+      } else if ((sc & 1) == 1) {
+        n2_store_pair(pC + (sc - 1) * ldb, offp, odd, held12, o12);
+      } else {                                                               // odd slot count: the last one alone
+        *reinterpret_cast<double*>(reinterpret_cast<char*>(fa.A12) + sc * ldb + nodeS * 8u) = o12;
+      }
+    }
+    t11 += fabs(o11); t22 += fabs(o22);
+    if (diag) { d11 = o11; d22 = o22; }
+    // general form: keep the neighbour loads of later slots from being hoisted above this slot's stores (each of the 27
+    // slots brings 2 - 4 loads: all of them in flight at once is 150 more live registers, i.e. scratch)
+    if (!FAST && (q % 3) == 2) __builtin_amdgcn_sched_barrier(0);
+  }
+  const double i1 = (d11 != 0.0) ? 1.0 / d11 : 1.0, i2 = (d22 != 0.0) ? 1.0 / d22 : 1.0;
+  const double q1 = t11 * fabs(i1), q2 = t22 * fabs(i2);
+  best1 = (own1 && q1 > best1) ? q1 : best1;   // (ghost rows: not rows of this rank's operator)
+  best2 = (own2 && q2 > best2) ? q2 : best2;
+  if (!FAST && !liveb) return;                 // (the per-row vectors have n entries, not the leading dimension)
+  fa.dinv1[node] = i1;
+  fa.dinv2[node] = i2;
+  if (HASRHS) {
+    double o1 = 0.0, o2 = 0.0, u1 = 0.0, u2 = 0.0;
+    if (!FAST) {
+      const double w1 = -(fa.a * tK1 + fa.b * tM), w2 = -(fa.c * tK2 - fa.b * tM);
+      const double h1 = fa.g1[node], h2 = fa.g2[node];
+      o1 = (nearb & (r1 == 0u ? 1u : 0u)) ? w1 : 0.0;
+      o2 = (nearb & (r2 == 0u ? 1u : 0u)) ? w2 : 0.0;
+      u1 = nearb ? h1 : 0.0;
+      u2 = nearb ? h2 : 0.0;
+    }
+    fa.rhs[node] = o1;
+    fa.rhs[n + node] = o2;
+    fa.u0[node] = u1;
+    fa.u0[n + node] = u2;
+  }
+}
+
+// PATH 0: both bodies in one kernel; 1: only the waves that take the straight-line body, 2: only the others (two
+// launches with separate register allocations; measured against PATH 0)
+template <int DIM, bool SYM, bool SYMC, bool HAS12, bool HAS21, bool HASRHS, bool SAME, int PATH>
+__global__ __launch_bounds__(256, PATH == 1 ? 3 : 2) void k_asm_node2(const double* __restrict__ cx, const double* __restrict__ cy,
+                                                      const double* __restrict__ cz, int nx, int ny, int nzl, int px, int py,
+                                                      int pz, int64_t n, FuseArgs fa, int xmap) {
+  constexpr int NSLOT = (DIM == 3) ? 27 : 9;
+  double best1 = 0.0, best2 = 0.0;
+  const int probe = 0;            // (the timing probes of DESIGN.md section 4.2 - no operator stores, synthetic coordinates - were
+                                  // runtime flags: every flag test splits the straight-line code; removed after measuring)
+  (void)probe;
+  // block order: as k_asm_node (round-robin blocks of 256 consecutive nodes; xmap 1: one contiguous eighth per XCD)
+  const int64_t nblk = (n + 255) / 256;
+  const int64_t bpx = xmap ? (int64_t)(gridDim.x >> 3) : (int64_t)gridDim.x;
+  const int64_t cpx = xmap ? (nblk + 7) >> 3 : nblk;
+  const int64_t blk0 = xmap ? (int64_t)(blockIdx.x & 7) * cpx : 0;
+  // (A rotated loop - the NEXT block's coordinates requested before this block's 48 stores - was built and measured: the
+  // wait for those loads at the loop head then also waits for the stores issued after them (one counter, in issue order),
+  // and 43 more live registers spill: 1.34 -> 1.91 ms.  The loads stay at the head of their own block.)
+  for (int64_t c = xmap ? (blockIdx.x >> 3) : blockIdx.x; c < cpx; c += bpx) {
+    const int64_t node64 = (blk0 + c) * 256 + threadIdx.x;
+    if (node64 - (threadIdx.x & 63) >= n) continue;     // a wave without a row (wave-uniform)
+    // a lane beyond n (last wave only; its index stays inside the leading dimension, a multiple of 64) goes through the general
+    // form with every predicate 0 and writes the zeros of its padding row: the paired stores need both lanes of a pair
+    const bool live = node64 < n;
+    const uint32_t nodeS = (uint32_t)node64;
+    const uint32_t node = live ? nodeS : 0u;
+    const int gi = (int)(node % (uint32_t)px);
+    const uint32_t tq = node / (uint32_t)px;
+    const int gj = (int)(tq % (uint32_t)py), gk = (int)(tq / (uint32_t)py);
+    const bool near = live && fa.near[node] != 0;
+    const bool inner = live && !near && gi > 0 && gi < px - 1 && gj > 0 && gj < py - 1 && (DIM == 2 || (gk > 0 && gk < pz - 1));
+    const bool fast = __all(inner);
+    const bool do_fast = PATH != 2 && fast, do_gen = PATH != 1 && !fast;
+    if (!do_fast && !do_gen) continue;
+    N2Pre<DIM> P;
+    n2_fetch<DIM>(cx, cy, cz, px, py, pz, fa.near, node, gi, gj, gk, 0, P);
+    bool has[DIM][2];
+    has[0][0] = gi < px - 1; has[0][1] = gi > 0;
+    has[1][0] = gj < py - 1; has[1][1] = gj > 0;
+    if constexpr (DIM == 3) { has[2][0] = gk < pz - 1; has[2][1] = gk > 0; }
+    unsigned hasb[DIM][2];
+#pragma unroll
+    for (int d = 0; d < DIM; ++d) { hasb[d][0] = has[d][0] ? 1u : 0u; hasb[d][1] = has[d][1] ? 1u : 0u; }
+    double kv[NSLOT], mv[NSLOT];
+    if (do_fast) {
+      n2_row<DIM, true>(P, has, kv, mv);
+      n2_epilogue<DIM, true, true, SYM, SYMC, HAS12, HAS21, HASRHS>(kv, mv, hasb, px, py, n, fa, node, nodeS, 1u, 0u, best1, best2);
+    } else {
+      n2_row<DIM, false>(P, has, kv, mv);
+      const unsigned nearb = near ? 1u : 0u;
+      n2_epilogue<DIM, false, SAME, SYM, SYMC, HAS12, HAS21, HASRHS>(kv, mv, hasb, px, py, n, fa, node, nodeS, live ? 1u : 0u, nearb,
+                                                                      best1, best2);
+    }
+  }
+  fuse_lam_max(best1, best2, fa.lam);
+}
+
 // every cell of a multilinear mesh has equal parallel edges (exact test of the tile kernel's phase A): out[0] != 0 otherwise
 template <int DIM>
 __global__ __launch_bounds__(256) void k_affine_check(const double* __restrict__ cx, const double* __restrict__ cy,
@@ -2313,6 +2746,45 @@ int pph_launch_fused_kernels(pph_ctx* ctx, MeshData& mesh, const FuseArgs& fa, d
   if (ctx->asm_node && ctx->asm_tile && ctx->asm_affine && mesh.all_affine && fa.ld != 0 && !fa.keep_km && !ctx->asm_tile_probe && !ctx->asm_ring) {
     const int64_t nb = ((ceil_div64(mesh.n, 256) + 7) / 8) * 8;
     const int grid = (int)(nb < 256 * 64 ? nb : 256 * 64);
+    // k_asm_node2 (round 4): storage variants as template parameters; 32-bit node offsets (n < 2^29: 812^3 nodes)
+    const bool sym = fa.slot_of[0] < 0, symc = fa.slot_of_c[0] < 0;
+    const bool h12 = fa.A12 != nullptr, h21 = fa.A21 != nullptr, hr = fa.rhs != nullptr;
+    const bool samek = fa.same != 0;       // both fields carry one Dirichlet set (then A21 is not stored: aliased to A12)
+    const int variant = (!h12 && !h21 && !hr) ? (sym ? 0 : 1) + (samek ? 0 : 6)             // multigrid level operators
+                        : (h12 && hr && !h21 && samek && sym == symc) ? (sym ? 2 : 3)       // fine level, A21 aliased to A12
+                        : (h12 && hr && h21 && !samek && !symc) ? (sym ? 4 : 5) : -1;       // fine level, A21 stored on its own
+    if (ctx->asm_node == 1 && variant >= 0 && mesh.n < ((int64_t)1 << 29)) {
+      const int pz = mesh.kind == PPH_CELL_QUAD ? 1 : mesh.pzl, nz = mesh.kind == PPH_CELL_QUAD ? 0 : mesh.nzl;
+      const bool split = mesh.n >= ctx->asm_node_split_min;   // two launches: straight-line waves, then the others
+#define PPH_N2P(DIMV, S, SC, H12, H21, HR, SM, PATHV)                                                                                  \
+      hipLaunchKernelGGL((k_asm_node2<DIMV, S, SC, H12, H21, HR, SM, PATHV>), dim3(grid), dim3(256), 0, ctx->stream, mesh.cx.p, mesh.cy.p, \
+                         mesh.cz.p, mesh.nx, mesh.ny, nz, mesh.px, mesh.py, pz, mesh.n, fa, ctx->asm_node_xmap)
+#define PPH_N2(DIMV, S, SC, H12, H21, HR, SM)                                                              \
+      do {                                                                                                  \
+        if (split) {                                                                                        \
+          if (!(ctx->asm_node_probe & 1)) PPH_N2P(DIMV, S, SC, H12, H21, HR, SM, 1);                        \
+          if (!(ctx->asm_node_probe & 2)) PPH_N2P(DIMV, S, SC, H12, H21, HR, SM, 2);                        \
+        }                                                                                                   \
+        else PPH_N2P(DIMV, S, SC, H12, H21, HR, SM, 0);                                                     \
+      } while (0)
+#define PPH_N2_DIM(DIMV)                                                        \
+      switch (variant) {                                                         \
+        case 0: PPH_N2(DIMV, true, true, false, false, false, true); break;      \
+        case 1: PPH_N2(DIMV, false, false, false, false, false, true); break;    \
+        case 2: PPH_N2(DIMV, true, true, true, false, true, true); break;        \
+        case 3: PPH_N2(DIMV, false, false, true, false, true, true); break;      \
+        case 4: PPH_N2(DIMV, true, false, true, true, true, false); break;       \
+        case 5: PPH_N2(DIMV, false, false, true, true, true, false); break;      \
+        case 6: PPH_N2(DIMV, true, true, false, false, false, false); break;     \
+        default: PPH_N2(DIMV, false, false, false, false, false, false); break;  \
+      }
+      if (mesh.kind == PPH_CELL_QUAD) { PPH_N2_DIM(2) } else { PPH_N2_DIM(3) }
+#undef PPH_N2_DIM
+#undef PPH_N2
+#undef PPH_N2P
+      PPH_HIP(ctx, hipGetLastError());
+      return PPH_OK;
+    }
     if (mesh.kind == PPH_CELL_QUAD)
       hipLaunchKernelGGL((k_asm_node<2, 2>), dim3(grid), dim3(256), 0, ctx->stream, mesh.cx.p, mesh.cy.p, mesh.cz.p, mesh.nx, mesh.ny, 0,
                          mesh.px, mesh.py, 1, mesh.n, fa, ctx->asm_node_xmap);

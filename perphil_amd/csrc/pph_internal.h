@@ -291,6 +291,8 @@ struct pph_ctx {
   int asm_tile_probe = 0;               // timing probe of the tile kernel: 1 stop after phase A, 2 after phase B (wrong results)
   int64_t asm_tile_min_nodes = 30000;   // levels with fewer nodes use the two-pass kernels (asm_tile 2: tile kernel always)
   int asm_node_xmap = 0;                // node kernel: blocks dealt round-robin to the XCDs (0, default) or one contiguous eighth per XCD (1: 2.0 instead of 4.1 GB read at 256^3, but 4.5 instead of 3.5 ms)
+  int64_t asm_node_split_min = 200000;  // node kernel on levels of at least this many nodes: straight-line waves and the others in two launches
+  int asm_node_probe = 0;               // timing probes (wrong results): 1 skip the straight-line launch, 2 skip the other
   int asm_node = 1;                     // box meshes, stencil-ELL output: one thread per node, registers only (k_asm_node); 0: tile / two-pass kernels
   int asm_tile_xmap = 0;                // tile kernel: x-adjacent tiles on ONE XCD (both halves of a 128-B line of a slot array meet in one L2)
   int asm_tile = 1;                     // multilinear fused assembly: 1 single-pass tile kernel (no element-row buffer), 0 two-pass
