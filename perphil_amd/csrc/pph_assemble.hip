@@ -2486,7 +2486,9 @@ __device__ __forceinline__ void n2_store_pair(char* base, uint32_t offp, bool od
   pph_d2 v;
   v.x = odd ? got : va;
   v.y = odd ? vb : got;
-  *reinterpret_cast<pph_d2*>(base + offp) = v;
+  // non-temporal: the operator entries are not read again by this kernel and would evict the coordinate lines its
+  // neighbours' rows need from the XCD's L2 (256^3 fine level: 2.50 -> 2.18 ms)
+  __builtin_nontemporal_store(v, reinterpret_cast<pph_d2*>(base + offp));
 }
 
 // fused epilogue (Dirichlet elimination, A11 / A22 / A12 (/ A21), lifting, u0, 1 / a_ii, spectral bound) - no predicated
@@ -2607,13 +2609,17 @@ __global__ __launch_bounds__(256, PATH == 1 ? 3 : 2) void k_asm_node2(const doub
   const int probe = 0;            // (the timing probes of DESIGN.md section 4.2 - no operator stores, synthetic coordinates - were
                                   // runtime flags: every flag test splits the straight-line code; removed after measuring)
   (void)probe;
-  // block order: as k_asm_node (round-robin blocks of 256 consecutive nodes; xmap 1: one contiguous eighth per XCD)
+  // Block order (blocks of 256 consecutive nodes): round-robin over the workgroups (xmap 0, default) or one contiguous eighth
+  // per XCD (1).  Measured at 256^3 with the non-temporal stores: round-robin 2.17 ms, contiguous eighths 2.75 (eight write
+  // fronts), and an XCD-striped order - XCD x takes, plane after plane, the blocks of the x-th in-plane stripe, persistent
+  // grid, so that a node's y and z neighbours share an L2 - 3.44 (the general-form waves pile up in the boundary stripes
+  // and planes of a static assignment); removed.
   const int64_t nblk = (n + 255) / 256;
   const int64_t bpx = xmap ? (int64_t)(gridDim.x >> 3) : (int64_t)gridDim.x;
   const int64_t cpx = xmap ? (nblk + 7) >> 3 : nblk;
   const int64_t blk0 = xmap ? (int64_t)(blockIdx.x & 7) * cpx : 0;
-  // (A rotated loop - the NEXT block's coordinates requested before this block's 48 stores - was built and measured: the
-  // wait for those loads at the loop head then also waits for the stores issued after them (one counter, in issue order),
+  // (A rotated loop - the NEXT block's coordinates requested before this block's stores - was also built and measured: the
+  // wait for those loads at the loop head then waits for the stores issued after them as well (one counter, in issue order),
   // and 43 more live registers spill: 1.34 -> 1.91 ms.  The loads stay at the head of their own block.)
   for (int64_t c = xmap ? (blockIdx.x >> 3) : blockIdx.x; c < cpx; c += bpx) {
     const int64_t node64 = (blk0 + c) * 256 + threadIdx.x;
