@@ -49,6 +49,7 @@ template struct DevBuf<int32_t>;
 template struct DevBuf<int64_t>;
 template struct DevBuf<uint8_t>;
 template struct DevBuf<uint16_t>;
+template struct DevBuf<uint32_t>;
 template struct DevBuf<unsigned long long>;
 
 // Dirichlet data of one field: the ghost-plane flag (bit 1) of the mask survives, the constrained flag (bit 0) and the
@@ -144,7 +145,7 @@ static void release_system(pph_ctx* ctx) {
 static void free_system(pph_ctx* ctx) {
   ctx->A11.release(); ctx->A22.release(); ctx->A12.release(); ctx->A21.release();
   ctx->E11.release(); ctx->E22.release(); ctx->E12.release(); ctx->E21.release();
-  ctx->D11.release(); ctx->D22.release(); ctx->D12.release();
+  ctx->D11.release(); ctx->D22.release(); ctx->D12.release(); ctx->DG.release();
   ctx->rhs.release(); ctx->u0.release(); ctx->sol.release();
   ctx->mrowptr.release(); ctx->mcol.release(); ctx->mval.release();
   mg_release(ctx);
@@ -649,6 +650,7 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
   if (!strcmp(name, "sell_dict_min_rows")) { ctx->sell_dict_min_rows = (int64_t)value; return PPH_OK; }
   if (!strcmp(name, "sell_dict_blocks")) { ctx->sell_dict_blocks = (int)value; la_release_graphs(ctx); return PPH_OK; }
   if (!strcmp(name, "sell_dict_zwalk")) { ctx->sell_dict_zwalk = (int)value; la_release_graphs(ctx); return PPH_OK; }
+  if (!strcmp(name, "sell_dict_fuse")) { ctx->dict_fuse = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "sell_dict_cap")) { ctx->sell_dict_cap = (int)value; return PPH_OK; }
   if (!strcmp(name, "sell_dict_walk")) { ctx->sell_dict_walk = value != 0; la_release_graphs(ctx); return PPH_OK; }
   if (!strcmp(name, "sell_dict_poison")) {

@@ -670,6 +670,19 @@ struct FuseArgs {
   int64_t ld;
   int8_t slot_of[27];
   int8_t slot_of_c[27];
+  // k_asm_node2, listed mode: row i of the (mini) output is the row of node list[i]
+  const uint32_t* list = nullptr;
+  // k_asm_node2, check mode (row dictionaries, pph_sell.hip "check fused into the assembly"): class arrays, tables and status
+  // words of the operators this launch writes (0: A11, 1: A22, 2: A12; null: no dictionary), the alarm word of the context
+  const uint16_t* dcls[3] = {nullptr, nullptr, nullptr};
+  const double* dtab[3] = {nullptr, nullptr, nullptr};
+  int* dstate[3] = {nullptr, nullptr, nullptr};
+  int dn[3] = {0, 0, 0};
+  int* alarm = nullptr;
+  // host side only: the group and dictionaries behind the check, and the views they describe
+  DictGroup* G = nullptr;
+  SellDict* dicts[3] = {nullptr, nullptr, nullptr};
+  const Sell* views[3] = {nullptr, nullptr, nullptr};
 };
 
 // Eliminated entries of the fused epilogues.  rm / cm: mask bytes of the row and of the column dof (bit 0 constrained,
@@ -2496,11 +2509,13 @@ __device__ __forceinline__ void n2_store_pair(char* base, uint32_t offp, bool od
 // itself where there is none; the entry is then an exact 0 and is stored as the pad's +0) and selects.  All predicates are
 // 0 / 1 integers combined with & | ^ (C++'s && would come back as exec-mask regions with the loads sunk into them).
 // SAME: both fields carry one Dirichlet set (m1 == m2): one predicate per entry position instead of four.
-template <int DIM, bool FAST, bool SAME, bool SYM, bool SYMC, bool HAS12, bool HAS21, bool HASRHS>
+// MODE 1: every stored entry is compared with the stored half of its class's table row (LDS; fact A of the fused dictionary
+// check); MODE 2 (listed): only the operator entries are produced
+template <int DIM, bool FAST, bool SAME, bool SYM, bool SYMC, bool HAS12, bool HAS21, bool HASRHS, int MODE>
 __device__ __forceinline__ void n2_epilogue(const double (&kv)[DIM == 3 ? 27 : 9], const double (&mv)[DIM == 3 ? 27 : 9],
                                             const unsigned (&hasb)[DIM][2], int px, int py, int64_t n, const FuseArgs& fa,
                                             uint32_t node, uint32_t nodeS, unsigned liveb, unsigned nearb, double& best1,
-                                            double& best2) {
+                                            double& best2, const double* __restrict__ stab, int c11, int c22, int c12) {
   // node: the row for loads (0 for a lane beyond n); nodeS: the lane's own row index for the operator stores (a lane beyond
   // n, always inside the leading dimension, writes the zeros of its padding row); liveb: 1 for a row of the mesh
   constexpr int NSLOT = (DIM == 3) ? 27 : 9;
@@ -2522,6 +2537,23 @@ __device__ __forceinline__ void n2_epilogue(const double (&kv)[DIM == 3 ? 27 : 9
   char* const pD = reinterpret_cast<char*>(odd ? fa.A22 : fa.A11);
   char* const pC = HAS21 ? reinterpret_cast<char*>(odd ? fa.A21 : fa.A12) : reinterpret_cast<char*>(fa.A12) + (odd ? ldb : 0);
   double held12 = 0.0;
+  // check modes: the row's class per operator -> its table row (stored half: NSLOT / 2 + 1 entries per class).  MODE 3: all
+  // 64 rows of the wave are of ONE class per operator (every interior wave of a uniform box) - the table row is wave-uniform
+  // and comes through scalar loads from the global table (c11 .. c12 are then the wave's classes); MODE 1: per-lane rows from LDS.
+  constexpr int SSC = NSLOT / 2 + 1;
+  constexpr bool CHK = (MODE == 1 || MODE == 3);
+  const bool chk12 = CHK && SYMC && HAS12 && fa.dcls[2] != nullptr;
+  const double *tr11 = nullptr, *tr22 = nullptr, *tr12 = nullptr;
+  unsigned long long acc11 = 0ull, acc22 = 0ull, acc12 = 0ull;
+  if (MODE == 1) {
+    tr11 = stab + c11 * SSC;
+    tr22 = stab + fa.dn[0] * SSC + c22 * SSC;
+    tr12 = stab + (fa.dn[0] + fa.dn[1]) * SSC + (chk12 ? c12 : 0) * SSC;
+  } else if (MODE == 3) {
+    tr11 = fa.dtab[0] + c11 * NSLOT + NSLOT / 2;
+    tr22 = fa.dtab[1] + c22 * NSLOT + NSLOT / 2;
+    tr12 = chk12 ? fa.dtab[2] + c12 * NSLOT + NSLOT / 2 : tr11;
+  }
 #pragma unroll
   for (int q = 0; q < NSLOT; ++q) {
     const int ox = n2_o<DIM>(q, 0), oy = n2_o<DIM>(q, 1), oz = n2_o<DIM>(q, 2);
@@ -2556,6 +2588,11 @@ __device__ __forceinline__ void n2_epilogue(const double (&kv)[DIM == 3 ? 27 : 9
     }
     const int so = SYM ? q - NSLOT / 2 : q, sc = SYMC ? q - NSLOT / 2 : q;   // stored slot (< 0: lower half, not stored)
     constexpr int NSC = SYMC ? NSLOT / 2 + 1 : NSLOT;                         // stored coupling slots
+    if (CHK && SYM && so >= 0) {
+      acc11 |= (unsigned long long)(__double_as_longlong(o11) ^ __double_as_longlong(tr11[so]));
+      acc22 |= (unsigned long long)(__double_as_longlong(o22) ^ __double_as_longlong(tr22[so]));
+    }
+    if (CHK && SYMC && HAS12 && sc >= 0) acc12 |= (unsigned long long)(__double_as_longlong(o12) ^ __double_as_longlong(tr12[sc]));
     if (so >= 0) n2_store_pair(pD + so * ldb, offp, odd, o11, o22);
     if (sc >= 0 && HAS12) {
       if (HAS21) {
@@ -2572,8 +2609,19 @@ __device__ __forceinline__ void n2_epilogue(const double (&kv)[DIM == 3 ? 27 : 9
     if (diag) { d11 = o11; d22 = o22; }
     // general form: keep the neighbour loads of later slots from being hoisted above this slot's stores (each of the 27
     // slots brings 2 - 4 loads: all of them in flight at once is 150 more live registers, i.e. scratch)
-    if (!FAST && (q % 3) == 2) __builtin_amdgcn_sched_barrier(0);
+    if (!FAST) __builtin_amdgcn_sched_barrier(0);
   }
+  if (CHK) {
+    // a row that left its class refuses that operator's dictionary: products take the stored values (pph_sell.hip)
+    const bool b11 = liveb && acc11 != 0ull, b22 = liveb && acc22 != 0ull, b12 = liveb && chk12 && acc12 != 0ull;
+    if (b11 | b22 | b12) {
+      if (b11) atomicExch(fa.dstate[0] + 1, -2);
+      if (b22) atomicExch(fa.dstate[1] + 1, -2);
+      if (b12) atomicExch(fa.dstate[2] + 1, -2);
+      if (fa.alarm) __hip_atomic_store(fa.alarm, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  if (MODE == 2) return;                       // listed mode: operator entries only
   const double i1 = (d11 != 0.0) ? 1.0 / d11 : 1.0, i2 = (d22 != 0.0) ? 1.0 / d22 : 1.0;
   const double q1 = t11 * fabs(i1), q2 = t22 * fabs(i2);
   best1 = (own1 && q1 > best1) ? q1 : best1;   // (ghost rows: not rows of this rank's operator)
@@ -2600,15 +2648,27 @@ __device__ __forceinline__ void n2_epilogue(const double (&kv)[DIM == 3 ? 27 : 9
 
 // PATH 0: both bodies in one kernel; 1: only the waves that take the straight-line body, 2: only the others (two
 // launches with separate register allocations; measured against PATH 0)
-template <int DIM, bool SYM, bool SYMC, bool HAS12, bool HAS21, bool HASRHS, bool SAME, int PATH>
-__global__ __launch_bounds__(256, PATH == 1 ? 3 : 2) void k_asm_node2(const double* __restrict__ cx, const double* __restrict__ cy,
+template <int DIM, bool SYM, bool SYMC, bool HAS12, bool HAS21, bool HASRHS, bool SAME, int PATH, int MODE = 0>
+__global__ __launch_bounds__(256, (PATH == 1 && MODE != 1) ? 3 : 2) void k_asm_node2(const double* __restrict__ cx, const double* __restrict__ cy,
                                                       const double* __restrict__ cz, int nx, int ny, int nzl, int px, int py,
                                                       int pz, int64_t n, FuseArgs fa, int xmap) {
   constexpr int NSLOT = (DIM == 3) ? 27 : 9;
   double best1 = 0.0, best2 = 0.0;
-  const int probe = 0;            // (the timing probes of DESIGN.md section 4.2 - no operator stores, synthetic coordinates - were
-                                  // runtime flags: every flag test splits the straight-line code; removed after measuring)
-  (void)probe;
+  // (the timing probes of DESIGN.md section 4.2 - no operator stores, synthetic coordinates - were runtime flags: every flag
+  // test splits the straight-line code; removed after measuring)
+  extern __shared__ double n2_stab[];
+  if (MODE == 1) {
+    // stored halves of the dictionaries' tables -> LDS: [A11 classes][A22 classes][A12 classes] x (NSLOT / 2 + 1)
+    constexpr int SSC = NSLOT / 2 + 1, C0 = NSLOT / 2;
+    int base = 0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if (fa.dtab[d])
+        for (int i = threadIdx.x; i < fa.dn[d] * SSC; i += 256) n2_stab[base + i] = fa.dtab[d][(i / SSC) * NSLOT + C0 + i % SSC];
+      base += fa.dn[d] * SSC;
+    }
+    __syncthreads();
+  }
   // Block order (blocks of 256 consecutive nodes): round-robin over the workgroups (xmap 0, default) or one contiguous eighth
   // per XCD (1).  Measured at 256^3 with the non-temporal stores: round-robin 2.17 ms, contiguous eighths 2.75 (eight write
   // fronts), and an XCD-striped order - XCD x takes, plane after plane, the blocks of the x-th in-plane stripe, persistent
@@ -2626,9 +2686,10 @@ __global__ __launch_bounds__(256, PATH == 1 ? 3 : 2) void k_asm_node2(const doub
     if (node64 - (threadIdx.x & 63) >= n) continue;     // a wave without a row (wave-uniform)
     // a lane beyond n (last wave only; its index stays inside the leading dimension, a multiple of 64) goes through the general
     // form with every predicate 0 and writes the zeros of its padding row: the paired stores need both lanes of a pair
+    // (listed mode: n = the rows of the mini operator, a multiple of 64, every one of them a node of the list)
     const bool live = node64 < n;
     const uint32_t nodeS = (uint32_t)node64;
-    const uint32_t node = live ? nodeS : 0u;
+    const uint32_t node = MODE == 2 ? fa.list[nodeS] : (live ? nodeS : 0u);
     const int gi = (int)(node % (uint32_t)px);
     const uint32_t tq = node / (uint32_t)px;
     const int gj = (int)(tq % (uint32_t)py), gk = (int)(tq / (uint32_t)py);
@@ -2646,18 +2707,73 @@ __global__ __launch_bounds__(256, PATH == 1 ? 3 : 2) void k_asm_node2(const doub
     unsigned hasb[DIM][2];
 #pragma unroll
     for (int d = 0; d < DIM; ++d) { hasb[d][0] = has[d][0] ? 1u : 0u; hasb[d][1] = has[d][1] ? 1u : 0u; }
+    // check mode: the row's classes (a wave-uniform variant - every interior wave of a uniform box has ONE class per operator,
+    // its table rows through scalar loads - was built beside the per-lane LDS rows: two epilogues in one kernel spill 0.6 - 1.3 KB
+    // per lane; the LDS rows alone are cheap enough)
+    int c11 = 0, c22 = 0, c12 = 0;
+    if (MODE == 1) {
+      const bool has12 = SYMC && HAS12 && fa.dcls[2] != nullptr;
+      c11 = fa.dcls[0][node]; c22 = fa.dcls[1][node]; c12 = has12 ? (int)fa.dcls[2][node] : 0;
+    }
     double kv[NSLOT], mv[NSLOT];
     if (do_fast) {
       n2_row<DIM, true>(P, has, kv, mv);
-      n2_epilogue<DIM, true, true, SYM, SYMC, HAS12, HAS21, HASRHS>(kv, mv, hasb, px, py, n, fa, node, nodeS, 1u, 0u, best1, best2);
+      n2_epilogue<DIM, true, true, SYM, SYMC, HAS12, HAS21, HASRHS, MODE>(kv, mv, hasb, px, py, n, fa, node, nodeS, 1u, 0u, best1, best2,
+                                                                         n2_stab, c11, c22, c12);
     } else {
       n2_row<DIM, false>(P, has, kv, mv);
       const unsigned nearb = near ? 1u : 0u;
-      n2_epilogue<DIM, false, SAME, SYM, SYMC, HAS12, HAS21, HASRHS>(kv, mv, hasb, px, py, n, fa, node, nodeS, live ? 1u : 0u, nearb,
-                                                                      best1, best2);
+      n2_epilogue<DIM, false, SAME, SYM, SYMC, HAS12, HAS21, HASRHS, MODE>(kv, mv, hasb, px, py, n, fa, node, nodeS, live ? 1u : 0u, nearb,
+                                                                            best1, best2, n2_stab, c11, c22, c12);
     }
   }
-  fuse_lam_max(best1, best2, fa.lam);
+  if (MODE != 2) fuse_lam_max(best1, best2, fa.lam);
+}
+
+// Fact A of the fused dictionary check for the rows of the GENERAL-form waves: the straight-line launch compares what it
+// stores for free (it waits on memory), the general-form launch has no registers to spare (the compare costs it 1 KB of scratch
+// per lane: 1.0 -> 2.85 ms), so its rows - about a quarter of a uniform box - are read back once: stored half of every
+// operator against the stored half of the row's class, bit for bit.  Same wave classification as k_asm_node2.
+template <int DIM>
+__global__ __launch_bounds__(256) void k_n2_check_general(int px, int py, int pz, int64_t n, FuseArgs fa) {
+  constexpr int NSLOT = (DIM == 3) ? 27 : 9, SSC = NSLOT / 2 + 1, C0 = NSLOT / 2;
+  extern __shared__ double n2_ctab[];
+  int base = 0, off[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    off[d] = base;
+    if (fa.dtab[d])
+      for (int i = threadIdx.x; i < fa.dn[d] * SSC; i += 256) n2_ctab[base + i] = fa.dtab[d][(i / SSC) * NSLOT + C0 + i % SSC];
+    base += fa.dn[d] * SSC;
+  }
+  __syncthreads();
+  const double* vals[3] = {fa.A11, fa.A22, fa.A12};
+  const int64_t nblk = (n + 255) / 256;
+  for (int64_t c = blockIdx.x; c < nblk; c += gridDim.x) {
+    const int64_t node64 = c * 256 + threadIdx.x;
+    if (node64 - (threadIdx.x & 63) >= n) continue;
+    const bool live = node64 < n;
+    const uint32_t node = live ? (uint32_t)node64 : 0u;
+    const int gi = (int)(node % (uint32_t)px);
+    const uint32_t tq = node / (uint32_t)px;
+    const int gj = (int)(tq % (uint32_t)py), gk = (int)(tq / (uint32_t)py);
+    const bool near = live && fa.near[node] != 0;
+    const bool inner = live && !near && gi > 0 && gi < px - 1 && gj > 0 && gj < py - 1 && (DIM == 2 || (gk > 0 && gk < pz - 1));
+    if (__all(inner) || !live) continue;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      if (!fa.dtab[d]) continue;
+      const double* row = n2_ctab + off[d] + (int)fa.dcls[d][node] * SSC;
+      unsigned long long acc = 0ull;
+#pragma unroll
+      for (int ss = 0; ss < SSC; ++ss)
+        acc |= (unsigned long long)(__double_as_longlong(vals[d][(int64_t)ss * fa.ld + node]) ^ __double_as_longlong(row[ss]));
+      if (acc != 0ull) {
+        atomicExch(fa.dstate[d] + 1, -2);
+        if (fa.alarm) __hip_atomic_store(fa.alarm, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 // every cell of a multilinear mesh has equal parallel edges (exact test of the tile kernel's phase A): out[0] != 0 otherwise
@@ -2762,30 +2878,83 @@ int pph_launch_fused_kernels(pph_ctx* ctx, MeshData& mesh, const FuseArgs& fa, d
     if (ctx->asm_node == 1 && variant >= 0 && mesh.n < ((int64_t)1 << 29)) {
       const int pz = mesh.kind == PPH_CELL_QUAD ? 1 : mesh.pzl, nz = mesh.kind == PPH_CELL_QUAD ? 0 : mesh.nzl;
       const bool split = mesh.n >= ctx->asm_node_split_min;   // two launches: straight-line waves, then the others
-#define PPH_N2P(DIMV, S, SC, H12, H21, HR, SM, PATHV)                                                                                  \
-      hipLaunchKernelGGL((k_asm_node2<DIMV, S, SC, H12, H21, HR, SM, PATHV>), dim3(grid), dim3(256), 0, ctx->stream, mesh.cx.p, mesh.cy.p, \
-                         mesh.cz.p, mesh.nx, mesh.ny, nz, mesh.px, mesh.py, pz, mesh.n, fa, ctx->asm_node_xmap)
+      // Row dictionaries in use on the operators of this launch and unchanged in shape: their per-assembly check runs inside
+      // the kernel (pph_sell.hip, "check fused into the assembly") - representative rows first (listed mode) -> tables +
+      // class adjacencies -> the assembly proper compares what it stores.  Otherwise sell_dict_update checks afterwards.
+      FuseArgs fc = fa;
+      bool fuse = ctx->dict_fuse && fa.G && fa.G->ok && split && sym && (variant == 0 || variant == 2 || variant == 4 || variant == 6);
+      int nd = 0;
+      size_t lds = 0;
+      if (fuse) {
+        const int want_nd = (variant == 2) ? 3 : 2;      // (A12 has a dictionary only in symmetric storage, i.e. with one Dirichlet set)
+        for (int d = 0; d < want_nd && fuse; ++d) {
+          const SellDict* D = fa.dicts[d];
+          const Sell* E = fa.views[d];
+          fuse = D && E && D->on && D->adj_ok && D->val == E->val && D->n == mesh.n && D->px == E->px && D->py == E->py &&
+                 D->bc_epoch == ctx->bc_epoch && D->cap == ctx->sell_dict_cap && D->ncls <= PPH_DICT_FUSE_CAP &&
+                 fa.G->cls_of[d] == (const void*)D->cls.p && fa.G->ncls[d] == D->ncls && ctx->sell_dict &&
+                 mesh.n >= ctx->sell_dict_min_rows && ctx->sell_rpt != 1;
+        }
+        nd = want_nd;
+      }
+      if (fuse) {
+        const int SS = sell_stored(mesh.kind, 1);
+        DictGroup& G = *fa.G;
+        FuseArgs fl = fa;
+        fl.ld = G.ldm;
+        fl.A11 = G.mini.p; fl.A22 = G.mini.p + (size_t)SS * G.ldm; fl.A12 = nd == 3 ? G.mini.p + (size_t)2 * SS * G.ldm : nullptr;
+        fl.A21 = nullptr; fl.rhs = nullptr; fl.u0 = nullptr;
+        fl.list = G.list.p;
+        const int gl = (int)ceil_div64(G.ldm, 256);
+#define PPH_N2L(DIMV, H12, HR, SM)                                                                                                  \
+        hipLaunchKernelGGL((k_asm_node2<DIMV, true, true, H12, false, HR, SM, 0, 2>), dim3(gl), dim3(256), 0, ctx->stream, mesh.cx.p, \
+                           mesh.cy.p, mesh.cz.p, mesh.nx, mesh.ny, nz, mesh.px, mesh.py, pz, G.ldm, fl, 0)
+        if (mesh.kind == PPH_CELL_QUAD) {
+          if (nd == 3) PPH_N2L(2, true, true, true); else if (samek) PPH_N2L(2, false, false, true); else PPH_N2L(2, false, false, false);
+        } else {
+          if (nd == 3) PPH_N2L(3, true, true, true); else if (samek) PPH_N2L(3, false, false, true); else PPH_N2L(3, false, false, false);
+        }
+#undef PPH_N2L
+        PPH_TRY(dict_group_tables(ctx, G, fa.dicts, nd, *fa.views[0]));
+        for (int d = 0; d < nd; ++d) {
+          fc.dcls[d] = fa.dicts[d]->cls.p; fc.dtab[d] = fa.dicts[d]->tab.p; fc.dstate[d] = fa.dicts[d]->state.p; fc.dn[d] = fa.dicts[d]->ncls;
+          lds += (size_t)fa.dicts[d]->ncls * SS * sizeof(double);
+        }
+        fc.alarm = ctx->dict_alarm_dev;
+      }
+#define PPH_N2P(DIMV, S, SC, H12, H21, HR, SM, PATHV, MODEV)                                                                            \
+      hipLaunchKernelGGL((k_asm_node2<DIMV, S, SC, H12, H21, HR, SM, PATHV, MODEV>), dim3(grid), dim3(256), MODEV == 1 ? lds : 0,          \
+                         ctx->stream, mesh.cx.p, mesh.cy.p, mesh.cz.p, mesh.nx, mesh.ny, nz, mesh.px, mesh.py, pz, mesh.n, fc,           \
+                         ctx->asm_node_xmap)
 #define PPH_N2(DIMV, S, SC, H12, H21, HR, SM)                                                              \
       do {                                                                                                  \
         if (split) {                                                                                        \
-          if (!(ctx->asm_node_probe & 1)) PPH_N2P(DIMV, S, SC, H12, H21, HR, SM, 1);                        \
-          if (!(ctx->asm_node_probe & 2)) PPH_N2P(DIMV, S, SC, H12, H21, HR, SM, 2);                        \
+          if (!(ctx->asm_node_probe & 1)) PPH_N2P(DIMV, S, SC, H12, H21, HR, SM, 1, 0);                     \
+          if (!(ctx->asm_node_probe & 2)) PPH_N2P(DIMV, S, SC, H12, H21, HR, SM, 2, 0);                     \
         }                                                                                                   \
-        else PPH_N2P(DIMV, S, SC, H12, H21, HR, SM, 0);                                                     \
+        else PPH_N2P(DIMV, S, SC, H12, H21, HR, SM, 0, 0);                                                  \
+      } while (0)
+      // (check mode exists for the symmetric-storage variants in two launches only: what a dictionary needs anyway)
+#define PPH_N2C(DIMV, S, SC, H12, H21, HR, SM)                                                             \
+      do {                                                                                                  \
+        PPH_N2P(DIMV, S, SC, H12, H21, HR, SM, 1, 1);                                                       \
+        PPH_N2P(DIMV, S, SC, H12, H21, HR, SM, 2, 0);                                                       \
+        hipLaunchKernelGGL(k_n2_check_general<DIMV>, dim3(grid), dim3(256), lds, ctx->stream, mesh.px, mesh.py, pz, mesh.n, fc); \
       } while (0)
 #define PPH_N2_DIM(DIMV)                                                        \
       switch (variant) {                                                         \
-        case 0: PPH_N2(DIMV, true, true, false, false, false, true); break;      \
+        case 0: if (fuse) PPH_N2C(DIMV, true, true, false, false, false, true); else PPH_N2(DIMV, true, true, false, false, false, true); break;      \
         case 1: PPH_N2(DIMV, false, false, false, false, false, true); break;    \
-        case 2: PPH_N2(DIMV, true, true, true, false, true, true); break;        \
+        case 2: if (fuse) PPH_N2C(DIMV, true, true, true, false, true, true); else PPH_N2(DIMV, true, true, true, false, true, true); break;        \
         case 3: PPH_N2(DIMV, false, false, true, false, true, true); break;      \
-        case 4: PPH_N2(DIMV, true, false, true, true, true, false); break;       \
+        case 4: if (fuse) PPH_N2C(DIMV, true, false, true, true, true, false); else PPH_N2(DIMV, true, false, true, true, true, false); break;       \
         case 5: PPH_N2(DIMV, false, false, true, true, true, false); break;      \
-        case 6: PPH_N2(DIMV, true, true, false, false, false, false); break;     \
+        case 6: if (fuse) PPH_N2C(DIMV, true, true, false, false, false, false); else PPH_N2(DIMV, true, true, false, false, false, false); break;     \
         default: PPH_N2(DIMV, false, false, false, false, false, false); break;  \
       }
       if (mesh.kind == PPH_CELL_QUAD) { PPH_N2_DIM(2) } else { PPH_N2_DIM(3) }
 #undef PPH_N2_DIM
+#undef PPH_N2C
 #undef PPH_N2
 #undef PPH_N2P
       PPH_HIP(ctx, hipGetLastError());
@@ -2874,8 +3043,13 @@ int pph_launch_fused_kernels(pph_ctx* ctx, MeshData& mesh, const FuseArgs& fa, d
 // rows, with the smoother's diagonal inverses and spectral bounds (no K/M, no coupling blocks, no lifting)
 int pph_launch_level_operators(pph_ctx* ctx, MeshData& mesh, const uint8_t* m1, const uint8_t* m2, const uint8_t* near,
                                int same, double coefK1, double coefK2, double coefM, double* A1, double* A2,
-                               double* dinv1, double* dinv2, unsigned long long* lam, int64_t ell_ld, int ell_sym) {
+                               double* dinv1, double* dinv2, unsigned long long* lam, int64_t ell_ld, int ell_sym,
+                               DictGroup* group, SellDict* dicts, const Sell* views) {
   FuseArgs fa;
+  if (group && dicts && views) {
+    fa.G = group;
+    for (int d = 0; d < 2; ++d) { fa.dicts[d] = &dicts[d]; fa.views[d] = &views[d]; }
+  }
   fuse_set_format(fa, mesh.kind, ell_ld, ell_sym, ell_sym);
   fa.symg = (ell_sym && ctx->world > 1) ? 1 : 0;
   fa.m1 = m1; fa.m2 = m2; fa.near = near;
@@ -2926,15 +3100,27 @@ int pph_launch_assemble_fused(pph_ctx* ctx, int monolithic) {
   fa.lam = ctx->lam0.p;
   fa.keep_km = ctx->asm_keep_km;
   fa.same = ctx->a21_alias ? 1 : 0;
+  if (ell) {
+    fa.G = &ctx->DG;
+    fa.dicts[0] = &ctx->D11; fa.dicts[1] = &ctx->D22; fa.dicts[2] = &ctx->D12;
+    fa.views[0] = &ctx->S11; fa.views[1] = &ctx->S22; fa.views[2] = &ctx->S12;
+  }
   PPH_TRY(pph_launch_fused_kernels(ctx, mesh, fa, ctx->asm_keep_km ? mesh.K.p : nullptr,
                                    ctx->asm_keep_km ? mesh.M.p : nullptr));
   PPH_HIP(ctx, hipGetLastError());
   if (ell) {
-    // row dictionaries of the three stored blocks (sell_dict): built on the first assembly, re-read and checked on the next
+    // row dictionaries of the three stored blocks (sell_dict): built on the first assembly; on the next ones checked by the
+    // assembly kernel itself (the group below) or, failing that, re-read and checked here
+    const int b0 = ctx->n_dict_build;
     PPH_TRY(sell_dict_update(ctx, &ctx->S11, ctx->D11, n));
     PPH_TRY(sell_dict_update(ctx, &ctx->S22, ctx->D22, n));
     PPH_TRY(sell_dict_update(ctx, &ctx->S12, ctx->D12, n));
     if (ctx->a21_alias) ctx->S21 = ctx->S12;
+    if (ctx->n_dict_build != b0) {     // dictionaries (re)built: their fused-check group follows
+      SellDict* ds[3] = {ctx->D11.on ? &ctx->D11 : nullptr, ctx->D22.on ? &ctx->D22 : nullptr, ctx->D12.on ? &ctx->D12 : nullptr};
+      ctx->DG.release();
+      if (ds[0] && ds[1]) PPH_TRY(dict_group_build(ctx, ctx->DG, ds, ds[2] ? 3 : 2, ctx->S11, n));
+    }
   }
   mesh.km_valid = ctx->asm_keep_km != 0;
   ctx->diag0_valid = true;

@@ -91,7 +91,28 @@ struct SellDict {
   int64_t n = 0;
   int px = 0, py = 0, bc_epoch = -1, cap = 0;   // ... and the configuration it was built (or refused) for
   const double* val = nullptr;       // the storage it describes
-  void release() { cls.release(); keys.release(); rep.release(); map.release(); tab.release(); state.release(); ncls = 0; on = tried = false; n = 0; val = nullptr; }
+  // check fused into the assembly (round 4, DictGroup below): which classes meet in which lower slot
+  DevBuf<uint32_t> adj;              // [ncls][S / 2][PPH_DICT_ADJW] bit c' : a row of class c has a row of class c' at its lower slot s (bit PPH_DICT_CAP: none, outside [0, n))
+  DevBuf<int32_t> src;               // [ncls][S]: where tab[c][s] comes from in the group's mini operator (-1: the 0 outside [0, n))
+  bool adj_ok = false;
+  bool checked = false;              // this assembly's rows were checked by the assembly kernel itself
+  void release() { cls.release(); keys.release(); rep.release(); map.release(); tab.release(); state.release(); adj.release(); src.release(); ncls = 0; on = tried = adj_ok = checked = false; n = 0; val = nullptr; }
+};
+#define PPH_DICT_ADJW (PPH_DICT_CAP / 32 + 1)
+#define PPH_DICT_FUSE_CAP 128      // classes per operator up to which the assembly kernel holds the stored halves of the tables in LDS
+// The operators one assembly launch writes together (fine level: A11, A22, A12; a multigrid level: its two operators) and
+// what the fused check needs besides their dictionaries: the representative rows of every class and the rows their lower
+// slots mirror, assembled FIRST into a mini operator of a few hundred rows by the same kernel (k_asm_node2 in listed mode),
+// from which the tables are read; the assembly proper then compares every entry it stores with its row's class entry.
+struct DictGroup {
+  DevBuf<uint32_t> list;             // node of mini row i
+  DevBuf<double> mini;               // [nd][stored slots][ldm]
+  int nlist = 0, nd = 0;
+  int64_t ldm = 0;
+  bool ok = false;
+  int ncls[3] = {0, 0, 0};           // class counts the group was built for
+  const void* cls_of[3] = {nullptr, nullptr, nullptr};
+  void release() { list.release(); mini.release(); nlist = 0; nd = 0; ldm = 0; ok = false; }
 };
 struct Sell {
   const double* val = nullptr;
@@ -217,6 +238,7 @@ struct MgLevel {
   DevBuf<double> own_val[2];     // storage of val[] on coarse levels
   DevBuf<double> own_ell[2];     // stencil-ELL storage of the level operators (op_format 1; level 0 aliases the context's)
   SellDict dict[2];              // row dictionaries of own_ell (sell_dict)
+  DictGroup dgroup;              // ... and their fused-check group
   Sell ell[2];                   // views used by the products when ell[f].val is set
   DevBuf<float> val32[2];        // fp32 copies of val[] for the smoother / residual SpMVs of the V-cycle
   DevBuf<double> dinv[2];
@@ -310,6 +332,8 @@ struct pph_ctx {
   DevBuf<double> E11, E22, E12, E21;
   Sell S11, S22, S12, S21;              // views of E* (S21 == S12 when a21_alias)
   SellDict D11, D22, D12;               // their row dictionaries (sell_dict; S21 shares D12 when aliased, else none)
+  DictGroup DG;                         // fused-check group of the three
+  int dict_fuse = 1;                    // option "sell_dict_fuse": the per-assembly check of every row runs inside the assembly kernel (0: k_dict_verify_sym)
   bool ell_ok = false;                  // S* hold the assembled blocks
   bool csr_ok = false;                  // A11 .. A21 hold the assembled blocks
   DevBuf<double> rhs, u0, sol;          // length 2n
@@ -446,7 +470,8 @@ int pph_launch_assemble_fused(pph_ctx* ctx, int monolithic);
 // A1, A2: CSR value arrays (ell_ld == 0) or stencil-ELL arrays with leading dimension ell_ld
 int pph_launch_level_operators(pph_ctx* ctx, MeshData& mesh, const uint8_t* m1, const uint8_t* m2, const uint8_t* near,
                                int same, double coefK1, double coefK2, double coefM, double* A1, double* A2,
-                               double* dinv1, double* dinv2, unsigned long long* lam, int64_t ell_ld, int ell_sym);
+                               double* dinv1, double* dinv2, unsigned long long* lam, int64_t ell_ld, int ell_sym,
+                               DictGroup* group = nullptr, SellDict* dicts = nullptr, const Sell* views = nullptr);
 void pph_launch_row_near(pph_ctx* ctx, const MeshData& mesh, const uint8_t* m1, const uint8_t* m2, uint8_t* out);   // (stencil walk: no CSR pattern)
 
 // linear algebra on the context stream; all results that feed control flow go through ctx->scal
@@ -551,7 +576,11 @@ static inline double sell_stream_bytes(const pph_ctx* ctx, const Sell& E) {
 }
 // (re)builds the row dictionary of E after its values were (re)written; sets / clears E->dict
 int sell_dict_update(pph_ctx* ctx, Sell* E, SellDict& D, int64_t n);
-int sell_dict_poll(pph_ctx* ctx);   // retires dictionaries a per-assembly check refused on the device (end of a solve)
+int sell_dict_poll(pph_ctx* ctx);
+// fused check (pph_sell.hip): (re)build the group after its dictionaries were built; before an assembly: fill the tables from
+// the mini operator and check the class adjacencies (after the listed launch); `dicts`: up to three, null entries allowed
+int dict_group_build(pph_ctx* ctx, DictGroup& G, SellDict* const* dicts, int nd, const Sell& shape, int64_t n);
+int dict_group_tables(pph_ctx* ctx, DictGroup& G, SellDict* const* dicts, int nd, const Sell& shape);   // retires dictionaries a per-assembly check refused on the device (end of a solve)
 int sell_from_csr(pph_ctx* ctx, const MeshData& mesh, const double* csr_val, DevBuf<double>& buf, Sell* out, int sym);
 // symmetric storage is used for operators that are symmetric on the local box: single context (a slab's ghost rows
 // are empty, which breaks the symmetry of the local matrix) and option sell_sym on

@@ -431,7 +431,7 @@ void mg_release(pph_ctx* ctx) {
     MgLevel& L = ctx->mg[l];
     if (l > 0) L.mesh.release_all();
     for (int f = 0; f < 2; ++f) {
-      L.own_val[f].release(); L.own_ell[f].release(); L.dict[f].release(); L.dinv[f].release(); L.mask[f].release(); L.val32[f].release();
+      L.own_val[f].release(); L.own_ell[f].release(); L.dict[f].release(); L.dgroup.release(); L.dinv[f].release(); L.mask[f].release(); L.val32[f].release();
       L.ell[f] = Sell();
     }
     L.x.release(); L.b.release(); L.r.release(); L.d.release(); L.t.release(); L.w.release();
@@ -597,10 +597,18 @@ int mg_setup(pph_ctx* ctx) {
         PPH_TRY(pph_launch_level_operators(ctx, m, L.maskp[0], L.maskp[1], L.rownear.p, ctx->a21_alias ? 1 : 0, coefK[0],
                                            coefK[1], ctx->b, ell_only ? L.own_ell[0].p : L.own_val[0].p,
                                            ell_only ? L.own_ell[1].p : L.own_val[1].p, L.dinv[0].p, L.dinv[1].p,
-                                           lamdev.p + 2 * l, ell_only ? L.ell[0].ld : 0, ell_only ? L.ell[0].sym : 0));
+                                           lamdev.p + 2 * l, ell_only ? L.ell[0].ld : 0, ell_only ? L.ell[0].sym : 0,
+                                           ell_only ? &L.dgroup : nullptr, ell_only ? L.dict : nullptr, ell_only ? L.ell : nullptr));
         level_fused = true;
-        if (ell_only)
+        if (ell_only) {
+          const int b0 = ctx->n_dict_build;
           for (int f = 0; f < 2; ++f) PPH_TRY(sell_dict_update(ctx, &L.ell[f], L.dict[f], L.n));
+          if (ctx->n_dict_build != b0) {     // dictionaries (re)built: their fused-check group follows
+            SellDict* ds[2] = {L.dict[0].on ? &L.dict[0] : nullptr, L.dict[1].on ? &L.dict[1] : nullptr};
+            L.dgroup.release();
+            if (ds[0] && ds[1]) PPH_TRY(dict_group_build(ctx, L.dgroup, ds, 2, L.ell[0], L.n));
+          }
+        }
       } else {
         for (int f = 0; f < 2; ++f) {
           pph_launch_scalar_block(ctx, m, L.maskp[f], coefK[f], ctx->b, L.own_val[f].p);

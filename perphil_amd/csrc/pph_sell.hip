@@ -12,6 +12,7 @@
 // + 16 nrows (x read once, y written once).
 #include "pph_internal.h"
 #include <chrono>
+#include <vector>
 
 __device__ inline double sell_wave_sum(double v) {
 #pragma unroll
@@ -889,7 +890,7 @@ static void dict_launch_verify(pph_ctx* ctx, const Sell& E, SellDict& D, int64_t
 int sell_dict_update(pph_ctx* ctx, Sell* E, SellDict& D, int64_t n) {
   E->dict = nullptr;
   const bool want = ctx->sell_dict && E->val && E->sym && n >= ctx->sell_dict_min_rows && ctx->sell_rpt != 1;
-  if (!want) { D.on = false; return PPH_OK; }
+  if (!want) { D.on = false; D.checked = false; return PPH_OK; }
   const bool same = D.val == E->val && D.n == n && D.px == E->px && D.py == E->py && D.bc_epoch == ctx->bc_epoch &&
                     D.cap == ctx->sell_dict_cap;
   // refused for this mesh and these Dirichlet sets (too many distinct rows / a failed check): not tried again.  A dictionary
@@ -899,6 +900,12 @@ int sell_dict_update(pph_ctx* ctx, Sell* E, SellDict& D, int64_t n) {
   const int64_t pxy = (int64_t)E->px * E->py;
   const int grid = sell_grid(n);
   const int cap = ctx->sell_dict_cap < PPH_DICT_CAP ? (ctx->sell_dict_cap < 1 ? 1 : ctx->sell_dict_cap) : PPH_DICT_CAP;
+  if (same && D.on && D.checked) {
+    // re-assembly whose kernel compared every entry it stored with the table read from the mini operator (facts A and B above)
+    D.checked = false;
+    E->dict = &D;
+    return PPH_OK;
+  }
   if (same && D.on) {
     // re-assembly: same classes expected - re-read the table from the representatives, check every row
     hipLaunchKernelGGL(k_dict_table, dim3(1), dim3(256), 0, ctx->stream, E->val, E->ld, E->sym, st, E->px, pxy, n, D.keys.p,
@@ -936,9 +943,163 @@ int sell_dict_update(pph_ctx* ctx, Sell* E, SellDict& D, int64_t n) {
   D.on = h[1] == 1;
   D.status = h[1];
   D.tried = true;
+  D.adj_ok = false; D.checked = false;     // (the group is rebuilt by the caller: dict_group_build)
   D.val = E->val; D.n = n; D.px = E->px; D.py = E->py; D.bc_epoch = ctx->bc_epoch; D.cap = ctx->sell_dict_cap;
   if (D.on != was_on || D.ncls != was_ncls) la_release_graphs(ctx);   // captured launches carry the old class count
   if (D.on) E->dict = &D;
+  return PPH_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Check fused into the assembly (round 4).  k_dict_verify_sym read every stored value again (1.9 GB per fine operator, 1.6 ms
+// per 256^3 step).  The same guarantee - every coefficient a product takes from the table equals, bit for bit, the one the
+// stored-value kernel would load - follows from two cheaper facts:
+//   A. every STORED entry of every row equals the stored half of its class's table row: checked by the assembly kernel on
+//      the value it is about to store (k_asm_node2 in check mode, pph_assemble.hip);
+//   B. for every pair of classes (c, c') that meet - some row of class c has a row of class c' at its lower slot s - the lower
+//      half of the table agrees with the mirror: tab[c][s] == tab[c'][S - 1 - s] (and == 0 where the slot leaves [0, n)):
+//      which classes meet where depends on the class arrays alone, is recorded once at build time (k_dict_adj) and checked
+//      per assembly on the tables (k_dict_tables_check, one workgroup).
+// A lower coefficient of row r is the mirror entry stored with row r + o; A makes that tab[cls[r + o]][S - 1 - s], B makes it
+// tab[cls[r]][s].  For A the table must exist BEFORE the assembly proper: the representative row of every class and the
+// rows its lower slots mirror are assembled first into a mini operator (k_asm_node2 in listed mode, a few hundred rows) and
+// the tables are read from there (DictGroup).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dict_adj(const uint16_t* __restrict__ cls, Stencil st, int px, int64_t pxy, int64_t n,
+                                                  uint32_t* adj, const int* __restrict__ state) {
+  if (state[1] != 1) return;
+  const int C0 = st.count / 2;
+  const int64_t nr = (n + 63) & ~(int64_t)63;      // (whole waves: the wave-uniform shortcut below needs all 64 lanes)
+  for (int64_t row = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; row < nr; row += (int64_t)gridDim.x * blockDim.x) {
+    const bool live = row < n;
+    const int c = live ? (int)cls[row] : -1;
+    for (int s = 0; s < C0; ++s) {
+      const int64_t rr = row + sell_off(st, s, px, pxy);
+      const int cp = !live ? -1 : ((rr >= 0 && rr < n) ? (int)cls[rr] : PPH_DICT_CAP);
+      // almost every wave holds ONE (class, neighbour class) pair per slot: one lane looks the bit up, not 64 (17 M rows
+      // polling the same few words took 2.9 ms per operator)
+      const int c0 = __builtin_amdgcn_readfirstlane(c), cp0 = __builtin_amdgcn_readfirstlane(cp);
+      const bool uni = __all(c == c0 && cp == cp0);
+      if (uni && (threadIdx.x & 63) != 0) continue;
+      if (!live) continue;
+      uint32_t* w = adj + ((int64_t)c * C0 + s) * PPH_DICT_ADJW + (cp >> 5);
+      const uint32_t bit = 1u << (cp & 31);
+      if (!(__atomic_load_n(w, __ATOMIC_RELAXED) & bit)) atomicOr(w, bit);
+    }
+  }
+}
+
+// tab[c][s] <- mini[src[c][s]] (0 where src < 0), then fact B on the finished table.  One workgroup per dictionary.
+__global__ __launch_bounds__(256) void k_dict_tables_check(const double* __restrict__ mini, const int32_t* __restrict__ src,
+                                                           double* __restrict__ tab, const uint32_t* __restrict__ adj, int S,
+                                                           int ncls, int* state, int* alarm) {
+  const int C0 = S / 2;
+  for (int i = threadIdx.x; i < ncls * S; i += 256) tab[i] = src[i] >= 0 ? mini[src[i]] : 0.0;
+  __syncthreads();
+  bool bad = false;
+  for (int i = threadIdx.x; i < ncls * C0; i += 256) {
+    const int c = i / C0, s = i % C0;
+    const long long mine = __double_as_longlong(tab[c * S + s]);
+    const uint32_t* w = adj + (int64_t)i * PPH_DICT_ADJW;
+    for (int cp = 0; cp <= PPH_DICT_CAP; ++cp) {
+      if (!((w[cp >> 5] >> (cp & 31)) & 1u)) continue;
+      const long long other = cp == PPH_DICT_CAP ? 0ll : (cp < ncls ? __double_as_longlong(tab[cp * S + (S - 1 - s)]) : ~mine);
+      bad |= mine != other;
+    }
+  }
+  if (threadIdx.x == 0) { state[0] = ncls; }
+  if (bad) {
+    atomicExch(state + 1, -2);
+    if (alarm) __hip_atomic_store(alarm, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// After the dictionaries of a group were built: the adjacency bit sets, the list of rows whose entries fill the tables and,
+// per dictionary, where each table entry sits in the mini operator.  Synchronises (build path only).
+int dict_group_build(pph_ctx* ctx, DictGroup& G, SellDict* const* dicts, int nd, const Sell& shape, int64_t n) {
+  G.ok = false;
+  const Stencil st = make_stencil(shape.kind);
+  const int S = st.count, C0 = S / 2, SS = S - C0;
+  const int64_t pxy = (int64_t)shape.px * shape.py;
+  if (!ctx->dict_fuse || !shape.sym) return PPH_OK;
+  for (int d = 0; d < nd; ++d)
+    if (dicts[d] && (!dicts[d]->on || dicts[d]->ncls > PPH_DICT_FUSE_CAP)) return PPH_OK;
+  std::vector<uint32_t> list;
+  std::vector<int64_t> keys;                      // node of list entry i (linear search is fine: a few hundred entries)
+  auto index_of = [&](int64_t node) -> int {
+    for (size_t i = 0; i < keys.size(); ++i) if (keys[i] == node) return (int)i;
+    keys.push_back(node);
+    list.push_back((uint32_t)node);
+    return (int)keys.size() - 1;
+  };
+  std::vector<std::vector<int64_t>> reps((size_t)nd);
+  for (int d = 0; d < nd; ++d) {
+    SellDict* D = dicts[d];
+    if (!D) continue;
+    reps[(size_t)d].resize((size_t)D->ncls);
+    PPH_HIP(ctx, hipMemcpyAsync(reps[(size_t)d].data(), D->rep.p + PPH_DICT_HASH, sizeof(int64_t) * (size_t)D->ncls, hipMemcpyDeviceToHost,
+                                ctx->stream));
+  }
+  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // first pass: the list (so that the mini operator's leading dimension is known), second pass: the source indices
+  for (int pass = 0; pass < 2; ++pass) {
+    const int64_t ldm = sell_ld((int64_t)list.size());
+    for (int d = 0; d < nd; ++d) {
+      SellDict* D = dicts[d];
+      if (!D) continue;
+      std::vector<int32_t> src((size_t)D->ncls * S, -1);
+      for (int c = 0; c < D->ncls; ++c) {
+        const int64_t r = reps[(size_t)d][(size_t)c];
+        const int ir = index_of(r);
+        for (int s = 0; s < S; ++s) {
+          if (s >= C0) { src[(size_t)c * S + s] = (int32_t)((int64_t)(s - C0) * ldm + ir); continue; }
+          const int64_t rr = r + (int64_t)st.d[s][0] + (int64_t)st.d[s][1] * shape.px + (int64_t)st.d[s][2] * pxy;
+          if (rr < 0 || rr >= n) continue;
+          src[(size_t)c * S + s] = (int32_t)((int64_t)(S - 1 - s - C0) * ldm + index_of(rr));
+        }
+      }
+      if (pass == 1) {
+        PPH_TRY(D->src.alloc(ctx, src.size()));
+        PPH_HIP(ctx, hipMemcpyAsync(D->src.p, src.data(), sizeof(int32_t) * src.size(), hipMemcpyHostToDevice, ctx->stream));
+        PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));     // (src is a local)
+      }
+    }
+  }
+  G.nlist = (int)list.size();
+  G.ldm = sell_ld((int64_t)G.nlist);
+  G.nd = nd;
+  PPH_TRY(G.list.alloc(ctx, (size_t)G.ldm));
+  list.resize((size_t)G.ldm, list.empty() ? 0u : list[0]);     // padding rows repeat a valid node
+  PPH_HIP(ctx, hipMemcpyAsync(G.list.p, list.data(), sizeof(uint32_t) * list.size(), hipMemcpyHostToDevice, ctx->stream));
+  PPH_TRY(G.mini.alloc(ctx, (size_t)3 * SS * (size_t)G.ldm));
+  PPH_HIP(ctx, hipMemsetAsync(G.mini.p, 0, sizeof(double) * (size_t)3 * SS * (size_t)G.ldm, ctx->stream));
+  for (int d = 0; d < nd; ++d) {
+    SellDict* D = dicts[d];
+    G.ncls[d] = D ? D->ncls : 0;
+    G.cls_of[d] = D ? (const void*)D->cls.p : nullptr;
+    if (!D) continue;
+    PPH_TRY(D->adj.alloc(ctx, (size_t)D->ncls * C0 * PPH_DICT_ADJW));
+    PPH_HIP(ctx, hipMemsetAsync(D->adj.p, 0, sizeof(uint32_t) * (size_t)D->ncls * C0 * PPH_DICT_ADJW, ctx->stream));
+    hipLaunchKernelGGL(k_dict_adj, dim3(sell_grid(n)), dim3(256), 0, ctx->stream, D->cls.p, st, shape.px, pxy, n, D->adj.p, D->state.p);
+    D->adj_ok = true;
+  }
+  PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  PPH_HIP(ctx, hipGetLastError());
+  G.ok = true;
+  return PPH_OK;
+}
+
+// before the assembly proper, after the listed launch has filled G.mini: tables + fact B, one small launch per dictionary
+int dict_group_tables(pph_ctx* ctx, DictGroup& G, SellDict* const* dicts, int nd, const Sell& shape) {
+  const int S = sell_slots(shape.kind), SS = S - S / 2;
+  for (int d = 0; d < nd; ++d) {
+    SellDict* D = dicts[d];
+    if (!D) continue;
+    hipLaunchKernelGGL(k_dict_tables_check, dim3(1), dim3(256), 0, ctx->stream, G.mini.p + (size_t)d * SS * (size_t)G.ldm, D->src.p, D->tab.p,
+                       D->adj.p, S, D->ncls, D->state.p, ctx->dict_alarm_dev);
+    D->checked = true;
+  }
+  PPH_HIP(ctx, hipGetLastError());
   return PPH_OK;
 }
 
