@@ -651,6 +651,27 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
   if (!strcmp(name, "sell_dict_blocks")) { ctx->sell_dict_blocks = (int)value; la_release_graphs(ctx); return PPH_OK; }
   if (!strcmp(name, "sell_dict_zwalk")) { ctx->sell_dict_zwalk = (int)value; la_release_graphs(ctx); return PPH_OK; }
   if (!strcmp(name, "sell_dict_fuse")) { ctx->dict_fuse = value != 0.0 ? 1 : 0; return PPH_OK; }
+  if (!strcmp(name, "sell_dict_corrupt_row")) {
+    // tests: move one row of A11 into another class ON THE DEVICE - the next assembly's fused check must notice that the
+    // entries it stores for that row are not its class's and refuse the dictionary
+    PPH_REQUIRE(ctx, ctx->D11.on && ctx->D11.cls.p && value >= 0 && (int64_t)value < ctx->n && ctx->D11.ncls > 1, "no dictionary to corrupt");
+    uint16_t c = 0;
+    PPH_HIP(ctx, hipMemcpy(&c, ctx->D11.cls.p + (int64_t)value, sizeof(c), hipMemcpyDeviceToHost));
+    // (another class whose STORED half differs: classes that differ in their mirrored lower half only meet the row through the
+    // class adjacencies recorded at build time, which assume what holds outside this test - class arrays do not change)
+    const int S = sell_slots(ctx->S11.kind), C0 = S / 2;
+    std::vector<double> tab((size_t)ctx->D11.ncls * S);
+    PPH_HIP(ctx, hipMemcpy(tab.data(), ctx->D11.tab.p, sizeof(double) * tab.size(), hipMemcpyDeviceToHost));
+    int pick = -1;
+    for (int k = 1; k < ctx->D11.ncls && pick < 0; ++k) {
+      const int cc = (c + k) % ctx->D11.ncls;
+      if (memcmp(&tab[(size_t)cc * S + C0], &tab[(size_t)c * S + C0], sizeof(double) * (size_t)(S - C0)) != 0) pick = cc;
+    }
+    PPH_REQUIRE(ctx, pick >= 0, "no class with another stored half");
+    c = (uint16_t)pick;
+    PPH_HIP(ctx, hipMemcpy(ctx->D11.cls.p + (int64_t)value, &c, sizeof(c), hipMemcpyHostToDevice));
+    return PPH_OK;
+  }
   if (!strcmp(name, "sell_dict_cap")) { ctx->sell_dict_cap = (int)value; return PPH_OK; }
   if (!strcmp(name, "sell_dict_walk")) { ctx->sell_dict_walk = value != 0; la_release_graphs(ctx); return PPH_OK; }
   if (!strcmp(name, "sell_dict_poison")) {

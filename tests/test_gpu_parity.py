@@ -1591,6 +1591,58 @@ def test_row_dictionary_comes_back_after_being_switched_off_and_retires_after_a_
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("which", ["interior", "near_boundary"])
+def test_fused_dictionary_check_refuses_a_row_that_left_its_class(gpu_ctx_factory, which):
+    """Round 4: the per-assembly check of the row dictionaries runs inside the assembly kernel (pph_sell.hip, "check fused into
+    the assembly": tables from the representative rows assembled first, every stored entry compared with its class's entry
+    before it is stored - the rows of general-form waves read back once -, class adjacencies checked on the tables).  A re-assembly
+    with other coefficients keeps the dictionaries without any k_dict_verify pass; one row moved into another class on the
+    device (an interior row: the compare inside the straight-line launch; a row next to the boundary: the read-back of the
+    general-form rows) makes the NEXT assembly refuse A11's dictionary - and only that one -, the solve still equals the
+    stored-value solve bit for bit and the host retires the dictionary at the end of it."""
+    f = _ffi()
+    import perphil_amd.fd as fdm
+
+    N = 64      # 274 625 rows per block: the two-launch node kernel (asm_node_split_min 200 000), i.e. the fused check's path
+    mesh = fdm.UnitCubeMesh(N, N, N, hexahedral=True)
+    b = mesh.boundary_nodes()
+    g1, g2 = o.exact_pressures(mesh.node_coordinates(b), P)
+    cfg = _cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_MG, inner_rtol=1e-10, inner_reduction=1e-1, inner_norm=1,
+               mg_smooth=1, picard_rtol=1e-8)
+    ref = None
+    for fuse in (0, 1):
+        ctx = gpu_ctx_factory()
+        ctx.set_option("sell_dict_min_rows", 100000)
+        ctx.set_option("sell_dict_fuse", fuse)
+        ctx.mesh_build(3, f.CELL_HEX, N, N, N)
+        ctx.set_dirichlet(0, b, g1)
+        ctx.set_dirichlet(1, b, g2)
+        ctx.assemble(P.k1, 3.0 * P.k2, P.beta, P.mu, monolithic=False)      # builds the dictionaries (+ the fused-check group)
+        ctx.assemble(P.k1, P.k2, P.beta, P.mu, monolithic=False)            # other coefficients: same classes, new tables
+        t = ctx.timers()
+        assert t["dict_operators"] >= 3 and t["dict_status"] == 1, t
+        x, info, hist = ctx.solve(cfg, hist_cap=32)
+        assert info.converged and ctx.timers()["dict_operators"] >= 3
+        if ref is None:
+            ref = (x.copy(), hist.copy(), (info.iterations, info.inner_iterations))
+            ctx.close()
+            continue
+        np.testing.assert_array_equal(x, ref[0])        # fused check or verify pass: the same operators, the same products
+        np.testing.assert_array_equal(hist, ref[1])
+        px = N + 1
+        row = (px // 2) + px * ((px // 2) + px * (px // 2)) if which == "interior" else 1 + px * ((px // 2) + px * (px // 2))
+        before = ctx.timers()["dict_operators"]
+        ctx.set_option("sell_dict_corrupt_row", row)
+        ctx.assemble(P.k1, P.k2, P.beta, P.mu, monolithic=False)            # the fused check meets the moved row
+        x2, info2, hist2 = ctx.solve(cfg, hist_cap=32)
+        assert info2.converged
+        np.testing.assert_array_equal(x2, ref[0])       # the refused dictionary's products took the stored values
+        t = ctx.timers()
+        assert t["dict_status"] == -2 and t["dict_operators"] == before - 1, t
+        ctx.close()
+
+
+@pytest.mark.gpu
 def test_large_results_come_back_in_pinned_arrays_that_are_safe_to_keep(gpu_ctx_factory):
     """Context.solution() / solve(fetch=True) hand large results out in page-locked arrays from a pool of three per context
     (pph_host_alloc): an array somebody still refers to - directly or through a view - is never written again, one that
