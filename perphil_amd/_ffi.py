@@ -18,7 +18,7 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libperphil_hip.so")
+LIB_PATH = os.environ.get("PERPHIL_HIP_LIB") or os.path.join(_HERE, "libperphil_hip.so")   # (the override: A/B builds of tools/)
 
 PPH_OK, PPH_ERR_INVALID, PPH_ERR_HIP, PPH_ERR_NOMEM, PPH_ERR_DIVERGED, PPH_ERR_COMM = 0, -1, -2, -3, -4, -5
 CELL_QUAD, CELL_TRI, CELL_HEX, CELL_TET = 0, 1, 2, 3

@@ -650,6 +650,9 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
   if (!strcmp(name, "sell_dict_min_rows")) { ctx->sell_dict_min_rows = (int64_t)value; return PPH_OK; }
   if (!strcmp(name, "sell_dict_blocks")) { ctx->sell_dict_blocks = (int)value; la_release_graphs(ctx); return PPH_OK; }
   if (!strcmp(name, "sell_dict_zwalk")) { ctx->sell_dict_zwalk = (int)value; la_release_graphs(ctx); return PPH_OK; }
+#ifdef PPH_DW_STAMPS
+  if (!strcmp(name, "dw_stamps")) return sell_dw_stamps(ctx, value != 0.0);
+#endif
   if (!strcmp(name, "sell_dict_fuse")) { ctx->dict_fuse = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "sell_dict_corrupt_row")) {
     // tests: move one row of A11 into another class ON THE DEVICE - the next assembly's fused check must notice that the

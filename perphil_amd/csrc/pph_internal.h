@@ -577,6 +577,9 @@ static inline double sell_stream_bytes(const pph_ctx* ctx, const Sell& E) {
 // (re)builds the row dictionary of E after its values were (re)written; sets / clears E->dict
 int sell_dict_update(pph_ctx* ctx, Sell* E, SellDict& D, int64_t n);
 int sell_dict_poll(pph_ctx* ctx);
+#ifdef PPH_DW_STAMPS
+int sell_dw_stamps(pph_ctx* ctx, int on);   // diagnostic build (tools/r4_dict_stamps.py)
+#endif
 // fused check (pph_sell.hip): (re)build the group after its dictionaries were built; before an assembly: fill the tables from
 // the mini operator and check the class adjacencies (after the listed launch); `dicts`: up to three, null entries allowed
 int dict_group_build(pph_ctx* ctx, DictGroup& G, SellDict* const* dicts, int nd, const Sell& shape, int64_t n);

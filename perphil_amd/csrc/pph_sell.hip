@@ -399,6 +399,9 @@ __device__ __forceinline__ void dictw_step(const double (&lo)[3][4], const doubl
   {
     const int cb[2] = {(int)(o.cls2 & 0xffffu) * 27, (int)(o.cls2 >> 16) * 27};
     int slot = 0;
+#ifdef PPH_DW_SPLITACC
+    double pa[3][2] = {{0.0, 0.0}, {0.0, 0.0}, {0.0, 0.0}};
+#endif
 #pragma unroll
     for (int l = 0; l < 9; ++l) {
       const double (&win)[3][4] = (l < 3) ? lo : (l < 6 ? mid : hi);
@@ -408,14 +411,28 @@ __device__ __forceinline__ void dictw_step(const double (&lo)[3][4], const doubl
 #pragma unroll
         for (int i = 0; i < 2; ++i) v[i] = dtab[cb[i] + slot];   // (a row that is not active reads class 0 and is not stored)
 #pragma unroll
+#ifdef PPH_DW_SPLITACC
+        for (int i = 0; i < 2; ++i) pa[l / 3][i] += v[i] * win[l % 3][i + d];
+#else
         for (int i = 0; i < 2; ++i) acc[i] += v[i] * win[l % 3][i + d];
+#endif
         ++slot;
       }
     }
+#ifdef PPH_DW_SPLITACC
+    for (int i = 0; i < 2; ++i) acc[i] = (pa[0][i] + pa[1][i]) + pa[2][i];
+#endif
   }
   sell_epilogue<MODE, 2>(acc, o.bv, xr, o.dv, o.tv, o.av, act, w, y, aux, z0, r0, dotacc, dlo, dhi, dotx, 0);   // (no store-hint experiments here: a branch around the stores costs the pipelining)
 }
 
+#ifdef PPH_DW_STAMPS
+// diagnostic build only (tools/r4_dict_stamps.py): s_memtime stamps of one wave per workgroup into a buffer nothing else reads
+__device__ unsigned long long* g_dw_stamps = nullptr;
+#define PPH_DW_STAMP(I) do { if (stp && (I) < 60) stp[(I)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define PPH_DW_STAMP(I) do { } while (0)
+#endif
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_spmv_dict_walk(const double* __restrict__ val, int64_t ld,
                                                         const double* __restrict__ x, const double* __restrict__ b,
@@ -425,11 +442,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
                                                         double* __restrict__ part, int64_t dlo, int64_t dhi, int flags,
                                                         SellDictArgs da) {
   extern __shared__ double dtab[];
+#ifdef PPH_DW_STAMPS
+  unsigned long long* stp = (g_dw_stamps && threadIdx.x == 0) ? g_dw_stamps + (size_t)blockIdx.x * 64 : nullptr;
+  int sti = 3;
+  PPH_DW_STAMP(0);
+#endif
   const bool dok = da.state[0] == da.ncls && da.state[1] == 1;
   if (dok) {
     for (int i = threadIdx.x; i < da.ncls * 27; i += 256) dtab[i] = da.tab[i];
     __syncthreads();
   }
+  PPH_DW_STAMP(1);
   const double w = (MODE == 3 || MODE == 4 || ((MODE == 5 || MODE == 6) && z0)) ? *wp : 0.0;
   double dotacc = 0.0;
   double dotx[2] = {0.0, 0.0};
@@ -487,6 +510,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
       O0 = O1;                                                                                                    \
       ++z;                                                                                                        \
     } while (0)
+#ifdef PPH_DW_STAMPS
+    PPH_DW_STAMP(2);      // range located, first three planes + operands requested
+#endif
     if (z == 0 && z < zend) PPH_DW_SINGLE();   // (plane 0 needs the clamped loads: one step outside the 4-step loop)
     if (pos * 512 + 512 <= pxy) {   // every lane has both rows in the plane
       while (z + 4 <= zend && z + 5 <= planes - 2 && z >= 1) {
@@ -495,9 +521,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
         PPH_DW_LOAD(B, z + 4); PPH_DW_FETCHA(O1, z + 3); PPH_DW_STEPA(C, D, A, O0, z + 2);
         PPH_DW_LOAD(C, z + 5); PPH_DW_FETCHA(O0, z + 4); PPH_DW_STEPA(D, A, B, O1, z + 3);
         z += 4;
+#ifdef PPH_DW_STAMPS
+        PPH_DW_STAMP(sti); ++sti;      // one stamp per four steps
+#endif
       }
     }
+#ifdef PPH_DW_STAMPS
+    PPH_DW_STAMP(sti); if (stp) stp[61] = (unsigned long long)sti; ++sti;
+#endif
     while (z < zend) PPH_DW_SINGLE();
+#ifdef PPH_DW_STAMPS
+    PPH_DW_STAMP(sti); ++sti;
+#endif
 #undef PPH_DW_SINGLE
 #undef PPH_DW_LOADC
 #undef PPH_DW_LOAD
@@ -506,6 +541,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
 #undef PPH_DW_FETCHA
 #undef PPH_DW_STEPA
   }
+#ifdef PPH_DW_STAMPS
+  if (stp) { stp[62] = __builtin_amdgcn_s_memtime(); stp[63] = (unsigned long long)__builtin_amdgcn_s_memrealtime(); }
+#endif
   if (MODE == 2 || MODE >= 4) {
     __shared__ double lds[4];
     dotacc = sell_wave_sum(dotacc);
@@ -524,6 +562,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
     }
   }
 }
+
+#ifdef PPH_DW_STAMPS
+// (diagnostic build) the stamps go to the context's right-hand-side vector, which the isolated product loop does not touch
+int sell_dw_stamps(pph_ctx* ctx, int on) {
+  unsigned long long* p = on ? reinterpret_cast<unsigned long long*>(ctx->rhs.p) : nullptr;
+  if (on) PPH_HIP(ctx, hipMemsetAsync(ctx->rhs.p, 0, sizeof(double) * 2 * (size_t)ctx->n, ctx->stream));
+  PPH_HIP(ctx, hipMemcpyToSymbol(HIP_SYMBOL(g_dw_stamps), &p, sizeof(p)));
+  return PPH_OK;
+}
+#endif
 
 // launches the walk kernel for a whole-operator product on a usable dictionary; returns the grid, 0 = not applicable
 static int sell_launch_dict_walk(pph_ctx* ctx, int mode, const Sell& E, const double* x, const double* b, const double* dinv,
