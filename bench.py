@@ -395,7 +395,7 @@ def main():
     ap.add_argument("--inner-max-it", type=int, default=50000, help="iteration limit of a block solve (A/B experiments)")
     ap.add_argument("--asm-kernel", type=int, default=2)
     ap.add_argument("--set", action="append", default=[], metavar="NAME=VALUE",
-                    help="extra pph_set_option settings for A/B runs (e.g. spmv_kernel=8)")
+                    help="extra pph_set_option settings for A/B runs (e.g. sell_dict=0)")
     ap.add_argument("--skip-fine-bench", action="store_true", help="omit the isolated fine-level SpMV loop (PMC passes)")
     ap.add_argument("--skip-csr", action="store_true", help="omit the extra untimed step on the CSR operator format")
     ap.add_argument("--halo-overlap", type=int, default=1, choices=(0, 1, 2),

@@ -277,7 +277,6 @@ int pph_get_timers(pph_ctx* ctx, double* out, int n);
  *   "sell_zwalk" [4], "sell_zwalk_min_chunks" [5500], "sell_xmap" [1]   symmetric product on large 3D levels: a workgroup
  *                        walks this many node planes at one in-plane position (>= 1000: a balanced share of a whole z
  *                        column); the in-plane positions of one XCD's workgroups are consecutive
- *   "spmv_kernel" [3]    CSR SpMV variant; values other than 3 need a library built with EXPERIMENTS=1
  *   "spmv_lanes" [0 = automatic, 4..64 lanes per CSR row], "spmv_blocks" [0 = 1024 workgroups], "spmv_bench_mode" [0]
  *   "time_spmv" [0]      1: bracket every SpMV launch of a solve with a HIP event pair on the context stream
  *   "asm_kernel" [2]     multilinear assembly: 0 cell-centred scatter-add (atomics), 1 node-centred gather, 2 fused kernels

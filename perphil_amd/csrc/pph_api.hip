@@ -488,9 +488,6 @@ int pph_spmv_bench(pph_ctx* ctx, int which, int reps, double* avg_ms) {
   if (!select_sell_only(ctx, which, &A)) {
     PPH_TRY(select_csr(ctx, which, &A));
     A.lanes = pph_pick_lanes(ctx, A.nnz, A.nrows);
-#ifdef PPH_EXPERIMENTS
-    if (ctx->spmv_kernel == 16) return la_padded_experiment(ctx, A, reps, avg_ms);  // padded-row experiment
-#endif
     PPH_TRY(attach_sell(ctx, which, &A));
   }
   DevBuf<double> x, y;
@@ -548,17 +545,6 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
     const int v = (int)value;
     PPH_REQUIRE(ctx, v == 0 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64, "spmv_lanes must be 0,4,8,16,32,64");
     ctx->spmv_lanes_override = v;
-    return PPH_OK;
-  }
-  if (!strcmp(name, "spmv_kernel")) {
-    const int v = (int)value;
-#ifdef PPH_EXPERIMENTS
-    PPH_REQUIRE(ctx, (v >= 0 && v <= 17), "spmv_kernel: 0 vector, 1 vector+preload, 2 LDS stream, 3 aligned-wide (default), 4 LDS-transposed, 5-7 multi-row, 8 aligned-wide XCD-contiguous, 10 no-gather probe");
-#else
-    PPH_REQUIRE(ctx, v == 3, "spmv_kernel %d is an A/B variant: this library was built without PPH_EXPERIMENTS "
-                             "(make -C perphil_amd/csrc EXPERIMENTS=1)", v);
-#endif
-    ctx->spmv_kernel = v;
     return PPH_OK;
   }
   if (!strcmp(name, "mg_replicate_below")) {
@@ -621,19 +607,6 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
   if (!strcmp(name, "part_cap")) {   // tests: partial sums one (split) product may write in total
     PPH_REQUIRE(ctx, value >= 32 && value <= PPH_PART_STRIDE && ((int)value % 32) == 0, "part_cap must be a multiple of 32 in [32, %d]", PPH_PART_STRIDE);
     ctx->part_cap = (int)value; la_release_graphs(ctx); return PPH_OK;
-  }
-  if (!strcmp(name, "sell_patch")) {
-#ifndef PPH_EXPERIMENTS
-    PPH_REQUIRE(ctx, value == 0.0, "sell_patch needs a library built with EXPERIMENTS=1");
-#endif
-    ctx->sell_patch = value != 0.0 ? 1 : 0; la_release_graphs(ctx); return PPH_OK;
-  }
-  if (!strcmp(name, "sell_patch_z")) { ctx->sell_patch_z = value >= 1 ? (int)value : 1; la_release_graphs(ctx); return PPH_OK; }
-  if (!strcmp(name, "sell_lds")) {
-#ifndef PPH_EXPERIMENTS
-    PPH_REQUIRE(ctx, value == 0.0, "sell_lds needs a library built with EXPERIMENTS=1");
-#endif
-    ctx->sell_lds = (value == 2.0) ? 2 : (value != 0.0 ? 1 : 0); la_release_graphs(ctx); return PPH_OK;
   }
   if (!strcmp(name, "sell_flags")) { ctx->sell_flags = (int)value; la_release_graphs(ctx); return PPH_OK; }
   if (!strcmp(name, "sell_group")) { ctx->sell_group = (int)value; return PPH_OK; }

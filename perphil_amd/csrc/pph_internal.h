@@ -421,7 +421,6 @@ struct pph_ctx {
   int64_t mg_replicate_cap = 1000000;
   int mg_fp32 = 0;                      // 1: V-cycle SpMVs read fp32 copies of the operator values (8 instead of 12 B per non-zero)
   int asm_kernel = 2;                   // multilinear cells: 2 two-pass (element rows + node gather, default), 1 one-pass node gather, 0 cell-centred atomic scatter-add
-  int spmv_kernel = 3;                  // 3: aligned-wide CSR-vector (default); 0,1,2,4..8,10: variants kept for A/B runs
   // operator format of the scalar blocks inside the block solves / Picard sweeps: 1 stencil-ELL (pph_sell.hip), 0 CSR
   int op_format = 1;
   int sell_sym_slabs = 1;               // ... also on slabs (0: full storage there)
@@ -429,8 +428,6 @@ struct pph_ctx {
   int64_t sell_zwalk_min_chunks = 5500; // levels with fewer 512-row chunks keep the plain chunk order (measured: 128^3 = 4200 chunks loses 4 % with the z-walk, 144^3 = 5950 equal, 160^3 gains 8 %, 192^3 4 %, 256^3 20 %)
   int sell_zwalk = 4;                   // > 0 (symmetric operators, 3D): a workgroup walks this many consecutive node planes at one in-plane position
   int sell_xmap = 1;                    // z-walk: consecutive in-plane positions on one XCD
-  int sell_patch = 0, sell_patch_z = 16; // (EXPERIMENTS build) a wave climbs a 16 x 8 patch, mirrors of its own rows from wave-private LDS; planes per climb
-  int sell_lds = 0;                     // (EXPERIMENTS build) symmetric 27-point operators on z-walk levels: mirrored values handed over through LDS
   int sell_flags = 0;                   // experiments: 1 non-temporal y stores (mode 0), 2 non-temporal loads of the diagonal slot
   int sell_dict = 1;                    // row dictionaries for the stencil-ELL blocks (struct SellDict)
   int64_t sell_dict_min_rows = 1000000; // ... of operators with at least this many rows
@@ -534,7 +531,6 @@ void la_dot2(pph_ctx* ctx, const double* x, const double* y, const double* z, in
 void la_cg_update(pph_ctx* ctx, double* x, double* r, double* z, const double* p, const double* q,
                   const double* dinv, double alpha, int64_t n, int slot, Seg sg);
 void la_extract_diag_inv(pph_ctx* ctx, const Csr& A, double* dinv);
-int la_padded_experiment(pph_ctx* ctx, const Csr& A, int reps, double* avg_ms);  // timing experiment (spmv_kernel 16)
 // fetch `count` reduction results starting at slot into ctx->h_scal (synchronises the stream)
 int la_fetch(pph_ctx* ctx, int slot, int count);
 // ghost planes of v <- owner's values (no-op without neighbours / communicator)

@@ -184,9 +184,6 @@ static int stream_T(int max_row) {
   return T;
 }
 
-#ifdef PPH_EXPERIMENTS
-#include "experiments/pph_spmv_experiments.inc"   // the A/B kernel variants of DESIGN.md section 4 (not part of the shipped library)
-#endif
 
 // Stencil-ELL product of a slab whose operand needs its ghost planes refreshed.  halo_overlap 0: exchange, then one
 // launch.  1 / 2: three launches - the chunks whose rows read no ghost value ("interior": everything but the two node
@@ -315,13 +312,7 @@ static int spmv_dispatch(pph_ctx* ctx, const Csr& A, const double* x, const doub
     if (A.nrows >= ctx->mesh.n) { ctx->n_spmv_fine++; ctx->spmv_bytes_fine += bytes_per_nnz * (double)A.nnz + 20.0 * (double)A.nrows; }
     return grid;
   }
-  if (ctx->spmv_kernel != 3) {
-#ifdef PPH_EXPERIMENTS
-    grid = spmv_dispatch_experiment<DOT>(ctx, A, x, bvec, y, part);   // A/B variants (pph_spmv_experiments.inc)
-#else
-    grid = -1;   // pph_set_option refuses other variants in a build without PPH_EXPERIMENTS
-#endif
-  } else {
+  {
     // aligned-wide CSR-vector kernel.  Lanes per row: one 4-wide step covers 4 G entries; rows of up to 29 entries fit G = 8
     int G = ctx->spmv_lanes_override > 0 ? ctx->spmv_lanes_override : (A.max_row > 0 && A.max_row + 3 <= 16 ? 4 : 8);
     if (G != 4 && G != 8 && G != 16 && G != 32 && G != 64) G = 8;

@@ -606,10 +606,6 @@ static int sell_launch_dict_walk(pph_ctx* ctx, int mode, const Sell& E, const do
   return grid;
 }
 
-#ifdef PPH_EXPERIMENTS
-#include "experiments/pph_sell_patch.inc"  // wave-private patch walk (option "sell_patch")
-#include "experiments/pph_sell_lds.inc"    // LDS hand-over product (option "sell_lds"); neither is part of the shipped library
-#endif
 
 template <int KIND, int RPT>
 static void sell_launch_mode(pph_ctx* ctx, int mode, int grid, const Sell& E, const double* x, const double* b,
@@ -692,16 +688,6 @@ int sell_spmv(pph_ctx* ctx, const Sell& E, int64_t n, int mode, const double* x,
   // step (measured on the 256^3 block: 0.58 ms plain order, 0.51 ms z-walk with 4096 workgroups, 0.47 ms with 256;
   // profiles/r02_sell_sym_probe_256.txt, r02_sell_sym_probe2_256.txt)
   const bool zw = E.sym && E.pz > 2 && ctx->sell_zwalk > 0 && chunk0 == 0 && nchunks >= ctx->sell_zwalk_min_chunks;   // (smaller levels: too few chunks per workgroup)
-#ifdef PPH_EXPERIMENTS
-  if (zw && ctx->sell_patch && rpt == 2 && E.kind == PPH_CELL_HEX && cend < 0) {
-    const int g = sell_launch_patch(ctx, mode, E, x, b, dinv, w, y, aux, z0, n, part, dlo, dhi);
-    if (g > 0) return g;
-  }
-  if (zw && ctx->sell_lds && rpt == 2 && E.kind == PPH_CELL_HEX && cend < 0) {
-    const int g = sell_launch_lds(ctx, mode, E, x, b, dinv, w, y, aux, z0, n, nchunks, part, dlo, dhi);
-    if (g > 0) return g;
-  }
-#endif
   const bool dict = rpt == 2 && E.sym && E.dict && E.dict->on;
   if (dict && cend < 0) {
     const int g = sell_launch_dict_walk(ctx, mode, E, x, b, dinv, w, y, aux, z0, n, part, dlo, dhi);
