@@ -662,7 +662,8 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
   }
   if (!strcmp(name, "asm_tile")) { ctx->asm_tile = (value == 2.0) ? 2 : (value != 0.0 ? 1 : 0); return PPH_OK; }
   if (!strcmp(name, "asm_node_xmap")) { ctx->asm_node_xmap = value != 0.0 ? 1 : 0; return PPH_OK; }
-  if (!strcmp(name, "asm_node")) { ctx->asm_node = value == 2.0 ? 2 : (value != 0.0 ? 1 : 0); return PPH_OK; }   // 1: k_asm_node2, 2: the round-3 k_asm_node
+  if (!strcmp(name, "asm_node")) { ctx->asm_node = value != 0.0 ? 1 : 0; return PPH_OK; }
+  if (!strcmp(name, "asm_uniform")) { ctx->asm_uniform = value != 0.0 ? 1 : 0; return PPH_OK; }
   if (!strcmp(name, "asm_node_probe")) { ctx->asm_node_probe = (int)value; return PPH_OK; }
   if (!strcmp(name, "asm_node_split_min")) { ctx->asm_node_split_min = (int64_t)value; return PPH_OK; }
   if (!strcmp(name, "asm_tile_xmap")) { ctx->asm_tile_xmap = value != 0.0 ? 1 : 0; return PPH_OK; }

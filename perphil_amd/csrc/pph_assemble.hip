@@ -670,6 +670,8 @@ struct FuseArgs {
   int64_t ld;
   int8_t slot_of[27];
   int8_t slot_of_c[27];
+  // k_asm_node2 on a uniform box (MeshData::uniform): the canonical edge lengths the cells are integrated on
+  double hcan[3] = {0, 0, 0};
   // k_asm_node2, listed mode: row i of the (mini) output is the row of node list[i]
   const uint32_t* list = nullptr;
   // k_asm_node2, check mode (row dictionaries, pph_sell.hip "check fused into the assembly"): class arrays, tables and status
@@ -2073,168 +2075,6 @@ __global__ __launch_bounds__(512, 4) void k_asm_tile(const double* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Node kernel (round 3; default on box meshes, whose cells all have equal parallel edges): ONE THREAD PER NODE,
-// registers only - no LDS, no barriers, no element rows.
-//
-// The tile kernel's phases B and C exist because a general cell needs its 8 x 8 element matrix once; for a cell with a
-// constant Jacobian the element row of corner a is 8 x (6 + 1) multiply-adds on the cell's geometry factor D against
-// the compile-time reference tables (TileRef), so every node can form the rows of its 2^d incident cells ITSELF from
-// the 3^d vertex coordinates around it (served by L1: neighbours overlap) and sum them slot by slot in registers:
-//     a_(node, node + o) = sum over incident cells c that also hold node + o of  K_e^c[a_c][b_c(o)],   a_c = corner of node in c.
-// The factor of a cell is recomputed by each of its 2^d nodes (8 x ~60 flops: cheap next to one pass over LDS), the
-// formula per entry and the order of every sum are the tile kernel's (constant-factor branch): the two kernels agree
-// to the last bit or two (the compiler contracts the multiply-adds of the two bodies differently; test: 1e-15 of the
-// largest entry, same sweeps / iterations).
-// What it buys: consecutive lanes are consecutive nodes of the linear numbering, so every slot store of a wave is
-// 512 contiguous, aligned bytes (tile kernel: 8 runs of 64 B each, none aligned: PMC showed 1.5 x the stored bytes
-// written and 4.4 GB fetched by a kernel with 0.5 GB of inputs - partial-line write-throughs), and there is nothing
-// left to synchronise.  Stencil-ELL output only; meshes with a cell that fails the exact equal-edges test
-// (MeshData::all_affine, established once at mesh build) take the tile kernel and its general pass.
-// ------------------------------------------------------------------------------------------------
-template <int DIM, int WPS>
-__global__ __launch_bounds__(256, WPS) void k_asm_node(const double* __restrict__ cx, const double* __restrict__ cy,
-                                                  const double* __restrict__ cz, int nx, int ny, int nzl, int px, int py,
-                                                  int pz, int64_t n, FuseArgs fa, int xmap) {
-  constexpr int NB = 1 << DIM;
-  constexpr int NSLOT = (DIM == 3) ? 27 : 9;
-  constexpr int NV = NSLOT;                                // vertices around a node
-  constexpr int ND = DIM * (DIM + 1) / 2 + 1;
-  const TileRef<DIM>& R = tile_ref<DIM>();
-  const int64_t pxy = (int64_t)px * py;
-  double best1 = 0.0, best2 = 0.0;
-  // Blocks of 256 consecutive nodes, dealt round-robin to the workgroups (xmap 0, default).  A node's 3^d vertex
-  // neighbourhood is shared with its neighbours in x, y AND z, so with that order every one of the eight non-coherent
-  // L2s ends up fetching every coordinate plane (PMC, 256^3: 4.1 GB read - mostly from the Infinity Cache - by a kernel
-  // with 0.5 GB of inputs).  xmap 1 gives every XCD (blockIdx % 8) one contiguous eighth of the blocks: 2.0 GB read,
-  // but 4.5 instead of 3.5 ms - eight write streams 0.8 GB apart instead of one front; the reads were never the limit.
-  const int64_t nblk = (n + 255) / 256;
-  const int64_t bpx = xmap ? (int64_t)(gridDim.x >> 3) : (int64_t)gridDim.x;   // (launcher: gridDim.x is a multiple of 8)
-  const int64_t cpx = xmap ? (nblk + 7) >> 3 : nblk;
-  const int64_t blk0 = xmap ? (int64_t)(blockIdx.x & 7) * cpx : 0;
-  for (int64_t c = xmap ? (blockIdx.x >> 3) : blockIdx.x; c < cpx; c += bpx) {
-    const int64_t node = (blk0 + c) * 256 + threadIdx.x;
-    if (node >= n) continue;
-    const int gi = (int)(node % px);
-    const int64_t tq = node / px;
-    const int gj = (int)(tq % py), gk = (int)(tq / py);
-    const uint8_t pnear = fa.near[node];
-    const bool near = pnear != 0;
-    const uint8_t r1 = near ? fa.m1[node] : 0, r2 = near ? fa.m2[node] : 0;
-    // vertex coordinates around the node, indices clamped into the box (cells outside it are skipped below)
-    double V[NV][DIM];
-#pragma unroll
-    for (int q = 0; q < NV; ++q) {
-      const int dx = q % 3 - 1, dy = (q / 3) % 3 - 1, dz = (DIM == 3) ? q / 9 - 1 : 0;
-      int vi = gi + dx, vj = gj + dy, vk = gk + dz;
-      vi = vi < 0 ? 0 : (vi > px - 1 ? px - 1 : vi);
-      vj = vj < 0 ? 0 : (vj > py - 1 ? py - 1 : vj);
-      vk = vk < 0 ? 0 : (vk > pz - 1 ? pz - 1 : vk);
-      const int64_t g = vi + (int64_t)px * vj + pxy * vk;
-      V[q][0] = cx[g];
-      V[q][1] = cy[g];
-      if constexpr (DIM == 3) V[q][2] = cz[g];
-    }
-    double kv[NSLOT], mv[NSLOT];
-#pragma unroll
-    for (int q = 0; q < NSLOT; ++q) { kv[q] = 0.0; mv[q] = 0.0; }
-    // incident cells in ascending corner index a of the node (the tile kernel's candidate order)
-#pragma unroll
-    for (int a = 0; a < NB; ++a) {
-      const int ax = a & 1, ay = (a >> 1) & 1, az = (DIM == 3) ? (a >> 2) & 1 : 0;
-      const int ci = gi - ax, cj = gj - ay, ck = (DIM == 3) ? gk - az : 0;
-      const bool incell = ci >= 0 && ci < nx && cj >= 0 && cj < ny && (DIM == 2 || (ck >= 0 && ck < nzl));
-      if (!incell) continue;
-      // vertex b of the cell = neighbourhood entry (b - a) + centre; J[e][d] = (x_{2^e} - x_0)[d] / 2
-      const int v0 = (1 - ax) + 3 * (1 - ay) + ((DIM == 3) ? 9 * (1 - az) : 0);
-      double J[DIM][DIM];
-#pragma unroll
-      for (int e = 0; e < DIM; ++e) {
-        const int ve = v0 + ((e == 0) ? 1 : (e == 1) ? 3 : 9);
-#pragma unroll
-        for (int d = 0; d < DIM; ++d) J[e][d] = 0.5 * (V[ve][d] - V[v0][d]);
-      }
-      double D[ND];
-      tile_factor<DIM>(J, D);
-#pragma unroll
-      for (int b = 0; b < NB; ++b) {
-        const int bx = b & 1, by = (b >> 1) & 1, bz = (DIM == 3) ? (b >> 2) & 1 : 0;
-        const int slot = (bx - ax + 1) + 3 * (by - ay + 1) + ((DIM == 3) ? 9 * (bz - az + 1) : 0);
-        double kb = 0.0;
-#pragma unroll
-        for (int f = 0; f < ND - 1; ++f) kb += D[f] * R.G[a][b][f];
-        kv[slot] += kb;
-        mv[slot] += D[ND - 1] * R.M[a][b];
-      }
-    }
-    // stencil row: fused epilogue of the tile kernel's phase C; partial sums per slot group (slot % 2^d), combined in
-    // the order of its shuffle tree
-    double g11[NB], g22[NB], gK1[NB], gK2[NB], gM[NB];
-#pragma unroll
-    for (int g = 0; g < NB; ++g) { g11[g] = 0.0; g22[g] = 0.0; gK1[g] = 0.0; gK2[g] = 0.0; gM[g] = 0.0; }
-    double d11 = 0.0, d22 = 0.0;
-#pragma unroll
-    for (int slot = 0; slot < NSLOT; ++slot) {
-      const int dx = slot % 3 - 1, dy = (slot / 3) % 3 - 1, dz = (DIM == 3) ? slot / 9 - 1 : 0;
-      const int ni = gi + dx, nj = gj + dy, nk = gk + dz;
-      if (ni < 0 || ni >= px || nj < 0 || nj >= py || nk < 0 || nk >= pz) continue;   // no such neighbour: pad / absent
-      const double kvs = kv[slot], mvs = mv[slot];
-      const int64_t j = node + dx + (int64_t)dy * px + (int64_t)dz * pxy;
-      const bool diag = (slot == NSLOT / 2);
-      double o11 = fa.a * kvs + fa.b * mvs, o22 = fa.c * kvs + fa.b * mvs, o12 = -fa.b * mvs, o21 = o12;
-      if (near) {
-        const uint8_t cm1 = fa.m1[j], cm2 = fa.same ? cm1 : fa.m2[j];
-        if (fa.rhs) {
-          const double v1 = fa.g1[j], v2 = fa.g2[j];
-          gK1[slot % NB] += kvs * v1; gK2[slot % NB] += kvs * v2; gM[slot % NB] += mvs * (v1 - v2);
-        }
-        o11 = fuse_elim_diag(o11, r1, cm1, diag, fa.symg);
-        o22 = fuse_elim_diag(o22, r2, cm2, diag, fa.symg);
-        o12 = fuse_elim_coupling(-fa.b * mvs, r1, cm2, fa.symg);
-        o21 = fuse_elim_coupling(-fa.b * mvs, r2, cm1, fa.symg);
-      }
-      const int sq = (dz + 1) * 9 + (dy + 1) * 3 + (dx + 1);
-      const int so = fa.slot_of[sq], sc = fa.slot_of_c[sq];     // stored slots (-1: lower half of a symmetric operator)
-      if (so >= 0) { fa.A11[(int64_t)so * fa.ld + node] = o11; fa.A22[(int64_t)so * fa.ld + node] = o22; }
-      if (sc >= 0) {
-        if (fa.A12) fa.A12[(int64_t)sc * fa.ld + node] = o12;
-        if (fa.A21) fa.A21[(int64_t)sc * fa.ld + node] = o21;
-      }
-      g11[slot % NB] += fabs(o11); g22[slot % NB] += fabs(o22);
-      if (diag) { d11 = o11; d22 = o22; }
-    }
-    auto combine = [&](double (&l)[NB]) -> double {
-#pragma unroll
-      for (int o = NB / 2; o > 0; o >>= 1)
-#pragma unroll
-        for (int g = 0; g < o; ++g) l[g] += l[g + o];
-      return l[0];
-    };
-    const double t11 = combine(g11), t22 = combine(g22);
-    const double i1 = (d11 != 0.0) ? 1.0 / d11 : 1.0, i2 = (d22 != 0.0) ? 1.0 / d22 : 1.0;
-    fa.dinv1[node] = i1;
-    fa.dinv2[node] = i2;
-    const double q1 = t11 * fabs(i1), q2 = t22 * fabs(i2);
-    if (!(r1 & 2)) best1 = q1 > best1 ? q1 : best1;   // (ghost rows: not rows of this rank's operator)
-    if (!(r2 & 2)) best2 = q2 > best2 ? q2 : best2;
-    if (fa.rhs) {
-      double o1 = 0.0, o2 = 0.0, u1 = 0.0, u2 = 0.0;
-      if (near) {
-        const double tK1 = combine(gK1), tK2 = combine(gK2), tM = combine(gM);
-        o1 = (r1 != 0) ? 0.0 : -(fa.a * tK1 + fa.b * tM);
-        o2 = (r2 != 0) ? 0.0 : -(fa.c * tK2 - fa.b * tM);
-        u1 = fa.g1[node];
-        u2 = fa.g2[node];
-      }
-      fa.rhs[node] = o1;
-      fa.rhs[n + node] = o2;
-      fa.u0[node] = u1;
-      fa.u0[n + node] = u2;
-    }
-  }
-  fuse_lam_max(best1, best2, fa.lam);
-}
-
-// ------------------------------------------------------------------------------------------------
 // Node kernel, round 4 (k_asm_node2; default): the same integrals, organised so that a node-wave needs ~3 x fewer
 // instructions.  What the round-3 kernel spent its 10 k instructions per node-wave on (ISA): 1 400 fp64 operations, 1 370
 // v_readlane / v_writelane (scalar registers spilled into vector lanes: the ~150 64-bit literals of the reference tables
@@ -2328,10 +2168,11 @@ struct N2Pre {
   double X0[DIM], XP[DIM][DIM], XM[DIM][DIM];   // XP[d] = x(node + e_d), XM[d] = x(node - e_d)
   uint8_t near;
 };
-template <int DIM>
+template <int DIM, bool UNI>
 __device__ __forceinline__ void n2_fetch(const double* __restrict__ cx, const double* __restrict__ cy, const double* __restrict__ cz,
                                          int px, int py, int pz, const uint8_t* __restrict__ nearp, uint32_t node, int gi, int gj,
                                          int gk, int probe, N2Pre<DIM>& P) {
+  if (UNI) return;     // uniform box: the cells are integrated on the canonical edges, no coordinate is read
   const uint32_t stride[3] = {1u, (uint32_t)px, (uint32_t)px * (uint32_t)py};
   const int g[3] = {gi, gj, gk};
   const int pd[3] = {px, py, pz};
@@ -2361,9 +2202,9 @@ __device__ __forceinline__ void n2_fetch(const double* __restrict__ cx, const do
 template <int DIM> __host__ __device__ constexpr double n2_lead(int e, int f) {   // largest |coefficient| of component (e, f): o = 0
   return n2_coef<DIM>((DIM == 3) ? 13 : 4, e, f);
 }
-template <int DIM, bool FAST, bool CELLMAJOR = true>
+template <int DIM, bool FAST, bool UNI, bool CELLMAJOR = true>
 __device__ __forceinline__ void n2_row(const N2Pre<DIM>& P, const bool (&has)[DIM][2], double (&kv)[DIM == 3 ? 27 : 9],
-                                       double (&mv)[DIM == 3 ? 27 : 9]) {
+                                       double (&mv)[DIM == 3 ? 27 : 9], const double (&hcan)[3]) {
   constexpr int NB = 1 << DIM;
   constexpr int NSLOT = (DIM == 3) ? 27 : 9;
   constexpr int NC = DIM * (DIM + 1) / 2;     // components of D
@@ -2373,9 +2214,15 @@ __device__ __forceinline__ void n2_row(const N2Pre<DIM>& P, const bool (&has)[DI
   for (int d = 0; d < DIM; ++d)
 #pragma unroll
     for (int c = 0; c < DIM; ++c) {
-      const double ep = P.XP[d][c] - P.X0[c], em = P.X0[c] - P.XM[d][c];
-      E[d][0][c] = (FAST || has[d][0]) ? ep : em;
-      E[d][1][c] = (FAST || has[d][1]) ? em : ep;
+      if (UNI) {
+        // uniform box (every edge checked against the canonical one at mesh build): all cells around the node are the
+        // same box, their factors one computation; rows repeat bit for bit whatever the rounding of i / nx (row dictionaries)
+        E[d][0][c] = E[d][1][c] = (c == d) ? hcan[d] : 0.0;
+      } else {
+        const double ep = P.XP[d][c] - P.X0[c], em = P.X0[c] - P.XM[d][c];
+        E[d][0][c] = (FAST || has[d][0]) ? ep : em;
+        E[d][1][c] = (FAST || has[d][1]) ? em : ep;
+      }
     }
   if constexpr (CELLMAJOR) {
 #pragma unroll
@@ -2648,7 +2495,7 @@ __device__ __forceinline__ void n2_epilogue(const double (&kv)[DIM == 3 ? 27 : 9
 
 // PATH 0: both bodies in one kernel; 1: only the waves that take the straight-line body, 2: only the others (two
 // launches with separate register allocations; measured against PATH 0)
-template <int DIM, bool SYM, bool SYMC, bool HAS12, bool HAS21, bool HASRHS, bool SAME, int PATH, int MODE = 0>
+template <int DIM, bool SYM, bool SYMC, bool HAS12, bool HAS21, bool HASRHS, bool SAME, int PATH, int MODE = 0, bool UNI = false>
 __global__ __launch_bounds__(256, (PATH == 1 && MODE != 1) ? 3 : 2) void k_asm_node2(const double* __restrict__ cx, const double* __restrict__ cy,
                                                       const double* __restrict__ cz, int nx, int ny, int nzl, int px, int py,
                                                       int pz, int64_t n, FuseArgs fa, int xmap) {
@@ -2699,7 +2546,7 @@ __global__ __launch_bounds__(256, (PATH == 1 && MODE != 1) ? 3 : 2) void k_asm_n
     const bool do_fast = PATH != 2 && fast, do_gen = PATH != 1 && !fast;
     if (!do_fast && !do_gen) continue;
     N2Pre<DIM> P;
-    n2_fetch<DIM>(cx, cy, cz, px, py, pz, fa.near, node, gi, gj, gk, 0, P);
+    n2_fetch<DIM, UNI>(cx, cy, cz, px, py, pz, fa.near, node, gi, gj, gk, 0, P);
     bool has[DIM][2];
     has[0][0] = gi < px - 1; has[0][1] = gi > 0;
     has[1][0] = gj < py - 1; has[1][1] = gj > 0;
@@ -2717,11 +2564,11 @@ __global__ __launch_bounds__(256, (PATH == 1 && MODE != 1) ? 3 : 2) void k_asm_n
     }
     double kv[NSLOT], mv[NSLOT];
     if (do_fast) {
-      n2_row<DIM, true>(P, has, kv, mv);
+      n2_row<DIM, true, UNI>(P, has, kv, mv, fa.hcan);
       n2_epilogue<DIM, true, true, SYM, SYMC, HAS12, HAS21, HASRHS, MODE>(kv, mv, hasb, px, py, n, fa, node, nodeS, 1u, 0u, best1, best2,
                                                                          n2_stab, c11, c22, c12);
     } else {
-      n2_row<DIM, false>(P, has, kv, mv);
+      n2_row<DIM, false, UNI>(P, has, kv, mv, fa.hcan);
       const unsigned nearb = near ? 1u : 0u;
       n2_epilogue<DIM, false, SAME, SYM, SYMC, HAS12, HAS21, HASRHS, MODE>(kv, mv, hasb, px, py, n, fa, node, nodeS, live ? 1u : 0u, nearb,
                                                                             best1, best2, n2_stab, c11, c22, c12);
@@ -2780,11 +2627,12 @@ __global__ __launch_bounds__(256) void k_n2_check_general(int px, int py, int pz
 template <int DIM>
 __global__ __launch_bounds__(256) void k_affine_check(const double* __restrict__ cx, const double* __restrict__ cy,
                                                       const double* __restrict__ cz, int nx, int ny, int nzl, int px, int py,
-                                                      int* __restrict__ out) {
+                                                      int* __restrict__ out, double hx, double hy, double hz, double tol) {
   constexpr int NB = 1 << DIM;
   const int64_t ncell = (int64_t)nx * ny * (DIM == 3 ? nzl : 1);
   const int64_t pxy = (int64_t)px * py;
-  bool bad = false;
+  bool bad = false, odd = false;
+  const double hc[3] = {hx, hy, hz};
   for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < ncell; c += (int64_t)gridDim.x * blockDim.x) {
     const int ci = (int)(c % nx);
     const int64_t t = c / nx;
@@ -2805,13 +2653,24 @@ __global__ __launch_bounds__(256) void k_affine_check(const double* __restrict__
 #pragma unroll
         for (int d = 0; d < DIM; ++d) bad = bad || !(X[b | (1 << e)][d] - X[b][d] == X[1 << e][d] - X[0][d]);
       }
+    // uniform box: the edge along axis e is (hc[e] e_e) up to the rounding of the coordinates
+#pragma unroll
+    for (int e = 0; e < DIM; ++e)
+#pragma unroll
+      for (int d = 0; d < DIM; ++d) odd = odd || !(fabs((X[1 << e][d] - X[0][d]) - (d == e ? hc[e] : 0.0)) <= tol);
   }
   if (bad) atomicOr(out, 1);
+  if (odd) atomicOr(out, 2);
 }
 
 int pph_mesh_check_affine(pph_ctx* ctx, MeshData& mesh) {
   mesh.all_affine = false;
+  mesh.uniform = false;
   if (mesh.kind != PPH_CELL_QUAD && mesh.kind != PPH_CELL_HEX) return PPH_OK;
+  // canonical edges of the unit square / cube this library builds (k_coords: node i at i / nx): the same doubles on every
+  // rank of a slab decomposition and on every multigrid level; tolerance = one rounding of a coordinate of magnitude <= 1
+  const double hx = 1.0 / (double)mesh.nx, hy = 1.0 / (double)mesh.ny, hz = mesh.dim == 3 ? 1.0 / (double)mesh.nz : 0.0;
+  const double tol = 2.220446049250313e-16;
   DevBuf<int> flag;
   PPH_TRY(flag.alloc(ctx, 1));
   PPH_HIP(ctx, hipMemsetAsync(flag.p, 0, sizeof(int), ctx->stream));
@@ -2819,15 +2678,17 @@ int pph_mesh_check_affine(pph_ctx* ctx, MeshData& mesh) {
   const int grid = (int)(ceil_div64(ncell, 256) < 4096 ? ceil_div64(ncell, 256) : 4096);
   if (mesh.dim == 2)
     hipLaunchKernelGGL(k_affine_check<2>, dim3(grid), dim3(256), 0, ctx->stream, mesh.cx.p, mesh.cy.p, mesh.cz.p, mesh.nx,
-                       mesh.ny, 0, mesh.px, mesh.py, flag.p);
+                       mesh.ny, 0, mesh.px, mesh.py, flag.p, hx, hy, hz, tol);
   else
     hipLaunchKernelGGL(k_affine_check<3>, dim3(grid), dim3(256), 0, ctx->stream, mesh.cx.p, mesh.cy.p, mesh.cz.p, mesh.nx,
-                       mesh.ny, mesh.nzl, mesh.px, mesh.py, flag.p);
+                       mesh.ny, mesh.nzl, mesh.px, mesh.py, flag.p, hx, hy, hz, tol);
   int h = 1;
   PPH_HIP(ctx, hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   flag.release();
-  mesh.all_affine = (h == 0);
+  mesh.all_affine = (h & 1) == 0;
+  mesh.uniform = h == 0;
+  mesh.hcan[0] = hx; mesh.hcan[1] = hy; mesh.hcan[2] = hz;
   return PPH_OK;
 }
 
@@ -2847,7 +2708,7 @@ int pph_launch_fused_kernels(pph_ctx* ctx, MeshData& mesh, const FuseArgs& fa, d
   // CSR positions are needed for CSR output and for K / M; the simplex and two-pass gather kernels also walk the
   // pattern's columns (the node and tile kernels address neighbours in closed form)
   const bool closed_form = multilinear && ctx->asm_tile && !ctx->asm_ring &&
-                           ((ctx->asm_node && ctx->asm_affine && mesh.all_affine && !ctx->asm_tile_probe) ||
+                           ((ctx->asm_node && ctx->asm_affine && mesh.all_affine && !ctx->asm_tile_probe && mesh.n < ((int64_t)1 << 29)) ||
                             ctx->asm_tile == 2 || mesh.n >= ctx->asm_tile_min_nodes);
   if (fa.ld == 0 || fa.keep_km || !closed_form) PPH_TRY(pph_ensure_pattern(ctx, mesh));
   if (!multilinear) {
@@ -2865,23 +2726,30 @@ int pph_launch_fused_kernels(pph_ctx* ctx, MeshData& mesh, const FuseArgs& fa, d
     return PPH_OK;
   }
   // box meshes (every cell with equal parallel edges), stencil-ELL output: one thread per node, registers only
-  if (ctx->asm_node && ctx->asm_tile && ctx->asm_affine && mesh.all_affine && fa.ld != 0 && !fa.keep_km && !ctx->asm_tile_probe && !ctx->asm_ring) {
+  if (ctx->asm_node && ctx->asm_tile && ctx->asm_affine && mesh.all_affine && fa.ld != 0 && !fa.keep_km && !ctx->asm_tile_probe && !ctx->asm_ring &&
+      mesh.n < ((int64_t)1 << 29)) {
     const int64_t nb = ((ceil_div64(mesh.n, 256) + 7) / 8) * 8;
     const int grid = (int)(nb < 256 * 64 ? nb : 256 * 64);
     // k_asm_node2 (round 4): storage variants as template parameters; 32-bit node offsets (n < 2^29: 812^3 nodes)
-    const bool sym = fa.slot_of[0] < 0, symc = fa.slot_of_c[0] < 0;
+    const int q0 = mesh.kind == PPH_CELL_QUAD ? 9 : 0;     // the first (lowest) stencil offset: not stored in symmetric storage
+    const bool sym = fa.slot_of[q0] < 0, symc = fa.slot_of_c[q0] < 0;
     const bool h12 = fa.A12 != nullptr, h21 = fa.A21 != nullptr, hr = fa.rhs != nullptr;
     const bool samek = fa.same != 0;       // both fields carry one Dirichlet set (then A21 is not stored: aliased to A12)
     const int variant = (!h12 && !h21 && !hr) ? (sym ? 0 : 1) + (samek ? 0 : 6)             // multigrid level operators
                         : (h12 && hr && !h21 && samek && sym == symc) ? (sym ? 2 : 3)       // fine level, A21 aliased to A12
                         : (h12 && hr && h21 && !samek && !symc) ? (sym ? 4 : 5) : -1;       // fine level, A21 stored on its own
-    if (ctx->asm_node == 1 && variant >= 0 && mesh.n < ((int64_t)1 << 29)) {
+    PPH_REQUIRE(ctx, variant >= 0, "node assembly kernel: no variant for this combination of stored blocks (A12 %d A21 %d rhs %d same %d sym %d symc %d)",
+                (int)h12, (int)h21, (int)hr, (int)samek, (int)sym, (int)symc);
+    {
       const int pz = mesh.kind == PPH_CELL_QUAD ? 1 : mesh.pzl, nz = mesh.kind == PPH_CELL_QUAD ? 0 : mesh.nzl;
       const bool split = mesh.n >= ctx->asm_node_split_min;   // two launches: straight-line waves, then the others
       // Row dictionaries in use on the operators of this launch and unchanged in shape: their per-assembly check runs inside
       // the kernel (pph_sell.hip, "check fused into the assembly") - representative rows first (listed mode) -> tables +
       // class adjacencies -> the assembly proper compares what it stores.  Otherwise sell_dict_update checks afterwards.
+      // uniform box: integrate on the canonical edges (no coordinate loads; rows repeat whatever the rounding of i / nx)
+      const bool uni = ctx->asm_uniform && mesh.uniform;
       FuseArgs fc = fa;
+      for (int d = 0; d < 3; ++d) fc.hcan[d] = mesh.hcan[d];
       bool fuse = ctx->dict_fuse && fa.G && fa.G->ok && split && sym && (variant == 0 || variant == 2 || variant == 4 || variant == 6);
       int nd = 0;
       size_t lds = 0;
@@ -2900,20 +2768,24 @@ int pph_launch_fused_kernels(pph_ctx* ctx, MeshData& mesh, const FuseArgs& fa, d
       if (fuse) {
         const int SS = sell_stored(mesh.kind, 1);
         DictGroup& G = *fa.G;
-        FuseArgs fl = fa;
+        FuseArgs fl = fc;
         fl.ld = G.ldm;
         fl.A11 = G.mini.p; fl.A22 = G.mini.p + (size_t)SS * G.ldm; fl.A12 = nd == 3 ? G.mini.p + (size_t)2 * SS * G.ldm : nullptr;
         fl.A21 = nullptr; fl.rhs = nullptr; fl.u0 = nullptr;
         fl.list = G.list.p;
         const int gl = (int)ceil_div64(G.ldm, 256);
-#define PPH_N2L(DIMV, H12, HR, SM)                                                                                                  \
-        hipLaunchKernelGGL((k_asm_node2<DIMV, true, true, H12, false, HR, SM, 0, 2>), dim3(gl), dim3(256), 0, ctx->stream, mesh.cx.p, \
-                           mesh.cy.p, mesh.cz.p, mesh.nx, mesh.ny, nz, mesh.px, mesh.py, pz, G.ldm, fl, 0)
-        if (mesh.kind == PPH_CELL_QUAD) {
-          if (nd == 3) PPH_N2L(2, true, true, true); else if (samek) PPH_N2L(2, false, false, true); else PPH_N2L(2, false, false, false);
-        } else {
-          if (nd == 3) PPH_N2L(3, true, true, true); else if (samek) PPH_N2L(3, false, false, true); else PPH_N2L(3, false, false, false);
-        }
+#define PPH_N2L(DIMV, H12, HR, SM, UNIV)                                                                                            \
+        hipLaunchKernelGGL((k_asm_node2<DIMV, true, true, H12, false, HR, SM, 0, 2, UNIV>), dim3(gl), dim3(256), 0, ctx->stream,       \
+                           mesh.cx.p, mesh.cy.p, mesh.cz.p, mesh.nx, mesh.ny, nz, mesh.px, mesh.py, pz, G.ldm, fl, 0)
+#define PPH_N2L_DIM(DIMV, UNIV)                                                                                     \
+        do {                                                                                                        \
+          if (nd == 3) PPH_N2L(DIMV, true, true, true, UNIV);                                                       \
+          else if (samek) PPH_N2L(DIMV, false, false, true, UNIV);                                                  \
+          else PPH_N2L(DIMV, false, false, false, UNIV);                                                            \
+        } while (0)
+        if (mesh.kind == PPH_CELL_QUAD) { if (uni) PPH_N2L_DIM(2, true); else PPH_N2L_DIM(2, false); }
+        else { if (uni) PPH_N2L_DIM(3, true); else PPH_N2L_DIM(3, false); }
+#undef PPH_N2L_DIM
 #undef PPH_N2L
         PPH_TRY(dict_group_tables(ctx, G, fa.dicts, nd, *fa.views[0]));
         for (int d = 0; d < nd; ++d) {
@@ -2922,37 +2794,38 @@ int pph_launch_fused_kernels(pph_ctx* ctx, MeshData& mesh, const FuseArgs& fa, d
         }
         fc.alarm = ctx->dict_alarm_dev;
       }
-#define PPH_N2P(DIMV, S, SC, H12, H21, HR, SM, PATHV, MODEV)                                                                            \
-      hipLaunchKernelGGL((k_asm_node2<DIMV, S, SC, H12, H21, HR, SM, PATHV, MODEV>), dim3(grid), dim3(256), MODEV == 1 ? lds : 0,          \
+#define PPH_N2P(DIMV, S, SC, H12, H21, HR, SM, PATHV, MODEV, UNIV)                                                                      \
+      hipLaunchKernelGGL((k_asm_node2<DIMV, S, SC, H12, H21, HR, SM, PATHV, MODEV, UNIV>), dim3(grid), dim3(256), MODEV == 1 ? lds : 0,    \
                          ctx->stream, mesh.cx.p, mesh.cy.p, mesh.cz.p, mesh.nx, mesh.ny, nz, mesh.px, mesh.py, pz, mesh.n, fc,           \
                          ctx->asm_node_xmap)
-#define PPH_N2(DIMV, S, SC, H12, H21, HR, SM)                                                              \
+#define PPH_N2(DIMV, S, SC, H12, H21, HR, SM, UNIV)                                                        \
       do {                                                                                                  \
         if (split) {                                                                                        \
-          if (!(ctx->asm_node_probe & 1)) PPH_N2P(DIMV, S, SC, H12, H21, HR, SM, 1, 0);                     \
-          if (!(ctx->asm_node_probe & 2)) PPH_N2P(DIMV, S, SC, H12, H21, HR, SM, 2, 0);                     \
+          if (!(ctx->asm_node_probe & 1)) PPH_N2P(DIMV, S, SC, H12, H21, HR, SM, 1, 0, UNIV);               \
+          if (!(ctx->asm_node_probe & 2)) PPH_N2P(DIMV, S, SC, H12, H21, HR, SM, 2, 0, UNIV);               \
         }                                                                                                   \
-        else PPH_N2P(DIMV, S, SC, H12, H21, HR, SM, 0, 0);                                                  \
+        else PPH_N2P(DIMV, S, SC, H12, H21, HR, SM, 0, 0, UNIV);                                            \
       } while (0)
       // (check mode exists for the symmetric-storage variants in two launches only: what a dictionary needs anyway)
-#define PPH_N2C(DIMV, S, SC, H12, H21, HR, SM)                                                             \
+#define PPH_N2C(DIMV, S, SC, H12, H21, HR, SM, UNIV)                                                       \
       do {                                                                                                  \
-        PPH_N2P(DIMV, S, SC, H12, H21, HR, SM, 1, 1);                                                       \
-        PPH_N2P(DIMV, S, SC, H12, H21, HR, SM, 2, 0);                                                       \
+        PPH_N2P(DIMV, S, SC, H12, H21, HR, SM, 1, 1, UNIV);                                                 \
+        PPH_N2P(DIMV, S, SC, H12, H21, HR, SM, 2, 0, UNIV);                                                 \
         hipLaunchKernelGGL(k_n2_check_general<DIMV>, dim3(grid), dim3(256), lds, ctx->stream, mesh.px, mesh.py, pz, mesh.n, fc); \
       } while (0)
-#define PPH_N2_DIM(DIMV)                                                        \
+#define PPH_N2_DIM(DIMV, UNIV)                                                  \
       switch (variant) {                                                         \
-        case 0: if (fuse) PPH_N2C(DIMV, true, true, false, false, false, true); else PPH_N2(DIMV, true, true, false, false, false, true); break;      \
-        case 1: PPH_N2(DIMV, false, false, false, false, false, true); break;    \
-        case 2: if (fuse) PPH_N2C(DIMV, true, true, true, false, true, true); else PPH_N2(DIMV, true, true, true, false, true, true); break;        \
-        case 3: PPH_N2(DIMV, false, false, true, false, true, true); break;      \
-        case 4: if (fuse) PPH_N2C(DIMV, true, false, true, true, true, false); else PPH_N2(DIMV, true, false, true, true, true, false); break;       \
-        case 5: PPH_N2(DIMV, false, false, true, true, true, false); break;      \
-        case 6: if (fuse) PPH_N2C(DIMV, true, true, false, false, false, false); else PPH_N2(DIMV, true, true, false, false, false, false); break;     \
-        default: PPH_N2(DIMV, false, false, false, false, false, false); break;  \
+        case 0: if (fuse) PPH_N2C(DIMV, true, true, false, false, false, true, UNIV); else PPH_N2(DIMV, true, true, false, false, false, true, UNIV); break;      \
+        case 1: PPH_N2(DIMV, false, false, false, false, false, true, UNIV); break;    \
+        case 2: if (fuse) PPH_N2C(DIMV, true, true, true, false, true, true, UNIV); else PPH_N2(DIMV, true, true, true, false, true, true, UNIV); break;        \
+        case 3: PPH_N2(DIMV, false, false, true, false, true, true, UNIV); break;      \
+        case 4: if (fuse) PPH_N2C(DIMV, true, false, true, true, true, false, UNIV); else PPH_N2(DIMV, true, false, true, true, true, false, UNIV); break;       \
+        case 5: PPH_N2(DIMV, false, false, true, true, true, false, UNIV); break;      \
+        case 6: if (fuse) PPH_N2C(DIMV, true, true, false, false, false, false, UNIV); else PPH_N2(DIMV, true, true, false, false, false, false, UNIV); break;     \
+        default: PPH_N2(DIMV, false, false, false, false, false, false, UNIV); break;  \
       }
-      if (mesh.kind == PPH_CELL_QUAD) { PPH_N2_DIM(2) } else { PPH_N2_DIM(3) }
+      if (mesh.kind == PPH_CELL_QUAD) { if (uni) { PPH_N2_DIM(2, true) } else { PPH_N2_DIM(2, false) } }
+      else { if (uni) { PPH_N2_DIM(3, true) } else { PPH_N2_DIM(3, false) } }
 #undef PPH_N2_DIM
 #undef PPH_N2C
 #undef PPH_N2
@@ -2960,14 +2833,6 @@ int pph_launch_fused_kernels(pph_ctx* ctx, MeshData& mesh, const FuseArgs& fa, d
       PPH_HIP(ctx, hipGetLastError());
       return PPH_OK;
     }
-    if (mesh.kind == PPH_CELL_QUAD)
-      hipLaunchKernelGGL((k_asm_node<2, 2>), dim3(grid), dim3(256), 0, ctx->stream, mesh.cx.p, mesh.cy.p, mesh.cz.p, mesh.nx, mesh.ny, 0,
-                         mesh.px, mesh.py, 1, mesh.n, fa, ctx->asm_node_xmap);
-    else
-      hipLaunchKernelGGL((k_asm_node<3, 2>), dim3(grid), dim3(256), 0, ctx->stream, mesh.cx.p, mesh.cy.p, mesh.cz.p, mesh.nx, mesh.ny,
-                         mesh.nzl, mesh.px, mesh.py, mesh.pzl, mesh.n, fa, ctx->asm_node_xmap);
-    PPH_HIP(ctx, hipGetLastError());
-    return PPH_OK;
   }
   // (small levels: the two-pass kernels, whose many small workgroups fill the chip where a few thousand tiles do not)
   if (ctx->asm_tile && !ctx->asm_ring && (ctx->asm_tile == 2 || mesh.n >= ctx->asm_tile_min_nodes)) {

@@ -214,6 +214,8 @@ struct MeshData {
   bool km_valid = false;                // K and M hold the integrals of this mesh
   bool pattern_ok = false;              // rowptr / col hold the scalar CSR pattern (built on demand: pph_ensure_pattern)
   bool all_affine = false;              // multilinear cells: every cell has equal parallel edges (exact test at mesh build)
+  bool uniform = false;                 // ... and every edge along axis d is (h[d] e_d) to within the rounding of the coordinates themselves
+  double hcan[3] = {0, 0, 0};           // (2^-52 x the largest coordinate): the box is uniform, the node kernel integrates on the canonical edges
   DevBuf<double> cx, cy, cz;            // nodal coordinates (SoA)
   DevBuf<int32_t> cells;                // cell -> dof map [ncell][m]
   DevBuf<int64_t> rowptr;               // scalar CSR pattern
@@ -314,6 +316,7 @@ struct pph_ctx {
   int64_t asm_tile_min_nodes = 30000;   // levels with fewer nodes use the two-pass kernels (asm_tile 2: tile kernel always)
   int asm_node_xmap = 0;                // node kernel: blocks dealt round-robin to the XCDs (0, default) or one contiguous eighth per XCD (1: 2.0 instead of 4.1 GB read at 256^3, but 4.5 instead of 3.5 ms)
   int64_t asm_node_split_min = 200000;  // node kernel on levels of at least this many nodes: straight-line waves and the others in two launches
+  int asm_uniform = 1;                  // node kernel on a uniform box (MeshData::uniform): canonical edges instead of coordinate loads
   int asm_node_probe = 0;               // timing probes (wrong results): 1 skip the straight-line launch, 2 skip the other
   int asm_node = 1;                     // box meshes, stencil-ELL output: one thread per node, registers only (k_asm_node); 0: tile / two-pass kernels
   int asm_tile_xmap = 0;                // tile kernel: x-adjacent tiles on ONE XCD (both halves of a 128-B line of a slot array meet in one L2)

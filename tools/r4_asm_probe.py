@@ -21,7 +21,7 @@ def run(label, **opts):
     print(f"{label:55s} assemble_ms {min(ts):.3f}  (all: {' '.join('%.3f' % t for t in ts)})", flush=True)
     for k in opts:
         ctx.set_option(k, {"asm_node": 1, "asm_node_split_min": 200000}.get(k, 0))
-run("round-3 kernel (asm_node 2)", asm_node=2)
+run("tile kernel (asm_node 0)", asm_node=0)
 run("k_asm_node2, both launches")
 run("k_asm_node2, straight-line launch only", asm_node_probe=2)
 run("k_asm_node2, predicated launch only", asm_node_probe=1)
