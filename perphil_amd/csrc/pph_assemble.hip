@@ -2161,6 +2161,51 @@ __device__ __forceinline__ void n2_box(const double (&Q)[1 << DIM], double (&out
   }
 }
 
+// Geometry factor for the node kernel: tile_factor's formulas with every rounding written out (no contraction left to the
+// compiler).  The straight-line and the general body, the listed (mini) launch and the check mode are different
+// instantiations of one source; where the compiler may choose which multiply to fuse into which add, two instantiations
+// can round one row differently - harmless for the operator (1e-16), fatal for the row dictionaries, which need the rows
+// of a class to repeat BIT FOR BIT (on 2^k cells per direction every product with h is exact and nothing showed; at 384^3
+// A11 had 37 classes instead of 28 and the fused check refused them).
+template <int DIM>
+__device__ __forceinline__ void n2_factor(const double (&J)[DIM][DIM], double* out) {
+#pragma clang fp contract(off)
+  if constexpr (DIM == 2) {
+    const double det = __builtin_fma(J[0][0], J[1][1], -(J[0][1] * J[1][0]));
+    const double r = 1.0 / det;
+    const double I00 = J[1][1] * r, I01 = -(J[0][1] * r), I10 = -(J[1][0] * r), I11 = J[0][0] * r;
+    const double w = fabs(det);
+    out[0] = w * __builtin_fma(I00, I00, I10 * I10);
+    out[1] = w * __builtin_fma(I00, I01, I10 * I11);
+    out[2] = w * __builtin_fma(I01, I01, I11 * I11);
+    out[3] = w;
+  } else {
+    const double c00 = __builtin_fma(J[1][1], J[2][2], -(J[1][2] * J[2][1]));
+    const double c01 = __builtin_fma(J[1][2], J[2][0], -(J[1][0] * J[2][2]));
+    const double c02 = __builtin_fma(J[1][0], J[2][1], -(J[1][1] * J[2][0]));
+    const double det = __builtin_fma(J[0][0], c00, __builtin_fma(J[0][1], c01, J[0][2] * c02));
+    const double r = 1.0 / det;
+    double I[3][3];
+    I[0][0] = c00 * r;
+    I[0][1] = __builtin_fma(J[0][2], J[2][1], -(J[0][1] * J[2][2])) * r;
+    I[0][2] = __builtin_fma(J[0][1], J[1][2], -(J[0][2] * J[1][1])) * r;
+    I[1][0] = c01 * r;
+    I[1][1] = __builtin_fma(J[0][0], J[2][2], -(J[0][2] * J[2][0])) * r;
+    I[1][2] = __builtin_fma(J[0][2], J[1][0], -(J[0][0] * J[1][2])) * r;
+    I[2][0] = c02 * r;
+    I[2][1] = __builtin_fma(J[0][1], J[2][0], -(J[0][0] * J[2][1])) * r;
+    I[2][2] = __builtin_fma(J[0][0], J[1][1], -(J[0][1] * J[1][0])) * r;
+    const double w = fabs(det);
+    out[0] = w * __builtin_fma(I[0][0], I[0][0], __builtin_fma(I[1][0], I[1][0], I[2][0] * I[2][0]));
+    out[1] = w * __builtin_fma(I[0][0], I[0][1], __builtin_fma(I[1][0], I[1][1], I[2][0] * I[2][1]));
+    out[2] = w * __builtin_fma(I[0][0], I[0][2], __builtin_fma(I[1][0], I[1][2], I[2][0] * I[2][2]));
+    out[3] = w * __builtin_fma(I[0][1], I[0][1], __builtin_fma(I[1][1], I[1][1], I[2][1] * I[2][1]));
+    out[4] = w * __builtin_fma(I[0][1], I[0][2], __builtin_fma(I[1][1], I[1][2], I[2][1] * I[2][2]));
+    out[5] = w * __builtin_fma(I[0][2], I[0][2], __builtin_fma(I[1][2], I[1][2], I[2][2] * I[2][2]));
+    out[6] = w;
+  }
+}
+
 // coordinates a node's row needs: the node and its two neighbours along every axis (indices clamped to the node itself
 // where the box ends), and the `near` byte
 template <int DIM>
@@ -2205,6 +2250,7 @@ template <int DIM> __host__ __device__ constexpr double n2_lead(int e, int f) { 
 template <int DIM, bool FAST, bool UNI, bool CELLMAJOR = true>
 __device__ __forceinline__ void n2_row(const N2Pre<DIM>& P, const bool (&has)[DIM][2], double (&kv)[DIM == 3 ? 27 : 9],
                                        double (&mv)[DIM == 3 ? 27 : 9], const double (&hcan)[3]) {
+#pragma clang fp contract(off)
   constexpr int NB = 1 << DIM;
   constexpr int NSLOT = (DIM == 3) ? 27 : 9;
   constexpr int NC = DIM * (DIM + 1) / 2;     // components of D
@@ -2239,7 +2285,7 @@ __device__ __forceinline__ void n2_row(const N2Pre<DIM>& P, const bool (&has)[DI
         for (int d = 0; d < DIM; ++d) J[e][d] = 0.5 * E[e][ae][d];
       }
       double D[NC + 1];
-      tile_factor<DIM>(J, D);
+      n2_factor<DIM>(J, D);
       // leading coefficient (and the cell's sign s_e s_f, and 0 for a cell outside the box) folded into the factor
       double U[NC + 1];
       int k = 0;
@@ -2273,10 +2319,10 @@ __device__ __forceinline__ void n2_row(const N2Pre<DIM>& P, const bool (&has)[DI
           for (int f = e; f < DIM; ++f) {
             constexpr double zero = 0.0;
             const double r = n2_coef<DIM>(q, e, f) / n2_lead<DIM>(e, f);     // +- 1, 1/2, 1/4 (exact) or 0
-            if (r != zero) kv[q] += r * U[k];
+            if (r != zero) kv[q] = __builtin_fma(r, U[k], kv[q]);
             ++k;
           }
-        mv[q] += (n2_cmass<DIM>(q) / n2_cmass<DIM>((DIM == 3) ? 13 : 4)) * U[NC];
+        mv[q] = __builtin_fma(n2_cmass<DIM>(q) / n2_cmass<DIM>((DIM == 3) ? 13 : 4), U[NC], mv[q]);
       }
     }
     return;
@@ -2295,7 +2341,7 @@ __device__ __forceinline__ void n2_row(const N2Pre<DIM>& P, const bool (&has)[DI
       for (int d = 0; d < DIM; ++d) J[e][d] = 0.5 * E[e][ae][d];
     }
     double D[NC + 1];
-    tile_factor<DIM>(J, D);
+    n2_factor<DIM>(J, D);
     int k = 0;
 #pragma unroll
     for (int e = 0; e < DIM; ++e)
@@ -2320,7 +2366,7 @@ __device__ __forceinline__ void n2_row(const N2Pre<DIM>& P, const bool (&has)[DI
         constexpr double zero = 0.0;
         const double c = n2_coef<DIM>(q, e, f);
         if (k == 0) kv[q] = c * bs[q];
-        else if (c != zero) kv[q] += c * bs[q];
+        else if (c != zero) kv[q] = __builtin_fma(c, bs[q], kv[q]);
       }
       ++k;
     }
@@ -2363,6 +2409,7 @@ __device__ __forceinline__ void n2_epilogue(const double (&kv)[DIM == 3 ? 27 : 9
                                             const unsigned (&hasb)[DIM][2], int px, int py, int64_t n, const FuseArgs& fa,
                                             uint32_t node, uint32_t nodeS, unsigned liveb, unsigned nearb, double& best1,
                                             double& best2, const double* __restrict__ stab, int c11, int c22, int c12) {
+#pragma clang fp contract(off)
   // node: the row for loads (0 for a lane beyond n); nodeS: the lane's own row index for the operator stores (a lane beyond
   // n, always inside the leading dimension, writes the zeros of its padding row); liveb: 1 for a row of the mesh
   constexpr int NSLOT = (DIM == 3) ? 27 : 9;
@@ -2406,7 +2453,8 @@ __device__ __forceinline__ void n2_epilogue(const double (&kv)[DIM == 3 ? 27 : 9
     const int ox = n2_o<DIM>(q, 0), oy = n2_o<DIM>(q, 1), oz = n2_o<DIM>(q, 2);
     const double kvs = kv[q], mvs = mv[q];
     const bool diag = (q == NSLOT / 2);
-    double o11 = fa.a * kvs + fa.b * mvs, o22 = fa.c * kvs + fa.b * mvs, o12 = -fa.b * mvs, o21 = o12;
+    const double bm = fa.b * mvs;
+    double o11 = __builtin_fma(fa.a, kvs, bm), o22 = __builtin_fma(fa.c, kvs, bm), o12 = -bm, o21 = o12;
     if (!FAST) {
       unsigned ex = liveb;
       if (ox != 0) ex &= hasb[0][ox > 0 ? 0 : 1];
@@ -2418,7 +2466,8 @@ __device__ __forceinline__ void n2_epilogue(const double (&kv)[DIM == 3 ? 27 : 9
       const unsigned cm2 = SAME ? cm1 : ((unsigned)fa.m2[j] & um);
       if (HASRHS) {
         const double v1 = fa.g1[j], v2 = fa.g2[j];
-        tK1 += kvs * v1; tK2 += kvs * v2; tM += mvs * (v1 - v2);     // (kvs = mvs = 0 where there is no neighbour)
+        tK1 = __builtin_fma(kvs, v1, tK1); tK2 = __builtin_fma(kvs, v2, tK2);
+        tM = __builtin_fma(mvs, v1 - v2, tM);     // (kvs = mvs = 0 where there is no neighbour)
       }
       // fuse_elim_diag / fuse_elim_coupling: an entry survives in a free row towards a free column; the ghost row of a slab
       // keeps it only in symmetric storage and towards an owned column; a constrained (non-ghost) row keeps a unit diagonal
@@ -2479,7 +2528,8 @@ __device__ __forceinline__ void n2_epilogue(const double (&kv)[DIM == 3 ? 27 : 9
   if (HASRHS) {
     double o1 = 0.0, o2 = 0.0, u1 = 0.0, u2 = 0.0;
     if (!FAST) {
-      const double w1 = -(fa.a * tK1 + fa.b * tM), w2 = -(fa.c * tK2 - fa.b * tM);
+      const double btm = fa.b * tM;
+      const double w1 = -__builtin_fma(fa.a, tK1, btm), w2 = -__builtin_fma(fa.c, tK2, -btm);
       const double h1 = fa.g1[node], h2 = fa.g2[node];
       o1 = (nearb & (r1 == 0u ? 1u : 0u)) ? w1 : 0.0;
       o2 = (nearb & (r2 == 0u ? 1u : 0u)) ? w2 : 0.0;

@@ -821,11 +821,14 @@ def test_hip_matches_cpu_port_mid_size(gpu_ctx_factory, hexa, N, norm, red):
 @pytest.mark.parametrize("dim,kind,nx,ny,nz", [(2, o.CELL_QUAD, 9, 6, 0), (2, o.CELL_QUAD, 70, 33, 0), (3, o.CELL_HEX, 6, 5, 4),
                                                (3, o.CELL_HEX, 1, 1, 1), (3, o.CELL_HEX, 35, 18, 9), (3, o.CELL_HEX, 64, 64, 64)])
 def test_node_assembly_kernel_equals_tile_kernel(gpu_ctx_factory, dim, kind, nx, ny, nz):
-    """k_asm_node (one thread per node, registers only; default on box meshes) against k_asm_tile (LDS element rows):
-    same formula per entry and the same order of every sum - what differs is the compiler's choice of multiply-add
-    contractions inside the two kernels, i.e. the last bit of some entries: operators and right-hand side equal to
-    1e-15 of the largest entry, u0 exactly, the multigrid-preconditioned Picard solve with the same sweeps and CG
-    iterations and the same solution to 1e-12; both against the oracle's matrix on the small meshes."""
+    """k_asm_node2 (one thread per node, registers only; default on box meshes) against k_asm_tile (LDS element rows).  The
+    node kernel integrates a uniform box on its CANONICAL edges h e_d (every edge of the mesh was checked against them to one
+    rounding of a coordinate at mesh build, MeshData::uniform), the tile kernel on the stored coordinates i / nx, whose
+    spacing wobbles by that rounding: relative to an edge of length 1 / n that is n x 2^-52.  Operators and right-hand side
+    therefore agree to (n + 4) x 2^-52 of the largest entry (1e-15 when the cell counts are powers of two: then i / n is
+    exact), u0 exactly, the multigrid-preconditioned Picard solve with the same sweeps and CG iterations and the same
+    solution to 1e-12; both against the oracle's matrix on the small meshes; asm_uniform 0 (stored coordinates in the node
+    kernel too) restores 1e-15 on every mesh."""
     f = _ffi()
     om = o.build_mesh(dim, kind, nx, ny, nz) if nx * max(ny, 1) * max(nz, 1) <= 6000 else None
     import perphil_amd.fd as fdm
@@ -834,9 +837,10 @@ def test_node_assembly_kernel_equals_tile_kernel(gpu_ctx_factory, dim, kind, nx,
     b = mesh.boundary_nodes()
     g1, g2 = o.exact_pressures(mesh.node_coordinates(b), P)
     out = []
-    for node in (1, 0):
+    for node, uni in ((1, 1), (0, 1), (1, 0)):
         ctx = gpu_ctx_factory()
         ctx.set_option("asm_node", node)
+        ctx.set_option("asm_uniform", uni)
         ctx.set_option("asm_tile", 2)
         ctx.mesh_build(dim, kind, nx, ny, nz)
         ctx.set_dirichlet(0, b, g1)
@@ -848,11 +852,16 @@ def test_node_assembly_kernel_equals_tile_kernel(gpu_ctx_factory, dim, kind, nx,
                                      inner_reduction=1e-1, inner_norm=1, mg_smooth=1, picard_rtol=1e-8))
         out.append((mats, rhs, u0, xs, (info.iterations, info.inner_iterations)))
         ctx.close()
+    exact = all(v & (v - 1) == 0 for v in (nx, ny, nz) if v > 0)
+    tol = 1e-15 if exact else (max(nx, ny, nz) + 4) * 2.0 ** -52
     for A, B in zip(out[0][0], out[1][0]):
         np.testing.assert_array_equal(A.indptr, B.indptr)
         np.testing.assert_array_equal(A.indices, B.indices)
+        np.testing.assert_allclose(A.data, B.data, rtol=0, atol=tol * np.abs(B.data).max())
+    np.testing.assert_allclose(out[0][1], out[1][1], rtol=0, atol=tol * np.abs(out[1][1]).max())
+    for A, B in zip(out[2][0], out[1][0]):          # the node kernel on the stored coordinates: the tile kernel's entries
         np.testing.assert_allclose(A.data, B.data, rtol=0, atol=1e-15 * np.abs(B.data).max())
-    np.testing.assert_allclose(out[0][1], out[1][1], rtol=0, atol=1e-15 * np.abs(out[1][1]).max())
+    np.testing.assert_allclose(out[2][1], out[1][1], rtol=0, atol=1e-15 * np.abs(out[1][1]).max())
     np.testing.assert_array_equal(out[0][2], out[1][2])
     np.testing.assert_allclose(out[0][3], out[1][3], rtol=0, atol=1e-12 * np.abs(out[1][3]).max())
     assert out[0][4] == out[1][4]

@@ -34,8 +34,9 @@ def check_row(row, g, dim):
     if ap == "GMRES":
         assert abs(its - ref) <= max(1, ref // 100), (its, ref)
         # (the norm of the LAST iterate: on the two smallest meshes it is far below the tolerance already and follows the
-        # last bits of the orthogonalisation - 2.3e-7 against 3.1e-7; from N = 16 on the norms agree to three digits)
-        assert row["residual"] == pytest.approx(g["residual"], rel=0.35 if g["dofs"] < 300 else 5e-3)
+        # last bits of the orthogonalisation and of the matrix entries - 2.3e-7 (round 3) / 5.1e-7 (round 4: canonical edges) against
+        # 3.1e-7, i.e. 1e-12 of the first residual; from N = 16 on the norms agree to three digits)
+        assert row["residual"] == pytest.approx(g["residual"], rel=1.0 if g["dofs"] < 300 else 5e-3)
     elif ap == "GMRES + ILU PC":
         if dim == 2:
             assert its == ref, (its, ref)
