@@ -1411,7 +1411,7 @@ def test_fieldsplit_gmres_ilu_blocks(gpu_ctx_factory, goldens, dim, kind, nx):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nx,ny,nz", [(32, 16, 8), (64, 64, 64), (16, 128, 32), (40, 36, 30), (15, 15, 15)])
+@pytest.mark.parametrize("nx,ny,nz", [(32, 16, 8), (64, 64, 64), (16, 128, 32), (40, 36, 30), (15, 15, 15), (96, 80, 72)])
 def test_row_dictionary_products_are_bitwise_the_stored_ones(gpu_ctx_factory, nx, ny, nz):
     """Option sell_dict (pph_internal.h: struct SellDict): the distinct rows of a stencil-ELL block stored once, a 2-byte
     class per row, the product's coefficients from LDS.  Same x loads, same order of the sums: y = A x BIT-identical to the
@@ -1421,8 +1421,12 @@ def test_row_dictionary_products_are_bitwise_the_stored_ones(gpu_ctx_factory, nx
     than the cap, or a failed check on the device, leave the stored values in charge - same results again.  Rows repeat
     bit for bit when the node spacing is exact in binary (cells per direction a power of two: 27 interior / next-to-boundary
     classes + the Dirichlet row); with 40 x 36 x 30 cells the rounding of i / 40 makes 1 574 distinct rows and the
-    dictionary is refused - the same assertions then hold on the stored values."""
-    exact = all(v & (v - 1) == 0 for v in (nx, ny, nz))
+    dictionary is refused - the same assertions then hold on the stored values.
+    Round 4: the node assembly kernel integrates a uniform box on its canonical edges (MeshData::uniform), so the rows repeat
+    bit for bit at EVERY cell count - 40 x 36 x 30, 15^3 and 96 x 80 x 72 carry the same 28 (+1) classes as 64^3; with
+    asm_uniform 0 (stored coordinates) the old behaviour - more distinct rows than the cap, refused automatically - is back
+    and is checked on 40 x 36 x 30."""
+    exact = True
     f = _ffi()
     import perphil_amd.fd as fdm
 
@@ -1491,6 +1495,21 @@ def test_row_dictionary_products_are_bitwise_the_stored_ones(gpu_ctx_factory, nx
     for name in ("dict_plain_grid", "cap"):
         np.testing.assert_array_equal(res[name][1], xs0)
         np.testing.assert_array_equal(res[name][3], hist0)
+    if (nx, ny, nz) == (40, 36, 30):
+        # rows that genuinely differ (the stored coordinates i / 40: 1 574 distinct rows) are still refused by themselves
+        ctx = gpu_ctx_factory()
+        ctx.set_option("asm_uniform", 0)
+        ctx.set_option("sell_dict_min_rows", 1)
+        ctx.mesh_build(3, f.CELL_HEX, nx, ny, nz)
+        ctx.set_dirichlet(0, b, g1)
+        ctx.set_dirichlet(1, b, g2)
+        ctx.assemble(P.k1, P.k2, P.beta, P.mu, monolithic=False)
+        t = ctx.timers()
+        assert t["dict_operators"] == 0 and t["dict_status"] == -1, t
+        xs, info, _ = ctx.solve(cfg)
+        assert info.converged and (info.iterations, info.inner_iterations) == its0
+        np.testing.assert_allclose(xs, xs0, rtol=0, atol=1e-11 * np.abs(xs0).max())
+        ctx.close()
 
 
 @pytest.mark.gpu
