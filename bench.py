@@ -581,7 +581,7 @@ def main():
     # offline with tools/pmc_summarize.py and committed under profiles/ (PMC cannot be sampled in-process).  The
     # file is stamped with the kernel and the launch count it was taken on: anything else reports null.
     traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "r03_pmc_spmv_dict_bench256.json" if dicton else "r03_pmc_spmv_bench256.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r04_pmc_spmv_dict_bench256.json" if dicton else "r03_pmc_spmv_bench256.json")
     if os.path.exists(pmc_file) and N == 256 and world == 1 and sell and not c5:
         try:
             with open(pmc_file) as f:

@@ -91,7 +91,10 @@ typedef struct {
                           * preconditioner applications instead of k + 1; 2 = none (KSP_NORM_NONE): no convergence
                           * test, every block solve runs exactly inner_max_it CG iterations - a Picard sweep then
                           * holds no host decision and is enqueued (replayed from a hipGraph) in one go              */
-  int32_t reserved0;
+  int32_t inner_exact;   /* 1: the block solves stand for the reference's LU blocks (fieldsplit_i_pc_type lu): where a block has at
+                          * most 4096 rows (the plumbing configurations) it is solved to inner_rtol inside ONE workgroup, on chip
+                          * (Jacobi-CG, no host round trip), instead of by the host-driven Krylov loop; larger blocks: as inner_*
+                          * say.  0: always as inner_* say                                                              */
 } pph_solver_cfg;
 
 typedef struct {

@@ -79,7 +79,7 @@ class SolverCfg(C.Structure):
         ("picard_rtol", C.c_double), ("picard_atol", C.c_double),
         ("picard_max_it", C.c_int32), ("mg_smooth", C.c_int32),
         ("inner_reduction", C.c_double),
-        ("inner_norm", C.c_int32), ("reserved0", C.c_int32),
+        ("inner_norm", C.c_int32), ("inner_exact", C.c_int32),
     ]
 
 

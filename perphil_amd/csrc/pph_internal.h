@@ -599,6 +599,10 @@ int pph_cg_jacobi(pph_ctx* ctx, const Csr& A, const double* b, double* x, const 
                   int max_it, double* r, double* z, double* p, double* q, int* its);
 // multigrid (pph_mg.hip)
 int mg_setup(pph_ctx* ctx);
+// Jacobi-CG of a stencil-ELL operator of at most 4096 rows inside ONE workgroup (the coarsest multigrid level's kernel;
+// also the reference's LU blocks on plumbing-size meshes): x = A^-1 b to rtol, zero guess; r, p, q: work vectors of n
+void mg_onchip_cg(pph_ctx* ctx, const Sell& E, const double* dinv, const double* b, double* x, double* r, double* p, double* q,
+                  int64_t n, double rtol, int max_it);
 void mg_release(pph_ctx* ctx);
 // z = Vcycle(r) for block `which` (0: A11, 1: A22); r and z have fine-level length n
 void mg_vcycle(pph_ctx* ctx, int which, const double* r, double* z, int nsmooth);

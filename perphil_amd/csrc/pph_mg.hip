@@ -826,6 +826,12 @@ __global__ __launch_bounds__(1024) void k_coarse_cg_sell(const double* __restric
   }
 }
 
+void mg_onchip_cg(pph_ctx* ctx, const Sell& E, const double* dinv, const double* b, double* x, double* r, double* p, double* q,
+                  int64_t n, double rtol, int max_it) {
+  hipLaunchKernelGGL(k_coarse_cg_sell, dim3(1), dim3(n <= 256 ? 256 : 1024), 0, ctx->stream, E.val, E.ld, E.sym, make_stencil(E.kind),
+                     E.px, E.py, E.pz, dinv, b, x, r, p, q, (int)n, rtol, max_it);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Tail of the V(1,1) cycle in ONE workgroup: the coarsest levels (from the first one with at most 1024 rows: 9^3
 // and coarser in 3D) are swept inside a single launch, entirely on-chip - every vector of every tail level lives

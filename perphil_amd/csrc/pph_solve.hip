@@ -613,6 +613,16 @@ struct BlockSolver {
     if (cfg->inner_pc_type == PPH_PC_ILU)
       pc = [this, which](const double* in, double* o) { if (ilu_apply(ctx, ctx->ilu[1 + which], in, o) < 0) failed = true; };
     KspOut ko;
+    if (cfg->inner_exact && !cfg->picard && ctx->world == 1 && n <= 4096 && A[which].ell.val && ctx->diag0_valid && !warm) {
+      // the reference's LU block on a plumbing-size mesh (16 x 16: 289 rows): the whole block solve inside one workgroup,
+      // Jacobi-CG to inner_rtol on chip - one launch instead of ~9 host-driven multigrid-CG iterations of ~10 launches and
+      // one round trip each (BASELINE config 1 through solve_dpp: 20 -> ~2 ms)
+      mg_onchip_cg(ctx, A[which].ell, ctx->dinv0[which].p, rhs, z, r, p, q, n, cfg->inner_rtol < 1e-12 ? cfg->inner_rtol : 1e-12,
+                   8 * (int)n + 64);
+      last_resid = nullptr;
+      total_its += 1;
+      return PPH_OK;
+    }
     if (cfg->inner_ksp_type == PPH_KSP_PREONLY) {
       // one application of the inner preconditioner
       if (dinv[which]) la_pointwise_mult(ctx, z, dinv[which], rhs, n);

@@ -80,7 +80,8 @@ def _inner_cfg(cfg: _ffi.SolverCfg, subs: List[Dict], notes: List[str]) -> None:
     if p in ("lu", "cholesky"):
         # exact block solve of the reference -> multigrid-CG to a tight tolerance
         cfg.inner_pc_type, cfg.inner_rtol = _ffi.PC_MG, 1e-12
-        notes.append("block LU -> CG + geometric multigrid, rtol 1e-12")
+        cfg.inner_exact = 1      # (blocks of at most 4096 rows: one on-chip solve per block instead of a host-driven loop)
+        notes.append("block LU -> CG + geometric multigrid, rtol 1e-12 (blocks of <= 4096 rows: one on-chip Jacobi-CG solve)")
         return
     if p not in ("mg", "jacobi", "none", "ilu"):
         raise NotImplementedError(f"fieldsplit block pc_type {p!r} is not supported (lu, ilu, mg, jacobi, none)")
@@ -154,6 +155,7 @@ def translate_options(params: Dict, nonlinear: bool = False) -> Tuple[_ffi.Solve
         cfg.rtol, cfg.atol, cfg.max_it = _DIRECT_RTOL, 1e-300, 200
         cfg.inner_ksp_type, cfg.inner_pc_type = _ffi.KSP_CG, _ffi.PC_MG
         cfg.inner_rtol, cfg.inner_atol = 1e-12, 1e-300
+        cfg.inner_exact = 1
         info["direct_equivalent"] = True
         notes.append("preonly+lu -> field-split GMRES with multigrid-CG block solves to 1e-13")
         info["notes"] = notes
