@@ -575,7 +575,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         dict_ops = int(t.item())
     dicton = sell and dict_ops >= 3
-    sell_bytes = (2.0 if dicton else 8.0 * S) * ctx.n + 16.0 * ctx.n
+    # (classes constant along z - every box with one Dirichlet set per face: the class words of four planes only are read)
+    zconst = dicton and bool(tr.get("dict_zconst", False))
+    cls_bytes = 2.0 * 4.0 / (N + 1) if zconst else 2.0
+    sell_bytes = (cls_bytes if dicton else 8.0 * S) * ctx.n + 16.0 * ctx.n
     csr_bytes = 12.0 * ctx.nnzb + 20.0 * ctx.n
     # HBM traffic of the same kernel mix from rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, KB), taken
     # offline with tools/pmc_summarize.py and committed under profiles/ (PMC cannot be sampled in-process).  The
@@ -598,7 +601,8 @@ def main():
                     "A11 in LDS, a 2-byte class per row instead of the 8 stored values; field-split block solves; the monolithic "
                     "GMRES products run k_spmv_wide on the field-major CSR and are not in this figure)") if (dicton and c5) else
                    (f"k_spmv_dict_walk<mode> (stencil-ELL SpMV on row dictionaries: {dict_classes} distinct rows of A11 in LDS, a "
-                    "2-byte class per row instead of the 14 stored values, x window of three planes in registers; operators "
+                    "2-byte class per row instead of the 14 stored values" + (" - read on four planes only: the classes of an in-plane "
+                    "position are constant on the interior planes" if zconst else "") + ", x window of three planes in registers; operators "
                     "below 1 M rows - the coarse multigrid levels - k_spmv_sell on their stored values; all multigrid "
                     "levels of one step)")
                    if dicton else
@@ -607,7 +611,7 @@ def main():
                     + "8 B per stored entry, all multigrid levels of one step)")
                    if sell else "k_spmv_wide<8,*,2> (aligned-wide CSR-vector SpMV, all multigrid levels of one step)"),
         "format": (("row dictionary over " if dicton else "") + ("stencil-ELL (symmetric)" if sym else "stencil-ELL")) if sell else "CSR",
-        "dictionary": {"operators": dict_ops, "classes_A11": dict_classes} if sell else None,
+        "dictionary": {"operators": dict_ops, "classes_A11": dict_classes, "classes_constant_along_z": zconst} if sell else None,
         "launches_per_step": int(launches), "avg_launch_us": round(1e3 * ms / max(launches, 1), 2),
         "algorithmic_bytes_per_launch": round(byts / max(launches, 1), 0),
         "fine_level": fine_block(sell_bytes if sell else csr_bytes),

@@ -267,7 +267,8 @@ int pph_comm_times(pph_ctx* ctx, double* out4);
  * 0 not built, -1 more distinct rows than the cap, -2 a row failed the bitwise check: plain storage is used);
  * out[20] ms spent so far in FIRST builds of row dictionaries (hash build + table + first bitwise check + the read-back of
  * the verdict; once per operator, mesh and Dirichlet-set pair - a symbolic-phase cost like the pattern of a CSR matrix),
- * out[21] how many such builds. */
+ * out[21] how many such builds; out[22] 1 when the products of A11 take the classes of the interior planes from the plane below
+ * (option "sell_dict_zconst": the class words of four planes only are read - launches count (16 + e) nrows bytes + those). */
 int pph_get_timers(pph_ctx* ctx, double* out, int n);
 /* tuning / profiling switches (no reference counterpart; defaults in brackets):
  *   "op_format" [1]      operator format of the scalar blocks inside block solves / Picard sweeps: 1 stencil-ELL
@@ -320,7 +321,9 @@ int pph_get_timers(pph_ctx* ctx, double* out, int n);
  *                        bit-identical.  More than "sell_dict_cap" [256] distinct rows (graded meshes, node spacing not
  *                        exact in binary) or a failed check: stored values as before.  "sell_dict_walk" [1]: whole-operator
  *                        products on hexahedra keep the x window in registers (k_spmv_dict_walk), "sell_dict_blocks"
- *                        [1024] their grid; 0 takes effect at once, 1 at the next assembly */
+ *                        [1024] their grid, "sell_dict_zconst" [1]: where the class of an in-plane position is the same on all
+ *                        interior planes (verified on the class array at the build) a step takes its classes from the step
+ *                        below instead of loading them; 0 takes effect at once, 1 at the next assembly */
 int pph_set_option(pph_ctx* ctx, const char* name, double value);
 
 #ifdef __cplusplus

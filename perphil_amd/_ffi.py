@@ -426,8 +426,8 @@ class Context:
         return {"halo_ms": t[0], "allreduce_ms": t[1], "halo_timed": int(t[2]), "allreduce_timed": int(t[3])}
 
     def timers(self) -> dict:
-        t = np.zeros(22, dtype=np.float64)
-        self._check(lib.pph_get_timers(self._h, _ptr(t), 22))
+        t = np.zeros(23, dtype=np.float64)
+        self._check(lib.pph_get_timers(self._h, _ptr(t), 23))
         return {"mesh_ms": t[0], "assemble_ms": t[1], "bc_blocks_ms": t[2], "solve_ms": t[3],
                 "spmv_ms": t[4], "spmv_launches": int(t[5]), "spmv_bytes": t[6],
                 "spmv_dot_ms": t[7], "spmv_dot_launches": int(t[8]), "spmv_dot_bytes": t[9],
@@ -436,4 +436,4 @@ class Context:
                 "split_products": int(t[14]), "symmetric_storage": bool(t[15]),
                 "max_split_partials": int(t[16]),
                 "dict_operators": int(t[17]), "dict_classes": int(t[18]), "dict_status": int(t[19]),
-                "dict_build_ms": t[20], "dict_builds": int(t[21])}
+                "dict_build_ms": t[20], "dict_builds": int(t[21]), "dict_zconst": bool(t[22])}

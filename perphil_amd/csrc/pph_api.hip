@@ -646,10 +646,13 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
     PPH_REQUIRE(ctx, pick >= 0, "no class with another stored half");
     c = (uint16_t)pick;
     PPH_HIP(ctx, hipMemcpy(ctx->D11.cls.p + (int64_t)value, &c, sizeof(c), hipMemcpyHostToDevice));
+    ctx->D11.zconst = false;   // (what k_dict_zconst established no longer holds for this class array)
+    la_release_graphs(ctx);
     return PPH_OK;
   }
   if (!strcmp(name, "sell_dict_cap")) { ctx->sell_dict_cap = (int)value; return PPH_OK; }
   if (!strcmp(name, "sell_dict_walk")) { ctx->sell_dict_walk = value != 0; la_release_graphs(ctx); return PPH_OK; }
+  if (!strcmp(name, "sell_dict_zconst")) { ctx->sell_dict_zconst = value != 0; la_release_graphs(ctx); return PPH_OK; }
   if (!strcmp(name, "sell_dict_poison")) {
     // tests: mark the dictionaries of the fine blocks as failed ON THE DEVICE only, as a failed re-assembly check would -
     // the products launched for them must then take the stored values (the plain path inside the dictionary kernel)
@@ -740,6 +743,7 @@ int pph_get_timers(pph_ctx* ctx, double* out, int n) {
   // row dictionaries: operators using one now (fine blocks and multigrid levels), classes of A11's, device status of A11's
   int dn = 0;
   for (const Sell* E : {&ctx->S11, &ctx->S22, &ctx->S12}) dn += (E->dict && E->dict->on) ? 1 : 0;
+  const bool zc11 = ctx->S11.dict && ctx->S11.dict->on && sell_stream_bytes(ctx, ctx->S11) < 2.0;   // (classes constant along z, used)
   for (size_t l = 1; ctx->mg_ok && l < ctx->mg.size(); ++l)   // (levels: only while the hierarchy matches the assembled system)
     for (int f = 0; f < 2; ++f) dn += (ctx->mg[l].ell[f].dict && ctx->mg[l].ell[f].dict->on) ? 1 : 0;
   int dst[2] = {0, 0};
@@ -747,14 +751,14 @@ int pph_get_timers(pph_ctx* ctx, double* out, int n) {
     (void)hipMemcpyAsync(dst, ctx->D11.state.p, sizeof(dst), hipMemcpyDeviceToHost, ctx->stream);
     (void)hipStreamSynchronize(ctx->stream);
   }
-  const double v[22] = {ctx->t_mesh, ctx->t_asm, ctx->t_bc, ctx->t_solve,
+  const double v[23] = {ctx->t_mesh, ctx->t_asm, ctx->t_bc, ctx->t_solve,
                         ctx->t_spmv[0], (double)ctx->n_spmv[0], ctx->spmv_bytes[0],
                         ctx->t_spmv[1], (double)ctx->n_spmv[1], ctx->spmv_bytes[1], (double)ctx->n_halo,
                         ctx->t_spmv_fine, (double)ctx->n_spmv_fine, ctx->spmv_bytes_fine, (double)ctx->n_split,
                         (ctx->ell_ok && ctx->S11.sym) ? 1.0 : 0.0, (double)ctx->max_split_partials,
                         (double)dn, (double)(ctx->D11.tried ? ctx->D11.ncls : 0), (double)(ctx->D11.on ? dst[1] : ctx->D11.status),
-                        ctx->t_dict_build, (double)ctx->n_dict_build};
-  for (int i = 0; i < n && i < 22; ++i) out[i] = v[i];
+                        ctx->t_dict_build, (double)ctx->n_dict_build, zc11 ? 1.0 : 0.0};
+  for (int i = 0; i < n && i < 23; ++i) out[i] = v[i];
   return PPH_OK;
 }
 

@@ -83,11 +83,12 @@ struct SellDict {
   DevBuf<int64_t> rep;               // [PPH_DICT_HASH] a row of the class that won hash slot h; [PPH_DICT_HASH + c]: of class c
   DevBuf<uint16_t> map;              // [PPH_DICT_HASH] hash slot -> class
   DevBuf<double> tab;                // [PPH_DICT_CAP][S]
-  DevBuf<int> state;                 // [0] classes  [1] 1 usable / 0 not built / < 0 refused  (read by every product launch)
+  DevBuf<int> state;                 // [0] classes  [1] 1 usable / 0 not built / < 0 refused  (read by every product launch)  [2] k_dict_zconst's count
   int ncls = 0;                      // host copy of state[0] after the build
   bool on = false;                   // products use the dictionary
   bool tried = false;                // a build was attempted for the current mesh / Dirichlet sets
   int status = 0;                    // host copy of state[1] after the build
+  bool zconst = false;               // hexahedral box: the class of an in-plane position is the same on planes 2 .. pz - 3 (state[2] == 0, k_dict_zconst)
   int64_t n = 0;
   int px = 0, py = 0, bc_epoch = -1, cap = 0;   // ... and the configuration it was built (or refused) for
   const double* val = nullptr;       // the storage it describes
@@ -96,7 +97,7 @@ struct SellDict {
   DevBuf<int32_t> src;               // [ncls][S]: where tab[c][s] comes from in the group's mini operator (-1: the 0 outside [0, n))
   bool adj_ok = false;
   bool checked = false;              // this assembly's rows were checked by the assembly kernel itself
-  void release() { cls.release(); keys.release(); rep.release(); map.release(); tab.release(); state.release(); adj.release(); src.release(); ncls = 0; on = tried = adj_ok = checked = false; n = 0; val = nullptr; }
+  void release() { cls.release(); keys.release(); rep.release(); map.release(); tab.release(); state.release(); adj.release(); src.release(); ncls = 0; on = tried = adj_ok = checked = zconst = false; n = 0; val = nullptr; }
 };
 #define PPH_DICT_ADJW (PPH_DICT_CAP / 32 + 1)
 #define PPH_DICT_FUSE_CAP 128      // classes per operator up to which the assembly kernel holds the stored halves of the tables in LDS
@@ -435,6 +436,7 @@ struct pph_ctx {
   int sell_dict = 1;                    // row dictionaries for the stencil-ELL blocks (struct SellDict)
   int64_t sell_dict_min_rows = 1000000; // ... of operators with at least this many rows
   int sell_dict_blocks = 1024, sell_dict_zwalk = -1;   // grid (cap) of a dictionary product; chunk z-walk of k_spmv_sell<DICT> (-1: as sell_zwalk)
+  int sell_dict_zconst = 1;             // ... without class loads where the classes are constant along z (SellDict::zconst)
   int sell_dict_walk = 1;               // whole-operator dictionary products of hexahedral blocks: x window in registers (k_spmv_dict_walk)
   int sell_dict_cap = PPH_DICT_CAP;     // classes accepted (tests lower it to force the plain path)
   int sell_rpt = 2, sell_blocks = 0, sell_group = 0;   // SELL SpMV tuning: rows per thread, grid cap, XCD chunk group
@@ -568,10 +570,13 @@ __device__ __forceinline__ void sell_ld2(const double* p, double& a, double& b) 
 #endif
 
 int sell_alloc(pph_ctx* ctx, const MeshData& mesh, DevBuf<double>& buf, Sell* out, int sym);
-// operator bytes a product streams per row: the stored values, or the 2-byte class with a usable row dictionary
+// operator bytes a product streams per row: the stored values, or the 2-byte class with a usable row dictionary - of the rows
+// of four planes only where the walk kernel takes the classes of the interior planes from the plane below (SellDict::zconst)
 static inline double sell_stream_bytes(const pph_ctx* ctx, const Sell& E) {
   const bool dict = ctx->sell_rpt != 1 && E.sym && E.dict && E.dict->on;
-  return dict ? 2.0 : 8.0 * sell_stored(E.kind, E.sym);
+  if (!dict) return 8.0 * sell_stored(E.kind, E.sym);
+  const bool zc = E.dict->zconst && ctx->sell_dict_zconst && ctx->sell_dict_walk && E.kind == PPH_CELL_HEX && E.pz >= 8;
+  return zc ? 2.0 * 4.0 / (double)E.pz : 2.0;
 }
 // (re)builds the row dictionary of E after its values were (re)written; sets / clears E->dict
 int sell_dict_update(pph_ctx* ctx, Sell* E, SellDict& D, int64_t n);

@@ -226,7 +226,7 @@ __device__ __forceinline__ void sell_rows(const double* __restrict__ val, int64_
   sell_epilogue<MODE, RPT>(acc, bv, xr, dv, tv, av, act, w, y, aux, z0, r0, dotacc, dlo, dhi, dotx, flags);
 }
 
-struct SellDictArgs { const uint16_t* cls; const double* tab; const int* state; int ncls; };
+struct SellDictArgs { const uint16_t* cls; const double* tab; const int* state; int ncls; int zconst; };   // zconst: SellDict::zconst
 
 template <int KIND, int MODE, int RPT, bool SYM = false, bool DICT = false>
 __global__ __launch_bounds__(256) void k_spmv_sell(const double* __restrict__ val, int64_t ld,
@@ -358,7 +358,8 @@ struct DwOps { double bv[2], dv[2], tv[2], av[2]; uint32_t cls2; };   // cls2: t
 // ALL: both rows of every lane are inside the plane (all position chunks but the last of a plane) - no lane masks, no
 // branches: the 4-step loop must stay straight-line code, or the compiler's wait-count pass drains every outstanding
 // request at each join and the requests of the next step are never in flight while this one computes
-template <int MODE, bool ALL>
+// NOCLS: the classes of the pair are those of the plane below (SellDict::zconst), the caller copies them
+template <int MODE, bool ALL, bool NOCLS = false>
 __device__ __forceinline__ void dictw_fetch(DwOps& o, const uint16_t* __restrict__ cls, const double* __restrict__ b,
                                             const double* __restrict__ dinv, const double* __restrict__ y,
                                             const double* __restrict__ aux, const double* __restrict__ z0, int64_t r0, bool a0,
@@ -366,7 +367,7 @@ __device__ __forceinline__ void dictw_fetch(DwOps& o, const uint16_t* __restrict
   const bool act[2] = {a0, a1};
   if (ALL || (a0 && a1)) {
     o.bv[0] = o.bv[1] = 0.0; o.dv[0] = o.dv[1] = 0.0; o.tv[0] = o.tv[1] = 0.0; o.av[0] = o.av[1] = 0.0;
-    o.cls2 = (uint32_t)cls[r0] | ((uint32_t)cls[r0 + 1] << 16);   // (two aligned 2-byte loads: r0 is odd on every other plane)
+    if (!NOCLS) o.cls2 = (uint32_t)cls[r0] | ((uint32_t)cls[r0 + 1] << 16);   // (two aligned 2-byte loads: r0 is odd on every other plane)
     if (MODE == 1 || (MODE >= 3 && MODE <= 5) || MODE == 7) sell_ld2(b + r0, o.bv[0], o.bv[1]);
     if (MODE == 3 || MODE == 4) sell_ld2(dinv + r0, o.dv[0], o.dv[1]);
     if (MODE == 5 || MODE == 6) { sell_ld2(y + r0, o.tv[0], o.tv[1]); sell_ld2(aux + r0, o.av[0], o.av[1]); if (z0) sell_ld2(dinv + r0, o.dv[0], o.dv[1]); }
@@ -433,8 +434,8 @@ __device__ unsigned long long* g_dw_stamps = nullptr;
 #else
 #define PPH_DW_STAMP(I) do { } while (0)
 #endif
-template <int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) void k_spmv_dict_walk(const double* __restrict__ val, int64_t ld,
+template <int MODE, bool ZC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE <= 1 ? 3 : 2, 4))) void k_spmv_dict_walk(const double* __restrict__ val, int64_t ld,
                                                         const double* __restrict__ x, const double* __restrict__ b,
                                                         const double* __restrict__ dinv, const double* __restrict__ wp,
                                                         double* __restrict__ y, double* __restrict__ aux,
@@ -513,17 +514,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 4))) voi
 #ifdef PPH_DW_STAMPS
     PPH_DW_STAMP(2);      // range located, first three planes + operands requested
 #endif
-    if (z == 0 && z < zend) PPH_DW_SINGLE();   // (plane 0 needs the clamped loads: one step outside the 4-step loop)
+    // (plane 0 needs the clamped loads: outside the 4-step loop; with constant classes along z also plane 1, whose classes differ)
+    while (z < (ZC ? 2 : 1) && z < zend) PPH_DW_SINGLE();
     if (pos * 512 + 512 <= pxy) {   // every lane has both rows in the plane
-      while (z + 4 <= zend && z + 5 <= planes - 2 && z >= 1) {
-        PPH_DW_LOAD(D, z + 2); PPH_DW_FETCHA(O1, z + 1); PPH_DW_STEPA(A, B, C, O0, z);
-        PPH_DW_LOAD(A, z + 3); PPH_DW_FETCHA(O0, z + 2); PPH_DW_STEPA(B, C, D, O1, z + 1);
-        PPH_DW_LOAD(B, z + 4); PPH_DW_FETCHA(O1, z + 3); PPH_DW_STEPA(C, D, A, O0, z + 2);
-        PPH_DW_LOAD(C, z + 5); PPH_DW_FETCHA(O0, z + 4); PPH_DW_STEPA(D, A, B, O1, z + 3);
-        z += 4;
+      if constexpr (ZC) {
+        // Round 4.  The class words are the one stream of this kernel that is read once, from HBM, and needed FIRST in its
+        // step (class -> table address -> coefficient -> first multiply-add): 2 of 18 bytes per row cost 0.03 of 0.11 ms
+        // (profiles/r04_dict_walk_probes.txt, P0 -> P1).  On a box the class of an in-plane position is the same on all
+        // planes 2 .. planes - 3 (checked on the class array when the dictionary is built: SellDict::zconst), so inside
+        // that range a step takes its classes from the step below: no class load, one word less in flight.
+#define PPH_DW_FETCHN(O, OP, ZZ)                                                                                  \
+        do {                                                                                                      \
+          dictw_fetch<MODE, true, true>(O, da.cls, b, dinv, y, aux, z0, (int64_t)(ZZ) * pxy + p, true, true);     \
+          uint32_t c_ = (OP).cls2;                                                                                \
+          asm volatile("" : "+v"(c_));   /* (opaque: or the 54 table reads are hoisted out of the loop - 108 registers) */ \
+          (O).cls2 = c_;                                                                                          \
+        } while (0)
+        while (z + 4 <= zend && z + 4 <= planes - 3) {
+          PPH_DW_LOAD(D, z + 2); PPH_DW_FETCHN(O1, O0, z + 1); PPH_DW_STEPA(A, B, C, O0, z);
+          PPH_DW_LOAD(A, z + 3); PPH_DW_FETCHN(O0, O1, z + 2); PPH_DW_STEPA(B, C, D, O1, z + 1);
+          PPH_DW_LOAD(B, z + 4); PPH_DW_FETCHN(O1, O0, z + 3); PPH_DW_STEPA(C, D, A, O0, z + 2);
+          PPH_DW_LOAD(C, z + 5); PPH_DW_FETCHN(O0, O1, z + 4); PPH_DW_STEPA(D, A, B, O1, z + 3);
+          z += 4;
 #ifdef PPH_DW_STAMPS
-        PPH_DW_STAMP(sti); ++sti;      // one stamp per four steps
+          PPH_DW_STAMP(sti); ++sti;      // one stamp per four steps
 #endif
+        }
+#undef PPH_DW_FETCHN
+      } else {
+        while (z + 4 <= zend && z + 5 <= planes - 2 && z >= 1) {
+          PPH_DW_LOAD(D, z + 2); PPH_DW_FETCHA(O1, z + 1); PPH_DW_STEPA(A, B, C, O0, z);
+          PPH_DW_LOAD(A, z + 3); PPH_DW_FETCHA(O0, z + 2); PPH_DW_STEPA(B, C, D, O1, z + 1);
+          PPH_DW_LOAD(B, z + 4); PPH_DW_FETCHA(O1, z + 3); PPH_DW_STEPA(C, D, A, O0, z + 2);
+          PPH_DW_LOAD(C, z + 5); PPH_DW_FETCHA(O0, z + 4); PPH_DW_STEPA(D, A, B, O1, z + 3);
+          z += 4;
+#ifdef PPH_DW_STAMPS
+          PPH_DW_STAMP(sti); ++sti;      // one stamp per four steps
+#endif
+        }
       }
     }
 #ifdef PPH_DW_STAMPS
@@ -580,7 +608,7 @@ static int sell_launch_dict_walk(pph_ctx* ctx, int mode, const Sell& E, const do
   const int64_t pxy = (int64_t)E.px * E.py;
   if (!ctx->sell_dict_walk || E.kind != PPH_CELL_HEX || E.pz < 4 || pxy < 2048 || n != pxy * E.pz) return 0;
   const SellDict& D = *E.dict;
-  const SellDictArgs da = {D.cls.p, D.tab.p, D.state.p, D.ncls};
+  const SellDictArgs da = {D.cls.p, D.tab.p, D.state.p, D.ncls, (D.zconst && ctx->sell_dict_zconst && E.pz >= 8) ? 1 : 0};
   const size_t lds = (size_t)D.ncls * 27 * sizeof(double);
   const int64_t items = ((pxy + 511) / 512) * E.pz;
   int64_t g = ctx->sell_dict_blocks >= 8 ? ctx->sell_dict_blocks : 1024;
@@ -590,8 +618,14 @@ static int sell_launch_dict_walk(pph_ctx* ctx, int mode, const Sell& E, const do
   if (g > items) g = items;
   const int grid = (int)g;
 #define PPH_DW_GO(MM)                                                                                                       \
-  hipLaunchKernelGGL((k_spmv_dict_walk<MM>), dim3(grid), dim3(256), lds, ctx->stream, E.val, E.ld, x, b, dinv, w, y, aux, z0, n, \
-                     E.px, pxy, E.pz, part, dlo, dhi, ctx->sell_flags, da)
+  do {                                                                                                                       \
+    if (da.zconst)                                                                                                           \
+      hipLaunchKernelGGL((k_spmv_dict_walk<MM, true>), dim3(grid), dim3(256), lds, ctx->stream, E.val, E.ld, x, b, dinv, w, y, aux, \
+                         z0, n, E.px, pxy, E.pz, part, dlo, dhi, ctx->sell_flags, da);                                       \
+    else                                                                                                                     \
+      hipLaunchKernelGGL((k_spmv_dict_walk<MM, false>), dim3(grid), dim3(256), lds, ctx->stream, E.val, E.ld, x, b, dinv, w, y, aux, \
+                         z0, n, E.px, pxy, E.pz, part, dlo, dhi, ctx->sell_flags, da);                                       \
+  } while (0)
   switch (mode) {
     case 0: PPH_DW_GO(0); break;
     case 1: PPH_DW_GO(1); break;
@@ -614,7 +648,7 @@ static void sell_launch_mode(pph_ctx* ctx, int mode, int grid, const Sell& E, co
   const int64_t pxy = (int64_t)E.px * E.py;
   const int64_t halo = (E.pz > 1 ? pxy : 0) + E.px + 2;   // reach of the x window of a row (2D: no z lines)
   int zwalk = (E.sym && E.pz > 2 && ctx->sell_zwalk > 0 && chunk0 == 0 && nchunks >= ctx->sell_zwalk_min_chunks) ? ctx->sell_zwalk : 0;   // (no gain on full storage)
-  const SellDictArgs nod = {nullptr, nullptr, nullptr, 0};
+  const SellDictArgs nod = {nullptr, nullptr, nullptr, 0, 0};
 #define PPH_SELL_GO(MM)                                                                                              \
   hipLaunchKernelGGL((k_spmv_sell<KIND, MM, RPT>), dim3(grid), dim3(256), 0, ctx->stream, E.val, E.ld, x, b, dinv, w, \
                      y, aux, z0, n, E.px, pxy, halo, nchunks, chunk0, group, zwalk, ctx->sell_xmap, part, dlo, dhi, ctx->sell_flags, nod)
@@ -622,7 +656,7 @@ static void sell_launch_mode(pph_ctx* ctx, int mode, int grid, const Sell& E, co
     if (E.sym && E.dict && E.dict->on) {
       // row dictionary: 2 B per row instead of the value streams; the table of distinct rows goes to LDS
       const SellDict& D = *E.dict;
-      const SellDictArgs da = {D.cls.p, D.tab.p, D.state.p, D.ncls};
+      const SellDictArgs da = {D.cls.p, D.tab.p, D.state.p, D.ncls, 0};
       const size_t lds = (size_t)D.ncls * SellSt<KIND>::S * sizeof(double);
       if (ctx->sell_dict_zwalk >= 0) zwalk = (E.pz > 2 && chunk0 == 0) ? ctx->sell_dict_zwalk : 0;
 #define PPH_SELL_GOD(MM)                                                                                                       \
@@ -921,6 +955,17 @@ static void dict_launch_verify(pph_ctx* ctx, const Sell& E, SellDict& D, int64_t
   }
 }
 
+// rows of planes 2 .. pz - 4 whose class differs from the class of the row one plane above: none = the class of an in-plane
+// position is constant on planes 2 .. pz - 3 (SellDict::zconst; k_spmv_dict_walk then loads no class words inside that range)
+__global__ __launch_bounds__(256) void k_dict_zconst(const uint16_t* __restrict__ cls, int64_t pxy, int pz, int* state) {
+  if (state[1] != 1 || pz < 8) return;
+  const int64_t lo = 2 * pxy, hi = (int64_t)(pz - 3) * pxy;
+  int bad = 0;
+  for (int64_t r = lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < hi; r += (int64_t)gridDim.x * blockDim.x)
+    bad |= cls[r] != cls[r + pxy];
+  if (bad) atomicAdd(state + 2, 1);
+}
+
 int sell_dict_update(pph_ctx* ctx, Sell* E, SellDict& D, int64_t n) {
   E->dict = nullptr;
   const bool want = ctx->sell_dict && E->val && E->sym && n >= ctx->sell_dict_min_rows && ctx->sell_rpt != 1;
@@ -967,8 +1012,10 @@ int sell_dict_update(pph_ctx* ctx, Sell* E, SellDict& D, int64_t n) {
   hipLaunchKernelGGL(k_dict_table, dim3(1), dim3(256), 0, ctx->stream, E->val, E->ld, E->sym, st, E->px, pxy, n, D.keys.p,
                      D.rep.p, D.map.p, D.tab.p, D.state.p, cap, 0, 0);
   dict_launch_verify(ctx, *E, D, n, D.map.p, cap);
+  if (E->kind == PPH_CELL_HEX && n == pxy * E->pz)
+    hipLaunchKernelGGL(k_dict_zconst, dim3(grid), dim3(256), 0, ctx->stream, D.cls.p, pxy, E->pz, D.state.p);
   PPH_HIP(ctx, hipGetLastError());
-  int h[2] = {0, 0};
+  int h[3] = {0, 0, 0};
   PPH_HIP(ctx, hipMemcpyAsync(h, D.state.p, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
   PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->t_dict_build += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build0).count();
@@ -976,6 +1023,7 @@ int sell_dict_update(pph_ctx* ctx, Sell* E, SellDict& D, int64_t n) {
   D.ncls = h[0];
   D.on = h[1] == 1;
   D.status = h[1];
+  D.zconst = D.on && E->kind == PPH_CELL_HEX && n == pxy * E->pz && E->pz >= 8 && h[2] == 0;
   D.tried = true;
   D.adj_ok = false; D.checked = false;     // (the group is rebuilt by the caller: dict_group_build)
   D.val = E->val; D.n = n; D.px = E->px; D.py = E->py; D.bc_epoch = ctx->bc_epoch; D.cap = ctx->sell_dict_cap;

@@ -1438,12 +1438,14 @@ def test_row_dictionary_products_are_bitwise_the_stored_ones(gpu_ctx_factory, nx
                mg_smooth=1, picard_rtol=1e-8)
     x = None
     res = {}
-    for name in ("plain", "dict", "dict_plain_grid", "cap", "poisoned"):
+    for name in ("plain", "dict", "dict_class_loads", "dict_plain_grid", "cap", "poisoned"):
         ctx = gpu_ctx_factory()
         ctx.set_option("sell_zwalk_min_chunks", 1)
         if name != "plain":
             ctx.set_option("sell_dict", 1)
             ctx.set_option("sell_dict_min_rows", 1)
+        if name == "dict_class_loads":    # the walk kernel that loads the classes of every plane (round 4: sell_dict_zconst)
+            ctx.set_option("sell_dict_zconst", 0)
         if name == "dict_plain_grid":     # k_spmv_sell<DICT> in the stored-value kernel's chunk order and grid
             ctx.set_option("sell_dict_walk", 0)
             ctx.set_option("sell_dict_blocks", 0)
@@ -1456,8 +1458,11 @@ def test_row_dictionary_products_are_bitwise_the_stored_ones(gpu_ctx_factory, nx
         ctx.assemble(P.k1, P.k2, P.beta, P.mu, monolithic=False)      # the re-assembly path: classes kept, table re-read
         ctx.assemble(P.k1, P.k2, P.beta, P.mu, monolithic=False)      # ... and with unchanged values: checked by the assembly kernel itself
         t = ctx.timers()
-        if name in ("dict", "dict_plain_grid", "poisoned") and exact:
+        if name in ("dict", "dict_class_loads", "dict_plain_grid", "poisoned") and exact:
             assert t["dict_operators"] >= 3 and t["dict_status"] == 1 and 8 <= t["dict_classes"] <= 64, t
+            # the class of an in-plane position is the same on the planes 2 .. pz - 3 of a box with one Dirichlet set per face:
+            # established on the class array at the build, used by the walk kernel (no class loads there) from 8 planes on
+            assert t["dict_zconst"] == (name in ("dict", "poisoned") and nz >= 7), (name, t)
         elif name in ("dict", "dict_plain_grid", "poisoned"):
             assert (t["dict_operators"] == 0 and t["dict_status"] == -1) or t["dict_classes"] <= 256, t
         elif name == "cap":
@@ -1485,13 +1490,15 @@ def test_row_dictionary_products_are_bitwise_the_stored_ones(gpu_ctx_factory, nx
         res[name] = (ys, xs, (info.iterations, info.inner_iterations), hist)
         ctx.close()
     ys0, xs0, its0, hist0 = res["plain"]
-    for name in ("dict", "dict_plain_grid", "cap", "poisoned"):
+    for name in ("dict", "dict_class_loads", "dict_plain_grid", "cap", "poisoned"):
         ys, xs, its, hist = res[name]
         for ya, yb in zip(ys0, ys):
             np.testing.assert_array_equal(ya, yb)
         assert its == its0, name
         np.testing.assert_allclose(xs, xs0, rtol=0, atol=1e-12 * np.abs(xs0).max())
         np.testing.assert_allclose(hist, hist0, rtol=1e-6)
+    np.testing.assert_array_equal(res["dict_class_loads"][1], res["dict"][1])     # (same grid, same sums: the solve bit for bit)
+    np.testing.assert_array_equal(res["dict_class_loads"][3], res["dict"][3])
     for name in ("dict_plain_grid", "cap"):
         np.testing.assert_array_equal(res[name][1], xs0)
         np.testing.assert_array_equal(res[name][3], hist0)
@@ -1510,6 +1517,52 @@ def test_row_dictionary_products_are_bitwise_the_stored_ones(gpu_ctx_factory, nx
         assert info.converged and (info.iterations, info.inner_iterations) == its0
         np.testing.assert_allclose(xs, xs0, rtol=0, atol=1e-11 * np.abs(xs0).max())
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_row_dictionary_with_classes_that_change_along_z(gpu_ctx_factory):
+    """Round 4 (sell_dict_zconst): the walk kernel takes the classes of the interior planes from the plane below only when the
+    class array says so (k_dict_zconst at the build).  Dirichlet data on the lower half of the boundary only: the rows next
+    to the faces change their class half way up, the flag stays off, the classes are loaded on every plane, and products and
+    the solve are those of the stored values bit for bit."""
+    f = _ffi()
+    import perphil_amd.fd as fdm
+
+    N = 16
+    mesh = fdm.UnitCubeMesh(N, N, N, hexahedral=True)
+    b_all = mesh.boundary_nodes()
+    xyz = mesh.node_coordinates(b_all)
+    b = b_all[xyz[:, 2] <= 0.5]
+    g1, g2 = o.exact_pressures(mesh.node_coordinates(b), P)
+    cfg = _cfg(picard=1, inner_ksp_type=f.KSP_CG, inner_pc_type=f.PC_MG, inner_rtol=1e-10, inner_reduction=1e-1, inner_norm=1,
+               mg_smooth=1, picard_rtol=1e-8)
+    rng = np.random.default_rng(5)
+    x = None
+    res = {}
+    for name in ("plain", "dict"):
+        ctx = gpu_ctx_factory()
+        ctx.set_option("sell_zwalk_min_chunks", 1)
+        ctx.set_option("sell_dict", 1 if name == "dict" else 0)
+        ctx.set_option("sell_dict_min_rows", 1)
+        ctx.mesh_build(3, f.CELL_HEX, N, N, N)
+        ctx.set_dirichlet(0, b, g1)
+        ctx.set_dirichlet(1, b, g2)
+        ctx.assemble(P.k1, P.k2, P.beta, P.mu, monolithic=False)
+        ctx.assemble(P.k1, P.k2, P.beta, P.mu, monolithic=False)
+        t = ctx.timers()
+        if name == "dict":
+            assert t["dict_operators"] >= 3 and t["dict_status"] == 1 and not t["dict_zconst"], t
+        if x is None:
+            x = rng.uniform(-1, 1, ctx.n)
+        ys = [ctx.spmv(w, x) for w in (f.MAT_A11, f.MAT_A22, f.MAT_A12)]
+        xs, info, _ = ctx.solve(cfg)
+        assert info.converged
+        res[name] = (ys, xs, (info.iterations, info.inner_iterations))
+        ctx.close()
+    for ya, yb in zip(res["plain"][0], res["dict"][0]):
+        np.testing.assert_array_equal(ya, yb)
+    assert res["plain"][2] == res["dict"][2]
+    np.testing.assert_allclose(res["dict"][1], res["plain"][1], rtol=0, atol=1e-12 * np.abs(res["plain"][1]).max())
 
 
 @pytest.mark.gpu
