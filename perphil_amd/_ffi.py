@@ -283,12 +283,21 @@ class Context:
     _PIN_MIN = 1 << 20      # entries; smaller results use pageable arrays
     _PIN_POOL = 3
 
+    @staticmethod
+    def _idle_refcount() -> int:
+        # what sys.getrefcount reports for an object only a list refers to, counted the way _result_array counts (list entry,
+        # loop variable, the call's argument): measured on this interpreter instead of assumed (3 on CPython 3.10)
+        for o in [object()]:
+            return sys.getrefcount(o)
+        return 3
+
     def _result_array(self, n: int) -> np.ndarray:
         if n < self._PIN_MIN:
             return np.empty(n, dtype=np.float64)
         pool = self.__dict__.setdefault("_pinned", [])
+        idle = self.__dict__.setdefault("_pinned_idle", self._idle_refcount())
         for arr in pool:
-            if arr.shape[0] == n and sys.getrefcount(arr) <= 3:    # the pool's list, the loop variable, getrefcount's argument
+            if arr.shape[0] == n and sys.getrefcount(arr) <= idle:    # nobody but the pool refers to it (views count: their base is arr)
                 return arr
         pool[:] = [a for a in pool if a.shape[0] == n]
         if len(pool) >= self._PIN_POOL:
