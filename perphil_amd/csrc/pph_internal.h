@@ -515,9 +515,10 @@ void la_sub(pph_ctx* ctx, double* z, const double* a, const double* b, int64_t n
 bool la_device_scalars(const pph_ctx* ctx);
 int la_reduce_device(pph_ctx* ctx, int slot, int count);
 int la_fetch_raw(pph_ctx* ctx, int slot, int count);
-void la_cg_update_dev(pph_ctx* ctx, double* x, double* r, const double* p, const double* q, int slot_num, int slot_den,
+// pub_count > 0: the caller would publish scal[pub_slot .. + pub_count) right after (la_publish); true = done in the same launch
+bool la_cg_update_dev(pph_ctx* ctx, double* x, double* r, const double* p, const double* q, int slot_num, int slot_den,
                       int64_t n, int slot_out, Seg sg, double* z0 = nullptr, const double* dinv0 = nullptr,
-                      const double* w0 = nullptr, int slot_bad = -1);   // slot_bad >= 0: scal[slot_bad] += 1 when p.Ap is 0 / NaN
+                      const double* w0 = nullptr, int slot_bad = -1, int pub_slot = -1, int pub_count = 0);   // slot_bad >= 0: scal[slot_bad] += 1 when p.Ap is 0 / NaN
 void la_p_update_dev(pph_ctx* ctx, double* p, const double* z, int slot_num, int slot_den, int64_t n);
 void la_shift(pph_ctx* ctx, double* R, double* told, const double* tnew, double sign, int64_t n);  // R += sign (tnew - told); told = tnew
 void la_block2_apply(pph_ctx* ctx, double* z, const double* binv /*[4][n]*/, const double* r, int64_t n);

@@ -169,6 +169,25 @@ __global__ __launch_bounds__(256) void k_reduce_final(const double* __restrict__
   if (threadIdx.x == 0) out[blockIdx.x] = v;
 }
 
+// the same (one block) followed by the publication of `count` scalars from psrc - the result just written among them - to
+// the host's mirror, as k_publish does it: one launch less per Krylov iteration (round 4; sum and order of k_reduce_final)
+__global__ __launch_bounds__(256) void k_reduce_final_publish(const double* __restrict__ part, int nblocks, double* __restrict__ out,
+                                                              const double* psrc, double* __restrict__ hdst, int count,
+                                                              unsigned long long* __restrict__ hseq, unsigned long long* ctr) {
+  __shared__ double lds[4];
+  double v = 0.0;
+  for (int i = threadIdx.x; i < nblocks; i += 256) v += part[i];
+  v = block_sum(v, lds);
+  if (threadIdx.x == 0) {
+    out[0] = v;
+    for (int i = 0; i < count; ++i) hdst[i] = (psrc + i == out) ? v : psrc[i];
+    __threadfence_system();
+    const unsigned long long seq = *ctr + 1;
+    *ctr = seq;
+    __hip_atomic_store(hseq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 static int spmv_grid(const pph_ctx* ctx, int64_t nrows, int rows_per_block) {
   const int cap = (ctx->spmv_blocks >= 8 && ctx->spmv_blocks <= SPMV_MAX_BLOCKS) ? (ctx->spmv_blocks / 8) * 8 : SPMV_DEF_BLOCKS;
   int64_t nchunks = ceil_div64(nrows, rows_per_block);
@@ -841,14 +860,23 @@ __global__ __launch_bounds__(256) void k_cg_update_dev(double* __restrict__ x, d
   if (threadIdx.x == 0) part[blockIdx.x] = a;
 }
 
-void la_cg_update_dev(pph_ctx* ctx, double* x, double* r, const double* p, const double* q, int slot_num, int slot_den,
-                      int64_t n, int slot_out, Seg sg, double* z0, const double* dinv0, const double* w0, int slot_bad) {
+bool la_cg_update_dev(pph_ctx* ctx, double* x, double* r, const double* p, const double* q, int slot_num, int slot_den,
+                      int64_t n, int slot_out, Seg sg, double* z0, const double* dinv0, const double* w0, int slot_bad,
+                      int pub_slot, int pub_count) {
   double* part = partials(ctx);
   int grid = ew_grid(n);
   if (grid > RED_BLOCKS) grid = RED_BLOCKS;
   hipLaunchKernelGGL(k_cg_update_dev, dim3(grid), dim3(256), 0, ctx->stream, x, r, p, q, ctx->scal.p + slot_num,
                      ctx->scal.p + slot_den, n, sg, part, z0, dinv0, w0, slot_bad >= 0 ? ctx->scal.p + slot_bad : (double*)nullptr);
+  if (pub_count > 0 && ctx->fetch_spin && (ctx->world == 1 || ctx->comm_suspended)) {
+    // the caller publishes right after this update (la_publish semantics): reduce and publish in one launch
+    ++ctx->pub_seq;
+    hipLaunchKernelGGL(k_reduce_final_publish, dim3(1), dim3(256), 0, ctx->stream, part, grid, ctx->scal.p + slot_out,
+                       ctx->scal.p + pub_slot, ctx->h_scal_dev + pub_slot, pub_count, ctx->h_seq_dev, ctx->pub_ctr.p);
+    return true;
+  }
   hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, ctx->stream, part, grid, ctx->scal.p + slot_out);
+  return false;
 }
 
 // p = z + beta p with beta = *num / *den read on the device

@@ -147,9 +147,15 @@ __global__ __launch_bounds__(256) void k_restrict_q1(double* __restrict__ bc, co
                                                      const double* __restrict__ wcp, const uint8_t* __restrict__ fast) {
   const int64_t nc = (int64_t)g.pxc * g.pyc * g.pzc;
   NODE_LOOP(id, nc) {
-    const int I = (int)(id % g.pxc);
-    const int64_t t = id / g.pxc;
-    const int J = (int)(t % g.pyc), K = (int)(t / g.pyc) + g.gzc;
+    int I, J, K;
+    if (nc < (int64_t)1 << 31) {   // (32-bit index arithmetic where the level allows it)
+      const uint32_t i32 = (uint32_t)id, t32 = i32 / (uint32_t)g.pxc, k32 = t32 / (uint32_t)g.pyc;
+      I = (int)(i32 - t32 * (uint32_t)g.pxc); J = (int)(t32 - k32 * (uint32_t)g.pyc); K = (int)k32 + g.gzc;
+    } else {
+      I = (int)(id % g.pxc);
+      const int64_t t = id / g.pxc;
+      J = (int)(t % g.pyc); K = (int)(t / g.pyc) + g.gzc;
+    }
     double s = 0.0;
     if (fast && fast[id]) {
       // interior: 3^DIM unconditional loads, no masks (same weights, same order of accumulation as below)
@@ -258,9 +264,17 @@ __global__ __launch_bounds__(256) void k_prolong_to_q1(double* __restrict__ xout
   const int hx = (g.pxf + 1) >> 1;
   const int64_t npairs = (int64_t)hx * g.pyf * g.pzf;
   NODE_LOOP(pid, npairs) {
-    const int m = (int)(pid % hx);
-    const int64_t t = pid / hx;
-    const int j = (int)(t % g.pyf), kl = (int)(t / g.pyf), kg = kl + g.gzf;
+    // (32-bit index arithmetic where the level allows it: a 64-bit division is ~100 instructions on this hardware)
+    int m, j, kl;
+    if (npairs < (int64_t)1 << 31) {
+      const uint32_t p32 = (uint32_t)pid, t32 = p32 / (uint32_t)hx;
+      m = (int)(p32 - t32 * (uint32_t)hx); kl = (int)(t32 / (uint32_t)g.pyf); j = (int)(t32 - (uint32_t)kl * (uint32_t)g.pyf);
+    } else {
+      m = (int)(pid % hx);
+      const int64_t t = pid / hx;
+      j = (int)(t % g.pyf); kl = (int)(t / g.pyf);
+    }
+    const int kg = kl + g.gzf;
     const int64_t id0 = 2 * m + (int64_t)g.pxf * (j + (int64_t)g.pyf * kl);
     const bool has1 = 2 * m + 1 < g.pxf;
     const int oy = j & 1, oz = kg & 1;

@@ -147,7 +147,9 @@ static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double*
     };
     // the two halves of an iteration around the host's convergence test.  `rotate`: r.z (current) := r.z (new) rides
     // on the final reduction of p.Ap - after the direction update read both, before the CG update reads the current one
-    auto half_product = [&](bool rotate) -> int {
+    bool published = false;   // (the publication of p.Ap and r.r rode on the update's final reduction)
+    auto half_product = [&](bool rotate, bool publish = false) -> int {
+      published = false;
       if (merged) {
         la_spmv_dot3(ctx, A, p, r, q, sE, rotate ? sRZn : -1, sRZc);
         PPH_TRY(la_reduce_device(ctx, sE, 4));
@@ -157,7 +159,8 @@ static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double*
       la_spmv_dot(ctx, A, p, q, sPQ, rotate ? sRZn : -1, sRZc);
       PPH_TRY(la_reduce_device(ctx, sPQ, 1));
       // x += alpha p ; r -= alpha q ; r.r (and the next cycle's pre-smoothed first guess into z)
-      la_cg_update_dev(ctx, x, r, p, q, sRZc, sPQ, n, sRR, sg, pre.on ? z : nullptr, pre.dinv, pre.w);
+      published = la_cg_update_dev(ctx, x, r, p, q, sRZc, sPQ, n, sRR, sg, pre.on ? z : nullptr, pre.dinv, pre.w, -1,
+                                   publish ? sPQ : -1, publish ? 2 : 0);
       PPH_TRY(la_reduce_device(ctx, sRR, 1));
       return PPH_OK;
     };
@@ -194,9 +197,9 @@ static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double*
       } else {
         auto body = [&]() -> int {
           PPH_TRY(half_direction());
-          PPH_TRY(half_product(true));
+          PPH_TRY(half_product(true, true));
           if (merged) la_publish(ctx, sRZc, 5);
-          else la_publish(ctx, sPQ, 2);
+          else if (!published) la_publish(ctx, sPQ, 2);
           return PPH_OK;
         };
         if (graphable) PPH_TRY(la_run_graph(ctx, gk, body));
