@@ -191,8 +191,9 @@ static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double*
     double rr_prev = res * res;   // (merged all-reduce) r.r the recurrence starts from: host-known before the first update
     while (its < max_it) {
       if (its == 0) {
-        PPH_TRY(half_product(false));
+        PPH_TRY(half_product(false, true));
         if (merged) PPH_TRY(la_fetch_raw(ctx, sRZc, 5));   // r.z (current), p.Ap, r.Ap, Ap.Ap, r.r of the previous update
+        else if (published) PPH_TRY(la_wait_published(ctx));
         else PPH_TRY(la_fetch_raw(ctx, sPQ, 2));
       } else {
         auto body = [&]() -> int {
