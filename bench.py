@@ -267,14 +267,21 @@ def bench_configs(_ffi, device, with_cpu, cores):
     import warnings
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        pa.solve_dpp(W, params, bcs, solver_parameters=spar.LINEAR_SOLVER_PARAMS)
-        t0 = time.perf_counter()
-        for _ in range(5):
+        for _ in range(2):
+            pa.solve_dpp(W, params, bcs, solver_parameters=spar.LINEAR_SOLVER_PARAMS)
+        # a call is ~4 ms of host-driven launches: timed call by call, median reported (right after the 16-thread CPU leg of
+        # this process a single scheduling stall - the cgroup's CPU quota - otherwise lands in a mean over five calls:
+        # measured 18.8 ms against 3.6 ms without that leg)
+        per_call = []
+        for _ in range(15):
+            t0 = time.perf_counter()
             sol = pa.solve_dpp(W, params, bcs, solver_parameters=spar.LINEAR_SOLVER_PARAMS)
-        ms = 1e3 * (time.perf_counter() - t0) / 5
+            per_call.append(1e3 * (time.perf_counter() - t0))
+        ms = float(np.median(per_call))
     e = {"config": 1, "workload": "2D UnitSquare 16x16 Q1, monolithic linear DPP, manufactured BCs, LINEAR_SOLVER_PARAMS "
-                                  "through solve_dpp (direct-equivalent solve; wall clock of the call, result on the host)",
-         "dofs": int(W.dim()), "ms": round(ms, 3), "iterations": int(sol.iteration_number), "parity": None}
+                                  "through solve_dpp (direct-equivalent solve; wall clock of a call, median of 15, result on the host)",
+         "dofs": int(W.dim()), "ms": round(ms, 3), "ms_mean": round(float(np.mean(per_call)), 3), "ms_max": round(max(per_call), 3),
+         "calls": len(per_call), "iterations": int(sol.iteration_number), "parity": None}
     if with_cpu:
         from oracle import dpp_oracle as o
 
