@@ -498,7 +498,9 @@ void la_set(pph_ctx* ctx, double* x, double v, int64_t n) {
   hipLaunchKernelGGL(k_set, dim3(ew_grid(n)), dim3(256), 0, ctx->stream, x, v, n);
 }
 void la_copy(pph_ctx* ctx, double* dst, const double* src, int64_t n) {
-  (void)hipMemcpyAsync(dst, src, sizeof(double) * (size_t)n, hipMemcpyDeviceToDevice, ctx->stream);
+  // (a kernel of our own: the runtime's device-to-device copy leaves 35 - 40 us of idle time around each call -
+  // profiles/r04_c_gaps256.txt, "after __amd_rocclr_copyBuffer")
+  if (n > 0) hipLaunchKernelGGL(k_copy, dim3(ew_grid(n)), dim3(256), 0, ctx->stream, dst, src, n);
 }
 void la_axpy(pph_ctx* ctx, double* y, double alpha, const double* x, int64_t n) {
   hipLaunchKernelGGL(k_axpy, dim3(ew_grid(n)), dim3(256), 0, ctx->stream, y, alpha, x, n);

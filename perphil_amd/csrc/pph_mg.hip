@@ -648,8 +648,7 @@ int mg_setup(pph_ctx* ctx) {
     if (l == 0 && ctx->diag0_valid) {
       // the fused assembly already produced the fine-level diagonal inverses and bounds
       for (int f = 0; f < 2; ++f)
-        PPH_HIP(ctx, hipMemcpyAsync(L.dinv[f].p, ctx->dinv0[f].p, sizeof(double) * (size_t)L.n, hipMemcpyDeviceToDevice,
-                                    ctx->stream));
+        la_copy(ctx, L.dinv[f].p, ctx->dinv0[f].p, L.n);
       PPH_HIP(ctx, hipMemcpyAsync(lamdev.p + 2 * l, ctx->lam0.p, 2 * sizeof(unsigned long long),
                                   hipMemcpyDeviceToDevice, ctx->stream));
     } else if (!level_fused)
