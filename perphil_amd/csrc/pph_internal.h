@@ -291,6 +291,16 @@ struct pph_ctx {
   int num_cus = 256;                    // compute units of the device (hipDeviceProp_t::multiProcessorCount)
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // the fused assembly's own event pair: pph_assemble_dpp returns without waiting, pph_get_timers resolves the time (round 4)
+  hipEvent_t ev_asm0 = nullptr, ev_asm1 = nullptr;
+  bool asm_time_pending = false;
+  // spectral bounds of the multigrid levels (bit patterns): device array kept across assemblies, read back into pinned host
+  // memory WITHOUT a synchronisation - the smoother weights are computed on the device (k_mg_weights); the host copies
+  // (MgLevel::lam) are filled when something on the host asks for them (mg_lam_host: multi-step Chebyshev, slabs)
+  DevBuf<unsigned long long> mg_lam;
+  unsigned long long* h_lam = nullptr;   // [2 * 32] pinned
+  hipEvent_t ev_lam = nullptr;
+  bool mg_lam_pending = false;
   // halo_overlap: the exchange of a product's operand runs on comm_stream while the rows that need no ghost value
   // are computed; 0 off (one launch after the exchange), 1 overlapped, 2 the same three launches without overlap
   hipStream_t comm_stream = nullptr;
@@ -605,6 +615,7 @@ int pph_cg_jacobi(pph_ctx* ctx, const Csr& A, const double* b, double* x, const 
                   int max_it, double* r, double* z, double* p, double* q, int* its);
 // multigrid (pph_mg.hip)
 int mg_setup(pph_ctx* ctx);
+int mg_lam_host(pph_ctx* ctx);   // host copies of the levels' spectral bounds (waits for the read-back if it is still on its way)
 // Jacobi-CG of a stencil-ELL operator of at most 4096 rows inside ONE workgroup (the coarsest multigrid level's kernel;
 // also the reference's LU blocks on plumbing-size meshes): x = A^-1 b to rtol, zero guess; r, p, q: work vectors of n
 void mg_onchip_cg(pph_ctx* ctx, const Sell& E, const double* dinv, const double* b, double* x, double* r, double* p, double* q,

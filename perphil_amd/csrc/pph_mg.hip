@@ -406,6 +406,16 @@ __global__ void k_cheb_step(double* __restrict__ x, double* __restrict__ d, doub
   }
 }
 
+// smoother weight 1 / (0.5 (hi + lo)), lo = MG_CHEB_LOWER hi, of every level and field from the bounds' bit patterns - the
+// arithmetic of cheb_w below, every operation rounded by itself (no contraction: the host's value bit for bit)
+__global__ void k_mg_weights(const unsigned long long* __restrict__ bits, double* __restrict__ w, int count) {
+  for (int i = threadIdx.x; i < count; i += blockDim.x) {
+    const double hi = __longlong_as_double((long long)bits[i]);
+    const double lo = __dmul_rn(MG_CHEB_LOWER, hi);
+    w[i] = __ddiv_rn(1.0, __dmul_rn(0.5, __dadd_rn(hi, lo)));
+  }
+}
+
 static inline double cheb_w(const MgLevel& L, int which) {
   const double hi = L.lam[which], lo = MG_CHEB_LOWER * hi;
   return 1.0 / (0.5 * (hi + lo));
@@ -526,10 +536,11 @@ int mg_setup(pph_ctx* ctx) {
   }
   if (build) ctx->mg.resize(nlev);
   PPH_REQUIRE(ctx, (int)ctx->mg.size() == nlev, "multigrid hierarchy out of date");
-  DevBuf<unsigned long long> lamdev;
+  DevBuf<unsigned long long>& lamdev = ctx->mg_lam;
   DevBuf<double> mtmp;
-  PPH_TRY(lamdev.alloc(ctx, (size_t)(2 * nlev)));   // spectral bounds of all levels: read back once after the loop
-  PPH_HIP(ctx, hipMemsetAsync(lamdev.p, 0, 2 * nlev * sizeof(unsigned long long), ctx->stream));
+  PPH_REQUIRE(ctx, nlev <= 32, "more than 32 multigrid levels");
+  if (lamdev.n < (size_t)(2 * nlev)) PPH_TRY(lamdev.alloc(ctx, (size_t)64));   // spectral bounds of all levels (kept across assemblies)
+  la_set(ctx, reinterpret_cast<double*>(lamdev.p), 0.0, 2 * nlev);
   const double coefK[2] = {ctx->a, ctx->c};
   // operator format of the levels: stencil-ELL (default) or CSR; the fp32 option keeps CSR values
   const bool use_ell = ctx->op_format == 1 && !ctx->mg_fp32;
@@ -649,8 +660,7 @@ int mg_setup(pph_ctx* ctx) {
       // the fused assembly already produced the fine-level diagonal inverses and bounds
       for (int f = 0; f < 2; ++f)
         la_copy(ctx, L.dinv[f].p, ctx->dinv0[f].p, L.n);
-      PPH_HIP(ctx, hipMemcpyAsync(lamdev.p + 2 * l, ctx->lam0.p, 2 * sizeof(unsigned long long),
-                                  hipMemcpyDeviceToDevice, ctx->stream));
+      la_copy(ctx, reinterpret_cast<double*>(lamdev.p + 2 * l), reinterpret_cast<const double*>(ctx->lam0.p), 2);
     } else if (!level_fused)
     for (int f = 0; f < 2; ++f)
       hipLaunchKernelGGL(k_diag_lam, dim3(mg_grid(L.n * 8)), dim3(256), 0, ctx->stream, L.rowptr, L.col, L.val[f], L.n,
@@ -661,30 +671,24 @@ int mg_setup(pph_ctx* ctx) {
     PPH_TRY(L.t.alloc(ctx, (size_t)L.n));
     if (l == nlev - 1) PPH_TRY(L.w.alloc(ctx, (size_t)L.n));
   }
-  {
-    std::vector<unsigned long long> bits((size_t)(2 * nlev));
-    PPH_HIP(ctx, hipMemcpyAsync(bits.data(), lamdev.p, sizeof(unsigned long long) * bits.size(), hipMemcpyDeviceToHost,
-                                ctx->stream));
-    PPH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    for (int l = 0; l < nlev; ++l) {
-      MgLevel& L = ctx->mg[l];
-      for (int f = 0; f < 2; ++f) {
-        double v;
-        memcpy(&v, &bits[(size_t)(2 * l + f)], sizeof(double));
-        if (dist && !L.replicated) PPH_TRY(comm_max_double(ctx, v, &v));
-        L.lam[f] = v;
-        PPH_REQUIRE(ctx, v > 0.0 && v == v, "multigrid level %d: bad spectral bound %g", l, v);
-      }
-    }
-  }
-  // smoother weights of the fused cycle, read by its kernels from device memory
-  ctx->mg_w_host.resize((size_t)(2 * nlev));
-  for (int l = 0; l < nlev; ++l)
-    for (int f = 0; f < 2; ++f) ctx->mg_w_host[(size_t)(2 * l + f)] = cheb_w(ctx->mg[l], f);
+  // Smoother weights of the fused cycle, read by its kernels from device memory - computed ON the device from the bounds
+  // (round 4): the host neither waits for the assembly's kernels here nor uploads anything.  The bounds travel to pinned
+  // host memory behind an event; MgLevel::lam is filled from there when host code needs it (mg_lam_host).  Slabs take the
+  // maximum over the ranks on the host and upload the weights, as before.
   PPH_TRY(ctx->mg_w.alloc(ctx, (size_t)(2 * nlev)));
-  PPH_HIP(ctx, hipMemcpyAsync(ctx->mg_w.p, ctx->mg_w_host.data(), sizeof(double) * ctx->mg_w_host.size(),
-                              hipMemcpyHostToDevice, ctx->stream));
-  lamdev.release();
+  PPH_HIP(ctx, hipMemcpyAsync(ctx->h_lam, lamdev.p, sizeof(unsigned long long) * (size_t)(2 * nlev), hipMemcpyDeviceToHost, ctx->stream));
+  PPH_HIP(ctx, hipEventRecord(ctx->ev_lam, ctx->stream));
+  ctx->mg_lam_pending = true;
+  if (dist) {
+    PPH_TRY(mg_lam_host(ctx));
+    ctx->mg_w_host.resize((size_t)(2 * nlev));
+    for (int l = 0; l < nlev; ++l)
+      for (int f = 0; f < 2; ++f) ctx->mg_w_host[(size_t)(2 * l + f)] = cheb_w(ctx->mg[l], f);
+    PPH_HIP(ctx, hipMemcpyAsync(ctx->mg_w.p, ctx->mg_w_host.data(), sizeof(double) * ctx->mg_w_host.size(),
+                                hipMemcpyHostToDevice, ctx->stream));
+  } else {
+    hipLaunchKernelGGL(k_mg_weights, dim3(1), dim3(64), 0, ctx->stream, lamdev.p, ctx->mg_w.p, 2 * nlev);
+  }
   mtmp.release();
   PPH_HIP(ctx, hipGetLastError());
   if (build) ctx->mg_epoch++;
@@ -694,9 +698,38 @@ int mg_setup(pph_ctx* ctx) {
   return PPH_OK;
 }
 
+int mg_lam_host(pph_ctx* ctx) {
+  if (!ctx->mg_lam_pending) return PPH_OK;
+  PPH_HIP(ctx, hipEventSynchronize(ctx->ev_lam));
+  ctx->mg_lam_pending = false;
+  const bool dist = ctx->world > 1;
+  const int nlev = (int)ctx->mg.size();
+  for (int l = 0; l < nlev; ++l) {
+    MgLevel& L = ctx->mg[l];
+    for (int f = 0; f < 2; ++f) {
+      double v;
+      memcpy(&v, &ctx->h_lam[(size_t)(2 * l + f)], sizeof(double));
+      if (dist && !L.replicated) PPH_TRY(comm_max_double(ctx, v, &v));
+      L.lam[f] = v;
+      PPH_REQUIRE(ctx, v > 0.0 && v == v, "multigrid level %d: bad spectral bound %g", l, v);
+    }
+  }
+  return PPH_OK;
+}
+
 // `steps` Chebyshev-Jacobi steps on A x = b.  zero_guess: x is overwritten, no initial SpMV.
 static void chebyshev(pph_ctx* ctx, MgLevel& L, int which, const double* b, double* x, int steps, bool zero_guess) {
   const Csr A = level_csr(ctx, L, which, true);
+  if (steps == 1 && ctx->world == 1) {
+    // one step = a weighted Jacobi sweep: the weight is read from the device array (no host copy of the bound needed)
+    double* r1 = L.r.p;
+    const double* r01 = b;
+    if (!zero_guess) { la_spmv_resid(ctx, A, x, b, r1); r01 = r1; }
+    hipLaunchKernelGGL(k_cheb_init, dim3(mg_grid(L.n)), dim3(256), 0, ctx->stream, x, L.d.p, r01, L.dinv[which].p, 0.0,
+                       zero_guess ? 1 : 0, 0, L.n, cheb_wp(ctx, (int)(&L - ctx->mg.data()), which));
+    return;
+  }
+  if (mg_lam_host(ctx) != PPH_OK) return;
   const double hi = L.lam[which], lo = MG_CHEB_LOWER * hi;
   const double theta = 0.5 * (hi + lo), delta = 0.5 * (hi - lo);
   const double sigma = theta / delta;

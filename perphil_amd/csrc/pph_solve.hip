@@ -951,6 +951,7 @@ int pph_solve_device(pph_ctx* ctx, const pph_solver_cfg* cfg, pph_solve_info* in
   ctx->t_solve = ms;
   la_harvest_spmv_times(ctx);
   PPH_TRY(sell_dict_poll(ctx));   // a dictionary refused by its per-assembly check on the device is retired on the host too
+  if (ctx->mg_lam_pending) PPH_TRY(mg_lam_host(ctx));   // (the bounds arrived long ago: this only checks them - a bad one is an error, not a diverged solve)
   PPH_HIP(ctx, hipGetLastError());
   if (info) *info = inf;
   if (ctx->comm_status != PPH_OK) { ctx->err = ctx->comm_error; return ctx->comm_status; }
