@@ -662,6 +662,13 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
   }
   if (!strcmp(name, "sell_dict_cap")) { ctx->sell_dict_cap = (int)value; return PPH_OK; }
   if (!strcmp(name, "sell_dict_walk")) { ctx->sell_dict_walk = value != 0; la_release_graphs(ctx); return PPH_OK; }
+  if (!strcmp(name, "transfer_bench")) {
+    // diagnostic (tools/r4_transfer_probe.py): times the fine-level transfer kernels, result on stderr
+    double t[2] = {0.0, 0.0};
+    PPH_TRY(mg_transfer_bench(ctx, 0, value > 0 ? (int)value : 50, t));
+    fprintf(stderr, "transfer_bench: interpolation %.4f ms, restriction %.4f ms per launch\n", t[0], t[1]);
+    return PPH_OK;
+  }
   if (!strcmp(name, "sell_dict_zconst")) { ctx->sell_dict_zconst = value != 0; la_release_graphs(ctx); return PPH_OK; }
   if (!strcmp(name, "sell_dict_poison")) {
     // tests: mark the dictionaries of the fine blocks as failed ON THE DEVICE only, as a failed re-assembly check would -

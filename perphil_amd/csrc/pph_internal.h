@@ -615,7 +615,8 @@ int pph_cg_jacobi(pph_ctx* ctx, const Csr& A, const double* b, double* x, const 
                   int max_it, double* r, double* z, double* p, double* q, int* its);
 // multigrid (pph_mg.hip)
 int mg_setup(pph_ctx* ctx);
-int mg_lam_host(pph_ctx* ctx);   // host copies of the levels' spectral bounds (waits for the read-back if it is still on its way)
+int mg_lam_host(pph_ctx* ctx);
+int mg_transfer_bench(pph_ctx* ctx, int which, int reps, double* out2);   // diagnostic: ms per launch of the fine-level interpolation / restriction   // host copies of the levels' spectral bounds (waits for the read-back if it is still on its way)
 // Jacobi-CG of a stencil-ELL operator of at most 4096 rows inside ONE workgroup (the coarsest multigrid level's kernel;
 // also the reference's LU blocks on plumbing-size meshes): x = A^-1 b to rtol, zero guess; r, p, q: work vectors of n
 void mg_onchip_cg(pph_ctx* ctx, const Sell& E, const double* dinv, const double* b, double* x, double* r, double* p, double* q,

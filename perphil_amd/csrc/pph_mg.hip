@@ -284,6 +284,8 @@ __global__ __launch_bounds__(256) void k_prolong_to_q1(double* __restrict__ xout
     double x0, x1 = 0.0;
     if (has1) sell_ld2(xf + id0, x0, x1); else x0 = xf[id0];   // (16-byte accesses per pair: pph_internal.h)
     const uint8_t m0 = mf[id0], m1 = has1 ? mf[id0 + 1] : 1;
+    // (round 4, measured with option transfer_bench: taking the right column from the next lane by a DPP wave shift - four
+    // loads instead of eight - leaves the kernel at 0.096 ms; a probe that also drops the odd node's arithmetic reaches 0.075)
     const double a00 = xc[c], b00 = xc[c + ex], a10 = xc[c + ey], b10 = xc[c + ey + ex];
     const double a01 = xc[c + ez], b01 = xc[c + ez + ex], a11 = xc[c + ez + ey], b11 = xc[c + ez + ey + ex];
     double s0, s1;
@@ -448,6 +450,32 @@ static TGeom tgeom(const MgLevel& F, const MgLevel& C) {
   g.pxf = F.px; g.pyf = F.py; g.pzf = F.pz; g.gzf = F.gz0;
   g.own_lo_f = F.own_lo; g.own_hi_f = F.own_hi;
   return g;
+}
+
+// isolated timing of the fine-level transfer kernels (hexahedra; tools/r4_transfer_probe.py): reps launches each of the
+// interpolation t = x + P x_c (levels 0 <- 1) and of the restriction b_c = R r (+ the coarse pre-smoothing), ms per launch
+int mg_transfer_bench(pph_ctx* ctx, int which, int reps, double* out2) {
+  PPH_REQUIRE(ctx, ctx->mg_ok && ctx->mg.size() >= 2 && ctx->mesh.kind == PPH_CELL_HEX, "transfer bench: needs a hexahedral hierarchy");
+  MgLevel& L = ctx->mg[0];
+  MgLevel& C = ctx->mg[1];
+  const TGeom tg = tgeom(L, C);
+  float ms = 0.f;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int i = 0; i < reps + 5; ++i) {
+      if (i == 5) PPH_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+      if (pass == 0)
+        hipLaunchKernelGGL(k_prolong_to_q1, dim3(mg_grid((L.n + 1) / 2 + L.py * L.pz)), dim3(256), 0, ctx->stream, L.t.p, L.d.p, C.x.p,
+                           L.maskp[which], tg);
+      else
+        hipLaunchKernelGGL(k_restrict_q1<3>, dim3(mg_grid(C.n)), dim3(256), 0, ctx->stream, C.b.p, L.r.p, C.maskp[which],
+                           L.maskp[which], tg, C.x.p, C.dinv[which].p, cheb_wp(ctx, 1, which), C.rfast[which].p);
+    }
+    PPH_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    PPH_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    PPH_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    out2[pass] = (double)ms / reps;
+  }
+  return PPH_OK;
 }
 
 void mg_release(pph_ctx* ctx) {
