@@ -436,6 +436,7 @@ def main():
     from perphil_amd import _ffi
 
     dist = None
+    rehearsal = None
     device = local_rank
     if world > 1:
         import torch.distributed as dist  # noqa: F811
@@ -443,6 +444,11 @@ def main():
         # "nccl" is RCCL on ROCm.  PERPHIL_DIST_BACKEND=gloo rehearses the multi-rank path on a box with
         # fewer GPUs than ranks (ranks then share devices; communication is staged through the host).
         backend = os.environ.get("PERPHIL_DIST_BACKEND", "nccl")
+        if backend == "nccl" and torch.cuda.device_count() < world:
+            # fewer GPUs than ranks: RCCL refuses two ranks on one device ("Duplicate GPU detected") - rehearse over gloo
+            # instead of failing without a line; config.transport says "torch-gloo", config.rehearsal why
+            backend = "gloo"
+            rehearsal = f"{world} ranks on {torch.cuda.device_count()} GPU(s): gloo transport, ranks share devices - timings are not a scaling measurement"
         device = local_rank % max(torch.cuda.device_count(), 1)
         torch.cuda.set_device(device)
         if backend == "nccl":
@@ -741,7 +747,7 @@ def main():
             "context_ms": round(context_ms, 2),
             "operator_format": ((("row dictionary (%d distinct rows) over " % dict_classes) if dicton else "")
                                 + ("stencil-ELL, symmetric storage" if sym else "stencil-ELL")) if sell else "CSR",
-            "transport": transport, "ranks_seen": int(ranks_seen), "rccl_native_error": rccl_error,
+            "transport": transport, "ranks_seen": int(ranks_seen), "rccl_native_error": rccl_error, "rehearsal": rehearsal,
             "comm": comm,
             "allreduces_per_step": int(cs["allreduces"]),
             "halo_overlap": int(args.halo_overlap), "split_products_per_step": int(tm.get("split_products", 0)),
