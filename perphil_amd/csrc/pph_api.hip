@@ -662,6 +662,7 @@ int pph_set_option(pph_ctx* ctx, const char* name, double value) {
   }
   if (!strcmp(name, "sell_dict_cap")) { ctx->sell_dict_cap = (int)value; return PPH_OK; }
   if (!strcmp(name, "sell_dict_walk")) { ctx->sell_dict_walk = value != 0; la_release_graphs(ctx); return PPH_OK; }
+  if (!strcmp(name, "fold_finals")) { ctx->fold_finals = value != 0.0 ? 1 : 0; la_release_graphs(ctx); return PPH_OK; }
   if (!strcmp(name, "transfer_bench")) {
     // diagnostic (tools/r4_transfer_probe.py): times the fine-level transfer kernels, result on stderr
     double t[2] = {0.0, 0.0};

@@ -294,6 +294,11 @@ struct pph_ctx {
   // the fused assembly's own event pair: pph_assemble_dpp returns without waiting, pph_get_timers resolves the time (round 4)
   hipEvent_t ev_asm0 = nullptr, ev_asm1 = nullptr;
   bool asm_time_pending = false;
+  // a final reduction left to its consumer (round 4, single context): the CG update sums the p.Ap partials itself, the
+  // direction update the r.z partials of the cycle's last kernel - two launches less per CG iteration (la_defer_final)
+  struct PendFinal { const double* part = nullptr; int n = 0, slot = -1, copy_src = -1, copy_dst = -1; bool valid = false; } pend;
+  bool defer_next_final = false;     // the next la_spmv_jacobi with a dot slot leaves its final reduction pending
+  int fold_finals = 1;               // option "fold_finals" 
   // spectral bounds of the multigrid levels (bit patterns): device array kept across assemblies, read back into pinned host
   // memory WITHOUT a synchronisation - the smoother weights are computed on the device (k_mg_weights); the host copies
   // (MgLevel::lam) are filled when something on the host asks for them (mg_lam_host: multi-step Chebyshev, slabs)
@@ -503,7 +508,10 @@ void la_spmv_jacobi(pph_ctx* ctx, const Csr& A, const double* x, const double* b
                     bool x_ghosts_valid = false);
 // y = A x and partial sums of dot(x, y) -> scal slot
 // (copy_src >= 0: scal[copy_dst] = scal[copy_src] is done by the final reduction's single workgroup)
-void la_spmv_dot(pph_ctx* ctx, const Csr& A, const double* x, double* y, int slot, int copy_src = -1, int copy_dst = -1);
+// defer: the final reduction of the partial sums is left pending for the kernel that consumes the scalar (la_cg_update_dev;
+// any other call that needs it launches it: la_flush_final)
+void la_spmv_dot(pph_ctx* ctx, const Csr& A, const double* x, double* y, int slot, int copy_src = -1, int copy_dst = -1, bool defer = false);
+void la_flush_final(pph_ctx* ctx);
 void la_spmv_dot3(pph_ctx* ctx, const Csr& A, const double* x, const double* r, double* y, int slot, int copy_src = -1,
                   int copy_dst = -1);   // + r.y and y.y in slot + 1, slot + 2 (stencil-ELL operators)
 // publication of scal[slot .. slot + count) to the host mirror (enqueue) / wait for the last publication

@@ -35,6 +35,20 @@ __device__ inline double block_sum(double v, double* lds) {
   return v;
 }
 
+// the sum k_reduce_final forms of n partial sums (same order: thread-strided, then block_sum), in EVERY thread of a 256-thread
+// block: kernels that only need the scalar a final reduction would produce compute it themselves (one launch less)
+__device__ inline double block_total_of_partials(const double* __restrict__ part, int n, double* lds) {
+  double v = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) v += part[i];
+  v = block_sum(v, lds);
+  __syncthreads();
+  if (threadIdx.x == 0) lds[0] = v;
+  __syncthreads();
+  v = lds[0];
+  __syncthreads();
+  return v;
+}
+
 // sum over groups of 8 consecutive lanes with DPP row shifts (no LDS crossbar): lane 0 of each group gets
 // the group total
 template <int CTRL>
@@ -373,6 +387,17 @@ void la_harvest_spmv_times(pph_ctx* ctx) {
   ctx->ev_used = 0;
 }
 
+// launches a pending final reduction the way its producer would have (nobody folded it into a consumer)
+void la_flush_final(pph_ctx* ctx) {
+  if (!ctx->pend.valid) return;
+  const pph_ctx::PendFinal f = ctx->pend;
+  ctx->pend.valid = false;
+  hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, ctx->stream, f.part, f.n, ctx->scal.p + f.slot,
+                     f.copy_src >= 0 ? (const double*)(ctx->scal.p + f.copy_src) : (const double*)nullptr,
+                     f.copy_src >= 0 ? ctx->scal.p + f.copy_dst : (double*)nullptr);
+}
+static inline bool la_can_fold(const pph_ctx* ctx) { return ctx->fold_finals && ctx->world == 1; }
+
 void la_reset_spmv_stats(pph_ctx* ctx) {
   la_harvest_spmv_times(ctx);
   for (int v = 0; v < 2; ++v) { ctx->t_spmv[v] = 0; ctx->spmv_bytes[v] = 0; ctx->n_spmv[v] = 0; }
@@ -396,8 +421,15 @@ void la_spmv_jacobi(pph_ctx* ctx, const Csr& A, const double* x, const double* b
                     double* y, int dot_slot, int64_t dlo, int64_t dhi, bool x_ghosts_valid) {
   const int grid = spmv_dispatch<false>(ctx, A, x, b, y, dot_slot >= 0 ? partials(ctx) : nullptr, dinv, w, dot_slot >= 0,
                                         dlo, dhi, x_ghosts_valid);
-  if (dot_slot >= 0)
+  if (dot_slot >= 0) {
+    if (ctx->defer_next_final && la_can_fold(ctx)) {
+      ctx->defer_next_final = false;
+      ctx->pend.part = partials(ctx); ctx->pend.n = grid; ctx->pend.slot = dot_slot; ctx->pend.copy_src = ctx->pend.copy_dst = -1;
+      ctx->pend.valid = true;
+      return;
+    }
     hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, ctx->stream, partials(ctx), grid, ctx->scal.p + dot_slot);
+  }
 }
 
 void la_spmv_shift(pph_ctx* ctx, const Csr& A, const double* x, const double* b, double* R, double* told, double* tmp,
@@ -444,13 +476,19 @@ void la_spmv_dot3(pph_ctx* ctx, const Csr& A, const double* x, const double* r, 
                      copy_src >= 0 ? ctx->scal.p + copy_dst : (double*)nullptr);
 }
 
-void la_spmv_dot(pph_ctx* ctx, const Csr& A, const double* x, double* y, int slot, int copy_src, int copy_dst) {
+void la_spmv_dot(pph_ctx* ctx, const Csr& A, const double* x, double* y, int slot, int copy_src, int copy_dst, bool defer) {
+  la_flush_final(ctx);
   double* part = partials(ctx);
   // the sum runs over the owned rows (slabs: ghost rows are empty in CSR / full stencil-ELL storage, but not in symmetric storage)
   const Seg sg = pph_owned_seg(A.geom, A.nrows);
   const bool two = sg.len2 > 0;   // field-major mixed vector: two owned segments - only operators with empty ghost rows get here
   const int grid = spmv_dispatch<true>(ctx, A, x, nullptr, y, part, nullptr, nullptr, false, two ? 0 : sg.off1,
                                        two ? A.nrows : sg.off1 + sg.len1);
+  if (defer && la_can_fold(ctx)) {
+    ctx->pend.part = part; ctx->pend.n = grid; ctx->pend.slot = slot; ctx->pend.copy_src = copy_src; ctx->pend.copy_dst = copy_dst;
+    ctx->pend.valid = true;
+    return;
+  }
   hipLaunchKernelGGL(k_reduce_final, dim3(1), dim3(256), 0, ctx->stream, part, grid, ctx->scal.p + slot,
                      copy_src >= 0 ? (const double*)(ctx->scal.p + copy_src) : (const double*)nullptr,
                      copy_src >= 0 ? ctx->scal.p + copy_dst : (double*)nullptr);
@@ -733,6 +771,7 @@ __global__ __launch_bounds__(64) void k_publish(const double* __restrict__ src, 
 }
 
 void la_publish(pph_ctx* ctx, int slot, int count) {
+  la_flush_final(ctx);
   ++ctx->pub_seq;
   hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, ctx->stream, ctx->scal.p + slot, ctx->h_scal_dev + slot, count,
                      ctx->h_seq_dev, ctx->pub_ctr.p);
@@ -763,6 +802,7 @@ int la_wait_published(pph_ctx* ctx) {
 }
 
 static int fetch_to_host(pph_ctx* ctx, int slot, int count) {
+  la_flush_final(ctx);
   if (!ctx->fetch_spin) {
     PPH_HIP(ctx, hipMemcpyAsync(ctx->h_scal + slot, ctx->scal.p + slot, sizeof(double) * (size_t)count,
                                 hipMemcpyDeviceToHost, ctx->stream));
@@ -838,14 +878,25 @@ int la_fetch_raw(pph_ctx* ctx, int slot, int count) {
 // the first kernel of the next preconditioner application, which then starts at its residual product)
 __global__ __launch_bounds__(256) void k_cg_update_dev(double* __restrict__ x, double* __restrict__ r,
                                                        const double* __restrict__ p, const double* __restrict__ q,
-                                                       const double* __restrict__ num, const double* __restrict__ den,
+                                                       const double* num, const double* __restrict__ den,
                                                        int64_t n, Seg sg, double* __restrict__ part,
                                                        double* __restrict__ z0, const double* __restrict__ dinv0,
-                                                       const double* __restrict__ w0p, double* bad) {
+                                                       const double* __restrict__ w0p, double* bad,
+                                                       const double* __restrict__ den_part, int den_n, double* den_out,
+                                                       const double* rot_src, double* rot_dst) {
   __shared__ double lds[4];
+  // den_part: the denominator's final reduction was left to this kernel - every block sums the partial sums (k_reduce_final's
+  // order), block 0 leaves the result (and the rotated r.z) where the host's publication and the next kernels read them
+  double dn;
+  if (den_part) {
+    dn = block_total_of_partials(den_part, den_n, lds);
+    if (rot_src) num = rot_src;             // r.z (current) := r.z (new): read from the source, written once below
+    if (blockIdx.x == 0 && threadIdx.x == 0) { *den_out = dn; if (rot_dst) *rot_dst = *rot_src; }
+  } else {
+    dn = *den;
+  }
   // p.Ap = 0 or not a number (a zero block residual, a breakdown): no update instead of NaNs in x and r, and a count in
   // *bad for the host - the launch-only sweeps (cg_solve_fixed) see no scalar of this solve otherwise
-  const double dn = *den;
   const bool okd = dn > 0.0 || dn < 0.0;
   const double alpha = okd ? *num / dn : 0.0;
   if (bad && !okd && blockIdx.x == 0 && threadIdx.x == 0) *bad += 1.0;
@@ -868,8 +919,19 @@ bool la_cg_update_dev(pph_ctx* ctx, double* x, double* r, const double* p, const
   double* part = partials(ctx);
   int grid = ew_grid(n);
   if (grid > RED_BLOCKS) grid = RED_BLOCKS;
+  // a pending final reduction of the denominator is folded into this kernel (its own partial sums then go to another area)
+  const double* den_part = nullptr; int den_n = 0; double* den_out = nullptr; const double* rot_src = nullptr; double* rot_dst = nullptr;
+  if (ctx->pend.valid && ctx->pend.slot == slot_den && (ctx->pend.copy_src < 0 || ctx->pend.copy_dst == slot_num)) {
+    den_part = ctx->pend.part; den_n = ctx->pend.n; den_out = ctx->scal.p + slot_den;
+    if (ctx->pend.copy_src >= 0) { rot_src = ctx->scal.p + ctx->pend.copy_src; rot_dst = ctx->scal.p + ctx->pend.copy_dst; }
+    ctx->pend.valid = false;
+    part = partials(ctx) + 8 * PART_STRIDE;
+  } else {
+    la_flush_final(ctx);
+  }
   hipLaunchKernelGGL(k_cg_update_dev, dim3(grid), dim3(256), 0, ctx->stream, x, r, p, q, ctx->scal.p + slot_num,
-                     ctx->scal.p + slot_den, n, sg, part, z0, dinv0, w0, slot_bad >= 0 ? ctx->scal.p + slot_bad : (double*)nullptr);
+                     ctx->scal.p + slot_den, n, sg, part, z0, dinv0, w0, slot_bad >= 0 ? ctx->scal.p + slot_bad : (double*)nullptr,
+                     den_part, den_n, den_out, rot_src, rot_dst);
   if (pub_count > 0 && ctx->fetch_spin && (ctx->world == 1 || ctx->comm_suspended)) {
     // the caller publishes right after this update (la_publish semantics): reduce and publish in one launch
     ++ctx->pub_seq;
@@ -882,16 +944,33 @@ bool la_cg_update_dev(pph_ctx* ctx, double* x, double* r, const double* p, const
 }
 
 // p = z + beta p with beta = *num / *den read on the device
-__global__ void k_p_update_dev(double* __restrict__ p, const double* __restrict__ z, const double* __restrict__ num,
-                               const double* __restrict__ den, int64_t n) {
+__global__ __launch_bounds__(256) void k_p_update_dev(double* __restrict__ p, const double* __restrict__ z, const double* __restrict__ num,
+                               const double* __restrict__ den, int64_t n, const double* __restrict__ num_part, int num_n,
+                               double* num_out) {
+  __shared__ double lds[4];
   const double dn = *den;
-  const double beta = (dn > 0.0 || dn < 0.0) ? *num / dn : 0.0;   // (r.z = 0: restart the direction, see k_cg_update_dev)
+  // num_part: the numerator's final reduction (r.z of the cycle's last kernel) was left to this kernel
+  double nm;
+  if (num_part) {
+    nm = block_total_of_partials(num_part, num_n, lds);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *num_out = nm;
+  } else {
+    nm = *num;
+  }
+  const double beta = (dn > 0.0 || dn < 0.0) ? nm / dn : 0.0;   // (r.z = 0: restart the direction, see k_cg_update_dev)
   EW_LOOP(i, n) p[i] = z[i] + beta * p[i];
 }
 
 void la_p_update_dev(pph_ctx* ctx, double* p, const double* z, int slot_num, int slot_den, int64_t n) {
+  const double* num_part = nullptr; int num_n = 0; double* num_out = nullptr;
+  if (ctx->pend.valid && ctx->pend.slot == slot_num && ctx->pend.copy_src < 0) {
+    num_part = ctx->pend.part; num_n = ctx->pend.n; num_out = ctx->scal.p + slot_num;
+    ctx->pend.valid = false;
+  } else {
+    la_flush_final(ctx);
+  }
   hipLaunchKernelGGL(k_p_update_dev, dim3(ew_grid(n)), dim3(256), 0, ctx->stream, p, z, ctx->scal.p + slot_num,
-                     ctx->scal.p + slot_den, n);
+                     ctx->scal.p + slot_den, n, num_part, num_n, num_out);
 }
 
 int la_fetch(pph_ctx* ctx, int slot, int count) {

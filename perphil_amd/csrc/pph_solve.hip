@@ -156,7 +156,7 @@ static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double*
         la_cg_update_dev(ctx, x, r, p, q, sRZc, sE, n, sE + 3, sg, pre.on ? z : nullptr, pre.dinv, pre.w);   // (its r.r: local, summed with the next product's)
         return PPH_OK;
       }
-      la_spmv_dot(ctx, A, p, q, sPQ, rotate ? sRZn : -1, sRZc);
+      la_spmv_dot(ctx, A, p, q, sPQ, rotate ? sRZn : -1, sRZc, true);   // (its final reduction: inside the update kernel)
       PPH_TRY(la_reduce_device(ctx, sPQ, 1));
       // x += alpha p ; r -= alpha q ; r.r (and the next cycle's pre-smoothed first guess into z)
       published = la_cg_update_dev(ctx, x, r, p, q, sRZc, sPQ, n, sRR, sg, pre.on ? z : nullptr, pre.dinv, pre.w, -1,
@@ -165,7 +165,9 @@ static int cg_solve_natural(pph_ctx* ctx, const Csr& A, const double* b, double*
       return PPH_OK;
     };
     auto half_direction = [&]() -> int {
+      ctx->defer_next_final = true;    // (r.z of the cycle's last kernel: summed inside the direction update)
       pc_and_rz(z, sRZn, pre.on);
+      ctx->defer_next_final = false;
       PPH_TRY(la_reduce_device(ctx, sRZn, 1));
       la_p_update_dev(ctx, p, z, sRZn, sRZc, n);                          // p = z + (r.z_new / r.z) p
       return PPH_OK;
