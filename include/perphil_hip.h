@@ -323,7 +323,11 @@ int pph_get_timers(pph_ctx* ctx, double* out, int n);
  *                        products on hexahedra keep the x window in registers (k_spmv_dict_walk), "sell_dict_blocks"
  *                        [1024] their grid, "sell_dict_zconst" [1]: where the class of an in-plane position is the same on all
  *                        interior planes (verified on the class array at the build) a step takes its classes from the step
- *                        below instead of loading them; 0 takes effect at once, 1 at the next assembly */
+ *                        below instead of loading them; 0 takes effect at once, 1 at the next assembly
+ *   "fold_finals" [1]    single context: the final reductions of p.Ap and of the multigrid cycle's r.z are summed inside the
+ *                        kernels that consume them instead of by launches of their own (same sums, same order)
+ *   "transfer_bench"     diagnostic: times `value` launches of the fine-level interpolation / restriction kernels of an existing
+ *                        hexahedral hierarchy and prints the result on stderr (tools/r4_transfer_probe.py) */
 int pph_set_option(pph_ctx* ctx, const char* name, double value);
 
 #ifdef __cplusplus
